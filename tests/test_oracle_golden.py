@@ -1,0 +1,145 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself.
+
+The goldens (tests/golden/*.npz) are outputs of /root/reference's own emulation.py /
+log_posterior.py run in the build container by tests/golden/make_goldens.py.  If the oracle
+reproduces them, it is a faithful restatement and the -m gpu tests may use it as the checker.
+"""
+import numpy as np
+import pytest
+
+import golden_util as GU
+from oracle import gp_oracle as O
+
+SYN = ["g1_rbf_noise", "g1_matern15_noise", "g1_matern25_const_noise", "g1_rbf_only", "g2_rbf_noise"]
+RTOL = 1e-9   # the oracle follows the same arithmetic; observed differences are ~1e-13
+
+
+def relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.mark.parametrize("name", SYN)
+def test_scaler_and_pca_exact_decisions(name):
+    g = GU.load(name)
+    mean, scale, var = O.scaler_fit(g["Y"])
+    np.testing.assert_allclose(mean, g["scaler_mean"], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(scale, g["scaler_scale"], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(var, g["scaler_var"], rtol=1e-13, atol=0)
+    pca = O.pca_fit((g["Y"] - mean) / scale)
+    k = int(g["n_pc"])
+    # integer decisions: bit-exact (sign-decision index of every component the emulator uses)
+    assert np.array_equal(pca["flip_argmax"][:k], g["flip_argmax"][:k])
+    # leading components: same LAPACK driver => agreement to rounding
+    assert relerr(pca["components"][:k], g["pca_components"][:k]) < 1e-10
+    assert relerr(pca["explained_variance"], g["pca_explained_variance"]) < 1e-12
+    assert relerr(pca["explained_variance_ratio"], g["pca_explained_variance_ratio"]) < 1e-12
+    assert relerr(pca["Y_pca"][:, :k], g["Y_pca_truncated"]) < 1e-10
+
+
+@pytest.mark.parametrize("name", SYN)
+def test_fit_at_theta_L_alpha_lml_grad(name):
+    g = GU.load(name)
+    spec = GU.spec_of(g)
+    X, ytr = g["design"], g["Y_pca_truncated"]
+    for j, i in enumerate(g["L_index"]):
+        gp = O.gp_fit_at_theta(X, ytr[:, i], g["theta"][i], spec, float(g["gpr_alpha"]))
+        assert relerr(gp.L, g["L"][j]) < 1e-9
+        # alpha_ = K^-1 y amplifies rounding by cond(K) (up to 1e9 for the noise-free kernel)
+        assert relerr(gp.alpha, g["alpha"][i]) < (1e-5 if not spec.has_noise else 1e-8)
+    for i in range(int(g["n_pc"])):
+        for th, lml_key, grad_key in ((g["theta"][i], "lml_at_theta", "grad_at_theta"),
+                                      (g["theta2"][i], "lml_at_theta2", "grad_at_theta2")):
+            lml, grad = O.lml_and_grad(X, ytr[:, i], th, spec, float(g["gpr_alpha"]))
+            assert abs(lml - g[lml_key][i]) <= 1e-8 * max(1.0, abs(g[lml_key][i]))
+            scale_g = max(1.0, np.max(np.abs(g[grad_key][i])))
+            assert np.max(np.abs(grad - g[grad_key][i])) <= 1e-6 * scale_g
+        assert abs(g["lml_value"][i] - g["lml_at_theta"][i]) <= 1e-8 * max(1, abs(g["lml_value"][i]))
+
+
+@pytest.mark.parametrize("name", SYN + ["g3_realdata_matern15"])
+def test_predict_and_logposterior(name):
+    g = GU.load(name)
+    design = GU.load("observables_fixture")["design"] if name.startswith("g3") else None
+    model = GU.group_model(g, design=design)
+    Xq = g["Xq"]
+    m, v = O.gp_predict_all(Xq, model)
+    assert relerr(m, g["gp_mean"]) < RTOL
+    assert np.max(np.abs(v - g["gp_var"])) < RTOL * max(1.0, np.max(g["gp_var"]))
+    cu = O.cov_unexplained(model)
+    assert relerr(cu, g["cov_unexplained"]) < RTOL
+    pb = O.predict_group(Xq, model)
+    assert relerr(pb["central_value"], g["batch_central_value"]) < RTOL
+    nh = g["batch_cov_head"].shape[0]
+    assert relerr(pb["cov"][:nh], g["batch_cov_head"]) < RTOL
+    for i in range(g["single_central_value"].shape[0]):
+        p1 = O.predict_group(Xq[i:i + 1], model)
+        assert relerr(p1["central_value"][0], g["single_central_value"][i]) < RTOL
+        if i < g["single_cov_head"].shape[0]:
+            assert relerr(p1["cov"][0], g["single_cov_head"][i]) < RTOL
+    lo, hi, ye, yr = g["lo"], g["hi"], g["y_exp"], g["y_err"]
+    per = np.array([O.log_posterior(Xq[i], {"g": model}, lo, hi, ye, yr)[0]
+                    for i in range(g["logpost_per_walker"].shape[0])])
+    np.testing.assert_allclose(per, g["logpost_per_walker"], rtol=1e-8)
+    np.testing.assert_allclose(O.log_posterior(Xq, {"g": model}, lo, hi, ye, yr), g["logpost_batched"], rtol=1e-8)
+    mixed = O.log_posterior(g["X_mixed"], {"g": model}, lo, hi, ye, yr)
+    assert np.array_equal(np.isneginf(mixed), np.isneginf(g["logpost_mixed"]))
+    fin = np.isfinite(mixed)
+    np.testing.assert_allclose(mixed[fin], g["logpost_mixed"][fin], rtol=1e-8)
+    # the /n_samples quirk is real: batched != per-walker
+    assert not np.allclose(g["logpost_batched"][:per.size], g["logpost_per_walker"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", SYN)
+def test_lowrank_form_equals_exact_form(name):
+    g = GU.load(name)
+    model = GU.group_model(g)
+    Xq = g["Xq"]
+    m, v = O.gp_predict_all(Xq, model)
+    st = O.lowrank_setup(model, g["y_exp"], g["y_err"], n_div=1)
+    lr = np.array([O.loglik_lowrank(m[i], v[i], st) for i in range(Xq.shape[0])])
+    np.testing.assert_allclose(lr, g["logpost_per_walker"], rtol=1e-9)
+    stB = O.lowrank_setup(model, g["y_exp"], g["y_err"], n_div=Xq.shape[0])
+    lrB = np.array([O.loglik_lowrank(m[i], v[i], stB) for i in range(Xq.shape[0])])
+    np.testing.assert_allclose(lrB, g["logpost_batched"], rtol=1e-9)
+
+
+def test_multigroup_merge():
+    g = GU.load("g5_multigroup")
+    models = {}
+    for grp in ("g1", "g2"):
+        models[grp] = GU.group_model(g, prefix=grp + "_")
+    mapping = {"A": ("g1", slice(0, 10), slice(0, 10)),
+               "B": ("g2", slice(10, 18), slice(0, 8)),
+               "C": ("g1", slice(18, 30), slice(10, 22))}
+    Xq = g["Xq"]
+    go = {k: O.predict_group(Xq, mdl) for k, mdl in models.items()}
+    merged = O.merge_groups(go, mapping, 30)
+    assert relerr(merged["central_value"], g["merged_central_value"]) < RTOL
+    assert relerr(merged["cov"][:2], g["merged_cov_head"]) < RTOL
+    lp = O.log_posterior(Xq, models, g["lo"], g["hi"], g["y_exp"], g["y_err"], mapping)
+    np.testing.assert_allclose(lp, g["logpost_batched"], rtol=1e-8)
+    per = np.array([O.log_posterior(Xq[i], models, g["lo"], g["hi"], g["y_exp"], g["y_err"], mapping)[0]
+                    for i in range(Xq.shape[0])])
+    np.testing.assert_allclose(per, g["logpost_per_walker"], rtol=1e-8)
+
+
+def test_c3_fixed_theta_golden():
+    """C3 shape (N=1000, F=500, k=10): factors regenerated by the oracle from the seed."""
+    g = GU.load("g4_c3_fixed_theta")
+    model, prob, pca = GU.fixed_theta_model(int(g["N"]), int(g["F"]), int(g["n_pc"]), seed=int(g["seed"]))
+    k = int(g["n_pc"])
+    assert np.array_equal(pca["flip_argmax"][:k], g["flip_argmax"])
+    assert relerr(pca["explained_variance"][:k], g["explained_variance_head"]) < 1e-11
+    assert relerr(np.stack([gp.alpha[:8] for gp in model.gps]), g["alpha_head"]) < 1e-8
+    Xq = g["Xq"]
+    m, v = O.gp_predict_all(Xq, model)
+    assert relerr(m, g["gp_mean"]) < 1e-9
+    assert np.max(np.abs(v - g["gp_var"])) < 1e-9
+    st = O.lowrank_setup(model, g["y_exp"], g["y_err"], n_div=1)
+    lr = np.array([O.loglik_lowrank(m[i], v[i], st) for i in range(Xq.shape[0])])
+    np.testing.assert_allclose(lr, g["logpost_per_walker"], rtol=1e-8)
+    p1 = O.predict_group(Xq[:1], model)
+    assert relerr(p1["central_value"][0], g["single_central_value"][0]) < 1e-9
+    assert relerr(np.diag(p1["cov"][0]), g["single_cov_diag"][0]) < 1e-9
+    assert relerr(p1["cov"][0][0], g["single_cov_row0"][0]) < 1e-9
