@@ -1,0 +1,457 @@
+// C ABI of libgpemu.so (see include/gpemu.h).  Host-side glue only: argument checks, device
+// memory ownership, launch sequencing.  All arithmetic is in the k_*.hip kernels.
+#include <cmath>
+#include <cstdarg>
+
+#include "internal.h"
+#include "linalg_dev.h"
+
+namespace gpemu {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int launch_lik_setup(gpemu_model *m, double *dA, double *dPT, double *dZ, int *dinfo, hipStream_t st);
+int launch_predict_full(gpemu_model *m, int64_t B, double n_div, double *dcv, double *dcov, hipStream_t st);
+int launch_loglik_exact(gpemu_model *m, int64_t B, const double *dXq, double *dout, hipStream_t st);
+
+template <typename T>
+static int dev_alloc(T **p, int64_t n) {
+  *p = nullptr;
+  if (n <= 0) n = 1;
+  GP_HIP(hipMalloc((void **)p, sizeof(T) * (size_t)n));
+  return GPEMU_OK;
+}
+#define GP_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != GPEMU_OK) return rc__; \
+  } while (0)
+
+static int upload(double *dst, const double *src, int64_t n, hipStream_t st) {
+  GP_HIP(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+  return GPEMU_OK;
+}
+
+static void free_workspace(Workspace &w) {
+  hipFree(w.Xq); hipFree(w.KS); hipFree(w.mean_part); hipFree(w.vsq_part);
+  hipFree(w.mean); hipFree(w.var); hipFree(w.logp);
+  w = Workspace();
+}
+
+int ensure_workspace(gpemu_model *m, int64_t B) {
+  Workspace &w = m->ws;
+  int64_t need = round_up(B < 1 ? 1 : B, TILE);
+  if (need <= w.Bcap) return GPEMU_OK;
+  GP_HIP(hipStreamSynchronize(m->stream));
+  free_workspace(w);
+  const int64_t k = m->k;
+  GP_TRY(dev_alloc(&w.Xq, need * DPAD));
+  GP_TRY(dev_alloc(&w.KS, k * m->Npad * need));
+  GP_TRY(dev_alloc(&w.mean_part, k * (m->Npad / JCHUNK) * need));
+  GP_TRY(dev_alloc(&w.vsq_part, k * (m->Npad / TILE) * need));
+  GP_TRY(dev_alloc(&w.mean, need * k));
+  GP_TRY(dev_alloc(&w.var, need * k));
+  GP_TRY(dev_alloc(&w.logp, need));
+  GP_HIP(hipMemsetAsync(w.KS, 0, sizeof(double) * (size_t)(k * m->Npad * need), m->stream));
+  GP_HIP(hipMemsetAsync(w.vsq_part, 0, sizeof(double) * (size_t)(k * (m->Npad / TILE) * need), m->stream));
+  w.Bcap = need;
+  return GPEMU_OK;
+}
+
+// ---- optional per-kernel timing ---------------------------------------------------------------
+static void prof_drain(gpemu_model *m) {
+  // all recorded events must have completed (callers synchronise the stream first)
+  for (int which = 0; which < 2; ++which) {
+    auto &v = which == 0 ? m->ev_trmm : m->ev_kstar;
+    for (auto &pr : v) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, m->ev_pool[pr.first], m->ev_pool[pr.second]) == hipSuccess) {
+        m->prof_ms[which] += ms;
+        m->prof_n[which] += 1;
+      }
+    }
+    v.clear();
+  }
+  m->ev_next = 0;
+}
+
+int prof_mark(gpemu_model *m, hipStream_t st) {
+  if (!m->profiling) return -1;
+  if (m->ev_next >= 8192) {  // bounded pool: fold what we have into the totals and reuse
+    (void)hipStreamSynchronize(st);
+    prof_drain(m);
+  }
+  if (m->ev_next >= m->ev_pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return -1;
+    m->ev_pool.push_back(e);
+  }
+  int idx = (int)m->ev_next++;
+  if (hipEventRecord(m->ev_pool[idx], st) != hipSuccess) return -1;
+  return idx;
+}
+
+void prof_pair(gpemu_model *m, int which, int e0, int e1) {
+  if (!m->profiling || e0 < 0 || e1 < 0) return;
+  (which == 0 ? m->ev_trmm : m->ev_kstar).emplace_back(e0, e1);
+}
+
+static int check_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_error("no HIP device available: libgpemu has no CPU implementation");
+    return GPEMU_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    set_error("device %d out of range (have %d)", device, n);
+    return GPEMU_ERR_ARG;
+  }
+  return GPEMU_OK;
+}
+
+}  // namespace gpemu
+
+namespace gpemu {
+// Log-posterior of B query rows already in the padded [rows >= round_up(B,128)][DPAD] layout
+// (the sampler writes its proposals in that layout).  accumulate != 0 adds to dout (multi-group).
+int logpost_padded(gpemu_model *m, int64_t B, const double *dXq, double *dout, int accumulate,
+                   hipStream_t st) {
+  if (!m->lik_ready) { set_error("gpemu_likelihood_setup has not been called"); return GPEMU_ERR_STATE; }
+  int rc = ensure_workspace(m, B);
+  if (rc == GPEMU_OK) rc = launch_kstar(m, B, dXq, st);
+  if (rc == GPEMU_OK) rc = launch_trmm_vsq(m, B, st);
+  if (rc != GPEMU_OK) return rc;
+  return launch_loglik_lowrank(m, B, dXq, dout, accumulate, st);
+}
+}  // namespace gpemu
+
+using namespace gpemu;
+
+extern "C" {
+
+const char *gpemu_version(void) { return "gpemu 0.1 (gfx950)"; }
+const char *gpemu_last_error(void) { return g_err; }
+
+int gpemu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int gpemu_device_name(int device, char *buf, int64_t buflen) {
+  GP_TRY(check_device(device));
+  GP_ARG(buf && buflen > 0, "buf");
+  hipDeviceProp_t prop;
+  GP_HIP(hipGetDeviceProperties(&prop, device));
+  snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return GPEMU_OK;
+}
+
+int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int64_t F, int64_t k,
+                       int kernel_kind, double nu, int has_const, int has_noise,
+                       const double *X_train, const double *ls, const double *constv,
+                       const double *noise, const double *alpha, const double *L,
+                       const double *components, const double *scaler_mean,
+                       const double *scaler_scale, const double *cov_unexplained) {
+  GP_ARG(out, "out");
+  *out = nullptr;
+  GP_ARG(N > 0 && d > 0 && F > 0 && k > 0, "N, d, F, k must be positive");
+  GP_ARG(d <= DPAD, "d > 8 parameters is not supported by this build");
+  GP_ARG(k <= 64, "k > 64 principal components is not supported by this build");
+  GP_ARG(kernel_kind == GPEMU_KERNEL_RBF || kernel_kind == GPEMU_KERNEL_MATERN, "kernel_kind");
+  if (kernel_kind == GPEMU_KERNEL_MATERN)
+    GP_ARG(nu == 0.5 || nu == 1.5 || nu == 2.5, "Matern nu must be 0.5, 1.5 or 2.5");
+  GP_ARG(X_train && ls && alpha && L && components && scaler_mean && scaler_scale, "null array");
+  GP_ARG(!has_const || constv, "constv");
+  GP_ARG(!has_noise || noise, "noise");
+  GP_TRY(check_device(device));
+  GP_HIP(hipSetDevice(device));
+
+  gpemu_model *m = new gpemu_model();
+  m->device = device;
+  m->N = N; m->d = d; m->F = F; m->k = k;
+  m->Npad = round_up(N, TILE);
+  m->kernel_kind = kernel_kind; m->nu = nu;
+  m->has_const = has_const ? 1 : 0; m->has_noise = has_noise ? 1 : 0;
+  const int64_t Np = m->Npad;
+  int rc = GPEMU_OK;
+  double *dL = nullptr;
+  auto fail = [&](int code) {
+    hipFree(dL);
+    gpemu_model_destroy(m);
+    return code;
+  };
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("hipStreamCreate failed");
+    return fail(GPEMU_ERR_HIP);
+  }
+  hipStream_t st = m->stream;
+
+  // host staging of the small padded arrays
+  std::vector<double> hXs((size_t)(k * Np * DPAD), 0.0), hls((size_t)(k * DPAD), 1.0),
+      hc((size_t)k, 0.0), hkd((size_t)k, 1.0), hal((size_t)(k * Np), 0.0);
+  for (int64_t p = 0; p < k; ++p) {
+    for (int64_t dd = 0; dd < d; ++dd) {
+      double l = ls[p * d + dd];
+      if (!(l > 0.0)) { set_error("length scale must be positive"); return fail(GPEMU_ERR_ARG); }
+      hls[p * DPAD + dd] = l;
+    }
+    for (int64_t j = 0; j < N; ++j)
+      for (int64_t dd = 0; dd < d; ++dd)
+        hXs[(p * Np + j) * DPAD + dd] = X_train[j * d + dd] / ls[p * d + dd];  // skl: X / length_scale
+    if (has_const) { hc[p] = constv[p]; hkd[p] += constv[p]; }
+    if (has_noise) hkd[p] += noise[p];
+    for (int64_t j = 0; j < N; ++j) hal[p * Np + j] = alpha[p * N + j];
+  }
+#define GP_STEP(expr) if ((rc = (expr)) != GPEMU_OK) return fail(rc)
+  GP_STEP(dev_alloc(&m->Xs, k * Np * DPAD));
+  GP_STEP(dev_alloc(&m->ls, k * DPAD));
+  GP_STEP(dev_alloc(&m->constv, k));
+  GP_STEP(dev_alloc(&m->kdiag, k));
+  GP_STEP(dev_alloc(&m->alpha, k * Np));
+  GP_STEP(dev_alloc(&m->Wt, k * Np * Np));
+  GP_STEP(dev_alloc(&m->comp, k * F));
+  GP_STEP(dev_alloc(&m->smean, F));
+  GP_STEP(dev_alloc(&m->sscale, F));
+  GP_STEP(dev_alloc(&m->cunexpl, F * F));
+  GP_STEP(dev_alloc(&dL, k * N * N));
+  GP_STEP(upload(m->Xs, hXs.data(), k * Np * DPAD, st));
+  GP_STEP(upload(m->ls, hls.data(), k * DPAD, st));
+  GP_STEP(upload(m->constv, hc.data(), k, st));
+  GP_STEP(upload(m->kdiag, hkd.data(), k, st));
+  GP_STEP(upload(m->alpha, hal.data(), k * Np, st));
+  GP_STEP(upload(m->comp, components, k * F, st));
+  GP_STEP(upload(m->smean, scaler_mean, F, st));
+  GP_STEP(upload(m->sscale, scaler_scale, F, st));
+  if (cov_unexplained) {
+    GP_STEP(upload(m->cunexpl, cov_unexplained, F * F, st));
+  } else if (hipMemsetAsync(m->cunexpl, 0, sizeof(double) * (size_t)(F * F), st) != hipSuccess) {
+    set_error("hipMemsetAsync failed");
+    return fail(GPEMU_ERR_HIP);
+  }
+  GP_STEP(upload(dL, L, k * N * N, st));
+  GP_STEP(launch_trtri_lower_to_Wt(dL, m->Wt, k, N, Np, st));
+#undef GP_STEP
+  if (hipStreamSynchronize(st) != hipSuccess) {
+    set_error("model_create: device synchronisation failed: %s", hipGetErrorString(hipGetLastError()));
+    return fail(GPEMU_ERR_HIP);
+  }
+  hipFree(dL);
+  *out = m;
+  return GPEMU_OK;
+}
+
+int gpemu_model_destroy(gpemu_model *m) {
+  if (!m) return GPEMU_OK;
+  hipSetDevice(m->device);
+  if (m->stream) hipStreamSynchronize(m->stream);
+  hipFree(m->Xs); hipFree(m->inv_ls); hipFree(m->ls); hipFree(m->constv); hipFree(m->kdiag);
+  hipFree(m->alpha); hipFree(m->Wt); hipFree(m->comp); hipFree(m->smean); hipFree(m->sscale);
+  hipFree(m->cunexpl); hipFree(m->yexp); hipFree(m->yerr); hipFree(m->lo); hipFree(m->hi);
+  hipFree(m->G); hipFree(m->g0); hipFree(m->scal); hipFree(m->exact_scratch);
+  free_workspace(m->ws);
+  for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
+  if (m->stream) hipStreamDestroy(m->stream);
+  delete m;
+  return GPEMU_OK;
+}
+
+int gpemu_model_profile(gpemu_model *m, int enable) {
+  GP_ARG(m, "model");
+  GP_HIP(hipSetDevice(m->device));
+  GP_HIP(hipDeviceSynchronize());
+  prof_drain(m);
+  m->profiling = enable != 0;
+  m->prof_ms[0] = m->prof_ms[1] = 0.0;
+  m->prof_n[0] = m->prof_n[1] = 0;
+  return GPEMU_OK;
+}
+
+int gpemu_model_profile_read(gpemu_model *m, double *ms_total, int64_t *launches) {
+  GP_ARG(m && ms_total && launches, "null pointer");
+  GP_HIP(hipSetDevice(m->device));
+  GP_HIP(hipDeviceSynchronize());
+  prof_drain(m);
+  for (int i = 0; i < 2; ++i) { ms_total[i] = m->prof_ms[i]; launches[i] = m->prof_n[i]; }
+  return GPEMU_OK;
+}
+
+int gpemu_model_dims(const gpemu_model *m, int64_t *N, int64_t *d, int64_t *F, int64_t *k) {
+  GP_ARG(m, "model");
+  if (N) *N = m->N;
+  if (d) *d = m->d;
+  if (F) *F = m->F;
+  if (k) *k = m->k;
+  return GPEMU_OK;
+}
+
+int gpemu_model_device(const gpemu_model *m) { return m ? m->device : GPEMU_ERR_ARG; }
+
+int gpemu_model_sync(gpemu_model *m) {
+  GP_ARG(m, "model");
+  GP_HIP(hipSetDevice(m->device));
+  GP_HIP(hipStreamSynchronize(m->stream));
+  return GPEMU_OK;
+}
+
+// ---- GP predict --------------------------------------------------------------------------------
+static int gp_predict_core(gpemu_model *m, int64_t B, const double *dX, hipStream_t st) {
+  GP_TRY(ensure_workspace(m, B));
+  GP_TRY(launch_pad_queries(m, B, dX, st));
+  GP_TRY(launch_kstar(m, B, m->ws.Xq, st));
+  GP_TRY(launch_trmm_vsq(m, B, st));
+  return GPEMU_OK;
+}
+
+
+int gpemu_gp_predict_dev(gpemu_model *m, int64_t B, const double *dX, double *dmean, double *dvar,
+                         void *stream) {
+  GP_ARG(m && dX && dmean && dvar, "null pointer");
+  GP_ARG(B > 0, "B must be positive");
+  GP_HIP(hipSetDevice(m->device));
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  GP_TRY(gp_predict_core(m, B, dX, st));
+  GP_TRY(launch_reduce_mean_var(m, B, dmean, dvar, st));
+  return GPEMU_OK;
+}
+
+int gpemu_gp_predict(gpemu_model *m, int64_t B, const double *X, double *mean_out, double *var_out) {
+  GP_ARG(m && X && mean_out && var_out, "null pointer");
+  GP_ARG(B > 0, "B must be positive");
+  GP_HIP(hipSetDevice(m->device));
+  hipStream_t st = m->stream;
+  double *dX = nullptr;
+  GP_TRY(ensure_workspace(m, B));
+  GP_TRY(dev_alloc(&dX, B * m->d));
+  int rc = upload(dX, X, B * m->d, st);
+  if (rc == GPEMU_OK) rc = gpemu_gp_predict_dev(m, B, dX, m->ws.mean, m->ws.var, st);
+  if (rc == GPEMU_OK) {
+    hipError_t e = hipMemcpyAsync(mean_out, m->ws.mean, sizeof(double) * B * m->k, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(var_out, m->ws.var, sizeof(double) * B * m->k, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error("gp_predict: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
+  }
+  hipFree(dX);
+  return rc;
+}
+
+// ---- likelihood ----------------------------------------------------------------------------------
+int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_err,
+                           const double *lo, const double *hi, double n_div) {
+  GP_ARG(m && y_exp && y_err && lo && hi, "null pointer");
+  GP_ARG(n_div >= 1.0, "n_div must be >= 1");
+  GP_HIP(hipSetDevice(m->device));
+  hipStream_t st = m->stream;
+  const int64_t F = m->F, k = m->k;
+  if (!m->yexp) {
+    GP_TRY(dev_alloc(&m->yexp, F)); GP_TRY(dev_alloc(&m->yerr, F));
+    GP_TRY(dev_alloc(&m->lo, DPAD)); GP_TRY(dev_alloc(&m->hi, DPAD));
+    GP_TRY(dev_alloc(&m->G, k * k)); GP_TRY(dev_alloc(&m->g0, k)); GP_TRY(dev_alloc(&m->scal, 2));
+  }
+  m->lik_ready = false;
+  m->n_div = n_div;
+  double hlo[DPAD], hhi[DPAD];
+  for (int i = 0; i < DPAD; ++i) { hlo[i] = i < m->d ? lo[i] : -INFINITY; hhi[i] = i < m->d ? hi[i] : INFINITY; }
+  GP_TRY(upload(m->yexp, y_exp, F, st)); GP_TRY(upload(m->yerr, y_err, F, st));
+  GP_TRY(upload(m->lo, hlo, DPAD, st)); GP_TRY(upload(m->hi, hhi, DPAD, st));
+  GP_HIP(hipStreamSynchronize(st));  // hlo/hhi are stack buffers
+  double *dA = nullptr, *dPT = nullptr, *dZ = nullptr;
+  int *dinfo = nullptr;
+  int rc = dev_alloc(&dA, F * F);
+  if (rc == GPEMU_OK) rc = dev_alloc(&dPT, chol_scratch_size(F));
+  if (rc == GPEMU_OK) rc = dev_alloc(&dZ, F * (k + 1));
+  if (rc == GPEMU_OK) rc = dev_alloc(&dinfo, 1);
+  int info = 0;
+  if (rc == GPEMU_OK) rc = launch_lik_setup(m, dA, dPT, dZ, dinfo, st);
+  if (rc == GPEMU_OK) {
+    hipError_t e = hipMemcpyAsync(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error("likelihood_setup: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
+  }
+  hipFree(dA); hipFree(dPT); hipFree(dZ); hipFree(dinfo);
+  if (rc != GPEMU_OK) return rc;
+  if (info != 0) {
+    set_error("likelihood_setup: A = C_unexpl/n o ss^T + diag(y_err^2) is not positive definite (pivot %d)", info);
+    return info;
+  }
+  m->lik_ready = true;
+  return GPEMU_OK;
+}
+
+int gpemu_logpost_dev(gpemu_model *m, int64_t B, const double *dX, double *dout, int mode, void *stream) {
+  GP_ARG(m && dX && dout, "null pointer");
+  GP_ARG(B > 0, "B must be positive");
+  GP_ARG(mode == GPEMU_LOGPOST_LOWRANK || mode == GPEMU_LOGPOST_EXACT, "mode");
+  if (!m->lik_ready) { set_error("gpemu_likelihood_setup has not been called"); return GPEMU_ERR_STATE; }
+  GP_HIP(hipSetDevice(m->device));
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  GP_TRY(gp_predict_core(m, B, dX, st));
+  if (mode == GPEMU_LOGPOST_LOWRANK) return launch_loglik_lowrank(m, B, m->ws.Xq, dout, 0, st);
+  return launch_loglik_exact(m, B, m->ws.Xq, dout, st);
+}
+
+int gpemu_logpost(gpemu_model *m, int64_t B, const double *X, double *out, int mode) {
+  GP_ARG(m && X && out, "null pointer");
+  GP_ARG(B > 0, "B must be positive");
+  GP_HIP(hipSetDevice(m->device));
+  hipStream_t st = m->stream;
+  double *dX = nullptr;
+  GP_TRY(ensure_workspace(m, B));
+  GP_TRY(dev_alloc(&dX, B * m->d));
+  int rc = upload(dX, X, B * m->d, st);
+  if (rc == GPEMU_OK) rc = gpemu_logpost_dev(m, B, dX, m->ws.logp, mode, st);
+  if (rc == GPEMU_OK) {
+    hipError_t e = hipMemcpyAsync(out, m->ws.logp, sizeof(double) * B, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error("logpost: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
+  }
+  hipFree(dX);
+  return rc;
+}
+
+// ---- full predict ----------------------------------------------------------------------------------
+int gpemu_predict_full_dev(gpemu_model *m, int64_t B, const double *dX, double n_div, double *dcv,
+                           double *dcov, void *stream) {
+  GP_ARG(m && dX && dcv && dcov, "null pointer");
+  GP_ARG(B > 0 && n_div >= 1.0, "B, n_div");
+  GP_HIP(hipSetDevice(m->device));
+  hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+  GP_TRY(gp_predict_core(m, B, dX, st));
+  GP_TRY(launch_reduce_mean_var(m, B, m->ws.mean, m->ws.var, st));
+  return launch_predict_full(m, B, n_div, dcv, dcov, st);
+}
+
+int gpemu_predict_full(gpemu_model *m, int64_t B, const double *X, double n_div, double *cv_out,
+                       double *cov_out) {
+  GP_ARG(m && X && cv_out && cov_out, "null pointer");
+  GP_ARG(B > 0, "B must be positive");
+  GP_HIP(hipSetDevice(m->device));
+  hipStream_t st = m->stream;
+  const int64_t F = m->F;
+  double *dX = nullptr, *dcv = nullptr, *dcov = nullptr;
+  GP_TRY(ensure_workspace(m, B));
+  int rc = dev_alloc(&dX, B * m->d);
+  if (rc == GPEMU_OK) rc = dev_alloc(&dcv, B * F);
+  if (rc == GPEMU_OK) rc = dev_alloc(&dcov, B * F * F);
+  if (rc == GPEMU_OK) rc = upload(dX, X, B * m->d, st);
+  if (rc == GPEMU_OK) rc = gpemu_predict_full_dev(m, B, dX, n_div, dcv, dcov, st);
+  if (rc == GPEMU_OK) {
+    hipError_t e = hipMemcpyAsync(cv_out, dcv, sizeof(double) * B * F, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(cov_out, dcov, sizeof(double) * B * F * F, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error("predict_full: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
+  }
+  hipFree(dX); hipFree(dcv); hipFree(dcov);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// Internal declarations shared by the translation units of libgpemu.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/gpemu.h"
+
+namespace gpemu {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+#define GP_HIP(call)                                                                        \
+  do {                                                                                      \
+    hipError_t e__ = (call);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      gpemu::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,    \
+                       __LINE__);                                                           \
+      return GPEMU_ERR_HIP;                                                                 \
+    }                                                                                       \
+  } while (0)
+#define GP_ARG(cond, msg)                \
+  do {                                   \
+    if (!(cond)) {                       \
+      gpemu::set_error("bad argument: %s", msg); \
+      return GPEMU_ERR_ARG;              \
+    }                                    \
+  } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+constexpr int DPAD = 8;        // parameter dimensions padded to 8 (reference uses d = 6 or 7)
+constexpr int TILE = 128;      // row / column tile of the triangular GEMM
+constexpr int JCHUNK = 128;    // training rows per workgroup in the cross-kernel kernel
+
+// ---- device model -----------------------------------------------------------------------------
+struct Workspace {
+  int64_t Bcap = 0;            // padded batch capacity (multiple of TILE)
+  double *Xq = nullptr;        // [Bcap][DPAD]   query points (padded with 0)
+  double *KS = nullptr;        // [k][Npad][Bcap] cross-kernel K_*^T per PC
+  double *mean_part = nullptr; // [k][nchunk][Bcap] partial K_* . alpha
+  double *vsq_part = nullptr;  // [k][nrb][Bcap]    partial ||W k_*||^2 per row block
+  double *mean = nullptr;      // [Bcap][k]
+  double *var = nullptr;       // [Bcap][k]
+  double *logp = nullptr;      // [Bcap]
+};
+
+}  // namespace gpemu
+
+struct gpemu_model {
+  int device = 0;
+  int64_t N = 0, d = 0, F = 0, k = 0;
+  int64_t Npad = 0;            // N rounded up to TILE
+  int kernel_kind = 0;
+  double nu = 0;
+  int has_const = 0, has_noise = 0;
+  hipStream_t stream = nullptr;
+
+  // per-PC GP state on the device
+  double *Xs = nullptr;        // [k][Npad][DPAD]  X_train / ls_p  (padded rows/dims = 0)
+  double *inv_ls = nullptr;    // [k][DPAD]        (unused dims 0) -- kept as ls for exact division
+  double *ls = nullptr;        // [k][DPAD]        length scales (padded dims = 1)
+  double *constv = nullptr;    // [k]
+  double *kdiag = nullptr;     // [k]  kernel_.diag = 1 (+const) (+noise)
+  double *alpha = nullptr;     // [k][Npad] (padded = 0)
+  double *Wt = nullptr;        // [k][Npad][Npad]  Wt[p][j][i] = (L_p^-1)[i][j]  (upper triangular)
+
+  // PCA / scaler
+  double *comp = nullptr;      // [k][F]
+  double *smean = nullptr;     // [F]
+  double *sscale = nullptr;    // [F]
+  double *cunexpl = nullptr;   // [F][F] (zeros if not given)
+
+  // likelihood state (gpemu_likelihood_setup)
+  bool lik_ready = false;
+  double n_div = 1.0;
+  double *yexp = nullptr, *yerr = nullptr, *lo = nullptr, *hi = nullptr;  // [F],[F],[DPAD],[DPAD]
+  double *G = nullptr;         // [k][k]   U^T A^-1 U
+  double *g0 = nullptr;        // [k]      U^T A^-1 r0
+  double *scal = nullptr;      // [2]      q0, logdetA
+
+  // exact-form (validation) scratch: per-workgroup Sigma, panel and residual
+  double *exact_scratch = nullptr;
+  int64_t exact_scratch_size = 0;
+
+  // optional per-kernel timing (gpemu_model_profile): HIP event pairs around the two hot kernels
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;         // reusable events
+  std::vector<std::pair<int, int>> ev_trmm, ev_kstar;  // indices into ev_pool (start, stop)
+  size_t ev_next = 0;
+  double prof_ms[2] = {0.0, 0.0};          // accumulated: [0] trmm_vsq, [1] kstar
+  int64_t prof_n[2] = {0, 0};
+
+  gpemu::Workspace ws;
+};
+
+namespace gpemu {
+int ensure_workspace(gpemu_model *m, int64_t B);
+
+// kernels (launchers; all asynchronous on `st`)
+int launch_trtri_lower_to_Wt(const double *dL, double *dWt, int64_t k, int64_t N, int64_t Npad,
+                             hipStream_t st);
+int launch_kstar(gpemu_model *m, int64_t B, const double *dXq_padded, hipStream_t st);
+int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st);
+int launch_reduce_mean_var(gpemu_model *m, int64_t B, double *dmean, double *dvar, hipStream_t st);
+int launch_pad_queries(gpemu_model *m, int64_t B, const double *dX, hipStream_t st);
+int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq_padded, double *dout,
+                          int accumulate, hipStream_t st);
+int logpost_padded(gpemu_model *m, int64_t B, const double *dXq, double *dout, int accumulate,
+                   hipStream_t st);
+// profiling helpers: record an event on `st` and return its pool index (-1 when profiling is off)
+int prof_mark(gpemu_model *m, hipStream_t st);
+void prof_pair(gpemu_model *m, int which, int e0, int e1);
+}  // namespace gpemu

@@ -1,0 +1,173 @@
+// Gaussian log-likelihood of the emulator prediction against the data, low-rank form.
+//
+// Replaces  ref: log_posterior.py:63-64, 87-99, 104-146  (box prior, dY, Sigma = cov + diag(y_err^2),
+// dpotrf + dpotrs per walker) for one emulation group.  With  s = scaler.scale_,  S_k = components_[:k]:
+//     Sigma(theta) = A + U diag(var(theta)) U^T,   A = (C_unexpl / n_div) o (s s^T) + diag(y_err^2),
+//     U = diag(s) S_k^T (F x k),   r(theta) = U m(theta) + r0,   r0 = scaler.mean_ - y_exp
+// (ref: emulation.py:508-539).  Woodbury + the matrix-determinant lemma give
+//     log p = -1/2 [ m^T G m + 2 m^T g0 + q0 - || L_M^-1 D^1/2 (G m + g0) ||^2 ]
+//             -1/2 [ log det A + 2 sum log diag L_M ],     M = I + D^1/2 G D^1/2 = L_M L_M^T,
+// with G = U^T A^-1 U, g0 = U^T A^-1 r0, q0 = r0^T A^-1 r0 computed once per (model, n_div) on the
+// device (setup kernel below).  The symmetric D^1/2 form stays finite when a variance is clipped to 0.
+#include "internal.h"
+#include "linalg_dev.h"
+
+namespace gpemu {
+
+// ---- setup ----------------------------------------------------------------------------------
+__global__ void build_A_kernel(const double *__restrict__ cun, const double *__restrict__ s,
+                               const double *__restrict__ yerr, double *__restrict__ A, int F,
+                               double inv_ndiv) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)F * F) return;
+  int f = (int)(idx / F), g = (int)(idx - (int64_t)f * F);
+  double v = cun[idx] * inv_ndiv * (s[f] * s[g]);
+  if (f == g) v += yerr[f] * yerr[f];
+  A[idx] = v;
+}
+
+// one workgroup: chol(A); Z = C^-1 [U | r0]; G = Zu^T Zu; g0 = Zu^T zr; q0 = zr^T zr; logdetA
+__global__ __launch_bounds__(CHOL_THREADS) void lik_setup_kernel(
+    double *A, double *PT, double *Z /*[F][k+1]*/, const double *__restrict__ comp,
+    const double *__restrict__ s, const double *__restrict__ smean, const double *__restrict__ yexp,
+    double *G, double *g0, double *scal, int F, int k, int *info) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int k1 = k + 1;
+  for (int idx = tid; idx < F * k1; idx += nthr) {
+    int f = idx / k1, p = idx - f * k1;
+    Z[idx] = (p < k) ? s[f] * comp[(int64_t)p * F + f] : (smean[f] - yexp[f]);
+  }
+  wg_cholesky_lower(A, F, F, PT, info);
+  wg_forward_solve_multi(A, F, F, Z, k1, k1);
+  for (int idx = tid; idx < k1 * k1; idx += nthr) {
+    int p = idx / k1, q = idx - p * k1;
+    double acc = 0.0;
+    for (int f = 0; f < F; ++f) acc = fma(Z[(int64_t)f * k1 + p], Z[(int64_t)f * k1 + q], acc);
+    if (p < k && q < k) G[p * k + q] = acc;
+    else if (p < k && q == k) g0[p] = acc;
+    else if (p == k && q == k) scal[0] = acc;
+  }
+  double ld = 0.0;
+  for (int f = tid; f < F; f += nthr) ld += log(A[(int64_t)f * F + f]);
+  ld = wg_sum(ld);
+  if (tid == 0) scal[1] = 2.0 * ld;
+}
+
+int launch_lik_setup(gpemu_model *m, double *dA, double *dPT, double *dZ, int *dinfo, hipStream_t st) {
+  const int F = (int)m->F;
+  int64_t n = (int64_t)F * F;
+  hipLaunchKernelGGL(build_A_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->cunexpl,
+                     m->sscale, m->yerr, dA, F, 1.0 / m->n_div);
+  hipLaunchKernelGGL(lik_setup_kernel, dim3(1), dim3(CHOL_THREADS), 0, st, dA, dPT, dZ, m->comp,
+                     m->sscale, m->smean, m->yexp, m->G, m->g0, m->scal, F, (int)m->k, dinfo);
+  GP_HIP(hipGetLastError());
+  return GPEMU_OK;
+}
+
+// ---- per-walker evaluation --------------------------------------------------------------------
+// One wave per walker (lane = PC index, k <= 64), 4 walkers per workgroup.  Sums the partial means
+// and partial ||W k_*||^2 written by kstar_kernel / trmm_vsq_kernel, so no separate reduce launch.
+__global__ __launch_bounds__(256) void loglik_lowrank_kernel(
+    const double *__restrict__ Xq, const double *__restrict__ lo, const double *__restrict__ hi,
+    const double *__restrict__ mean_part, const double *__restrict__ vsq_part,
+    const double *__restrict__ kdiag, const double *__restrict__ G, const double *__restrict__ g0,
+    const double *__restrict__ scal, double *__restrict__ out, double *__restrict__ mean_out,
+    double *__restrict__ var_out, int64_t B, int64_t Bcap, int d, int k, int nchunk, int nrb,
+    int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  if (b >= B) return;  // whole wave exits together; no workgroup barriers below
+  double *M = smem + (size_t)wave * k * (k + 1);
+  const int ldm = k + 1;
+
+  // strict box prior (ref: log_posterior.py:63-64)
+  bool in = true;
+  if (lane < d) in = (Xq[b * DPAD + lane] > lo[lane]) && (Xq[b * DPAD + lane] < hi[lane]);
+  const bool inside = __all(in);
+
+  double mu = 0.0, sd = 0.0;
+  if (lane < k) {
+    double vs = 0.0;
+    for (int c = 0; c < nchunk; ++c) mu += mean_part[((int64_t)lane * nchunk + c) * Bcap + b];
+    for (int r = 0; r < nrb; ++r) vs += vsq_part[((int64_t)lane * nrb + r) * Bcap + b];
+    double v = kdiag[lane] - vs;
+    if (v < 0.0) v = 0.0;
+    sd = sqrt(v);
+    if (mean_out) mean_out[b * k + lane] = mu;
+    if (var_out) var_out[b * k + lane] = sd * sd;
+  }
+  if (!inside) {
+    if (lane == 0) out[b] = -INFINITY;
+    return;
+  }
+  // h = G m + g0 ; quadA = m.(h + g0) + q0
+  double h = 0.0, gl = (lane < k) ? g0[lane] : 0.0;
+  for (int q = 0; q < k; ++q) {
+    double mq = __shfl(mu, q);
+    if (lane < k) h = fma(G[lane * k + q], mq, h);
+  }
+  h += gl;
+  double t = (lane < k) ? mu * (h + gl) : 0.0;
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+  const double quadA = t + scal[0];
+  // M = I + D^1/2 G D^1/2 (row `lane`)
+  for (int q = 0; q < k; ++q) {
+    double sq = __shfl(sd, q);
+    if (lane < k) M[lane * ldm + q] = ((lane == q) ? 1.0 : 0.0) + sd * G[lane * k + q] * sq;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // in-wave Cholesky of M (k x k, lane = row), right-looking
+  double logdiag = 0.0;
+  for (int j = 0; j < k; ++j) {
+    double piv = sqrt(M[j * ldm + j]);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == j) {
+      M[j * ldm + j] = piv;
+      logdiag = log(piv);
+    }
+    if (lane > j && lane < k) M[lane * ldm + j] = M[lane * ldm + j] / piv;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane > j && lane < k) {
+      double lij = M[lane * ldm + j];
+      for (int c = j + 1; c <= lane; ++c) M[lane * ldm + c] -= lij * M[c * ldm + j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // w = L_M^-1 (sd o h)
+  double y = (lane < k) ? sd * h : 0.0;
+  for (int j = 0; j < k; ++j) {
+    double zj = __shfl(y, j) / M[j * ldm + j];
+    if (lane == j) y = zj;
+    if (lane > j && lane < k) y = fma(-M[lane * ldm + j], zj, y);
+  }
+  double ww = (lane < k) ? y * y : 0.0;
+  double ldsum = logdiag;
+  for (int off = 32; off > 0; off >>= 1) {
+    ww += __shfl_xor(ww, off);
+    ldsum += __shfl_xor(ldsum, off);
+  }
+  if (lane == 0) {
+    double lp = -0.5 * (quadA - ww) - 0.5 * (scal[1] + 2.0 * ldsum);
+    out[b] = accumulate ? out[b] + lp : lp;
+  }
+}
+
+int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq, double *dout, int accumulate,
+                          hipStream_t st) {
+  const Workspace &w = m->ws;
+  const int k = (int)m->k;
+  size_t shm = sizeof(double) * 4 * (size_t)k * (k + 1);
+  hipLaunchKernelGGL(loglik_lowrank_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), shm, st, dXq,
+                     m->lo, m->hi, w.mean_part, w.vsq_part, m->kdiag, m->G, m->g0, m->scal, dout,
+                     w.mean, w.var, B, w.Bcap, (int)m->d, k, (int)(m->Npad / JCHUNK),
+                     (int)(m->Npad / TILE), accumulate);
+  GP_HIP(hipGetLastError());
+  return GPEMU_OK;
+}
+
+}  // namespace gpemu

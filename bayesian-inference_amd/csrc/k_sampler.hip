@@ -1,0 +1,562 @@
+// Affine-invariant stretch-move ensemble sampler, resident on the device.
+//
+// Replaces  ref: mcmc.py:83-107, 187-204  (emcee 3.1.4 EnsembleSampler + StretchMove(a=2) inside
+// RedBlueMove(nsplits=2, randomize_split=True), driven through a multiprocessing pool).  emcee is
+// a third-party dependency that is not vendored in the reference (ref: pdm.lock:504-505); the move
+// is restated from its published algorithm (Goodman & Weare 2010; emcee moves/red_blue.py,
+// moves/stretch.py), see oracle/sampler_oracle.py.  Per step:
+//     inds = shuffle(arange(W) % 2)
+//     for split in (0, 1):  s = walkers with inds == split,  c = the others (CURRENT positions)
+//         zz = ((a-1) u + 1)^2 / a ; rint = randint(Nc) ; q = c[rint] - (c[rint] - s) zz
+//         accept iff (d-1) log zz + logp(q) - logp(s) > log(u')
+// Randomness is either drawn on the device (Philox4x32-10, counter = (step, stream, index, draw),
+// identical on every rank so no communication is needed for it) or supplied by the host in emcee's
+// draw order (gpemu_sampler_step_host_rng) to replay a numpy RandomState stream.
+#include "internal.h"
+
+namespace gpemu {
+
+// ---- Philox4x32-10 (Salmon et al., SC'11) ----------------------------------------------------
+struct u32x4 { uint32_t x, y, z, w; };
+__host__ __device__ static inline u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)M0 * c.x, p1 = (uint64_t)M1 * c.z;
+    u32x4 n;
+    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (uint32_t)p1;
+    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (uint32_t)p0;
+    c = n;
+    k0 += W0;
+    k1 += W1;
+  }
+  return c;
+}
+__host__ __device__ static inline double u01_from(uint32_t hi, uint32_t lo) {
+  uint64_t v = ((uint64_t)hi << 32) | lo;
+  return (double)(v >> 11) * (1.0 / 9007199254740992.0);  // [0,1), 53 bits
+}
+
+}  // namespace gpemu
+
+struct gpemu_sampler {
+  int device = 0;
+  std::vector<gpemu_model *> groups;
+  int64_t W = 0, d = 0;
+  int64_t ns[2] = {0, 0};      // set sizes: ceil(W/2), floor(W/2)
+  int64_t qcap = 0;            // rows of q (>= ns[0] rounded up to 128, + 128)
+  double a = 2.0;
+  uint64_t seed = 0;
+  uint64_t step_counter = 0;   // RNG counter, never reset
+  int64_t iterations = 0;      // steps since the last reset
+  hipStream_t stream = nullptr;
+  double *X = nullptr;         // [W][DPAD]
+  double *logp = nullptr;      // [W]
+  int *inds = nullptr;         // [W] split of each walker
+  int *idx = nullptr;          // [2][W] members of each set, ascending walker index
+  double *zz = nullptr;        // [2][W]
+  double *logu = nullptr;      // [2][W]
+  int *rint = nullptr;         // [2][W]
+  double *q = nullptr;         // [qcap][DPAD]
+  double *factors = nullptr;   // [W]
+  double *newlp = nullptr;     // [qcap]
+  long long *naccept = nullptr;  // [W]
+  int *flags = nullptr;        // [1] count of NaN log-probabilities seen
+  double *chain = nullptr;     // [chain_cap][W][d]
+  double *lpchain = nullptr;   // [chain_cap][W]
+  int64_t chain_cap = 0, chain_len = 0;
+};
+
+namespace gpemu {
+
+// ---- kernels ------------------------------------------------------------------------------------
+// One workgroup: random balanced split (sort W random keys), set member lists, and the step's
+// zz / rint / log u draws for both halves.
+__global__ __launch_bounds__(1024) void rng_step_kernel(int *inds, int *idx, double *zz, double *logu,
+                                                        int *rint, int W, int n0, int n1, double a,
+                                                        uint32_t k0, uint32_t k1, uint32_t step_lo,
+                                                        uint32_t step_hi) {
+  extern __shared__ unsigned long long keys[];  // P = next pow2 >= W entries, then W ints for the scan
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  int P = 1;
+  while (P < W) P <<= 1;
+  for (int w = tid; w < P; w += nthr) {
+    if (w < W) {
+      u32x4 r = philox4x32_10(u32x4{(uint32_t)w, 0u, step_lo, step_hi}, k0, k1);
+      keys[w] = ((unsigned long long)r.x << 32) | (unsigned)w;
+    } else {
+      keys[w] = ~0ull;
+    }
+  }
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < P / 2; t += nthr) {
+        int lo = (t / stride) * 2 * stride + (t % stride);
+        int hi = lo + stride;
+        bool up = ((lo & size) == 0);
+        unsigned long long x = keys[lo], y = keys[hi];
+        if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  int *split = reinterpret_cast<int *>(keys + P);  // [W]
+  for (int pos = tid; pos < W; pos += nthr) {
+    int w = (int)(keys[pos] & 0xffffffffu);
+    split[w] = pos & 1;   // == (arange(W) % 2) after a uniform shuffle
+  }
+  __syncthreads();
+  // member lists in ascending walker order (serial scan by one thread per set; W is small)
+  if (tid < 2) {
+    int c = 0;
+    for (int w = 0; w < W; ++w)
+      if (split[w] == tid) idx[tid * W + c++] = w;
+  }
+  for (int w = tid; w < W; w += nthr) inds[w] = split[w];
+  for (int h = 0; h < 2; ++h) {
+    const int ns = h == 0 ? n0 : n1, nc = W - ns;
+    for (int i = tid; i < ns; i += nthr) {
+      u32x4 r = philox4x32_10(u32x4{(uint32_t)i, (uint32_t)(1 + h), step_lo, step_hi}, k0, k1);
+      u32x4 r2 = philox4x32_10(u32x4{(uint32_t)i, (uint32_t)(3 + h), step_lo, step_hi}, k0, k1);
+      double u = u01_from(r.x, r.y);
+      double t = (a - 1.0) * u + 1.0;
+      zz[h * W + i] = t * t / a;
+      rint[h * W + i] = (int)(((unsigned long long)r.z * (unsigned long long)nc) >> 32);
+      logu[h * W + i] = log(u01_from(r2.x, r2.y));
+    }
+  }
+}
+
+// set lists from host-supplied inds (emcee order)
+__global__ void build_sets_kernel(const int *inds, int *idx, int W) {
+  if (threadIdx.x < 2 && blockIdx.x == 0) {
+    int c = 0;
+    for (int w = 0; w < W; ++w)
+      if (inds[w] == (int)threadIdx.x) idx[threadIdx.x * W + c++] = w;
+  }
+}
+
+__global__ void propose_kernel(const double *__restrict__ X, const int *__restrict__ idx_s,
+                               const int *__restrict__ idx_c, const double *__restrict__ zz,
+                               const int *__restrict__ rint, double *__restrict__ q,
+                               double *__restrict__ factors, int ns, int d) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const int w = idx_s[i], j = idx_c[rint[i]];
+  const double z = zz[i];
+#pragma unroll
+  for (int dd = 0; dd < DPAD; ++dd) {
+    double cj = X[j * DPAD + dd], sw = X[w * DPAD + dd];
+    q[i * DPAD + dd] = (dd < d) ? cj - (cj - sw) * z : 0.0;   // emcee moves/stretch.py get_proposal
+  }
+  factors[i] = (d - 1.0) * log(z);
+}
+
+__global__ void accept_kernel(double *__restrict__ X, double *__restrict__ logp,
+                              const int *__restrict__ idx_s, const double *__restrict__ q,
+                              const double *__restrict__ factors, const double *__restrict__ newlp,
+                              const double *__restrict__ logu, long long *__restrict__ naccept,
+                              int *__restrict__ flags, int ns) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  const int w = idx_s[i];
+  const double nlp = newlp[i];
+  if (nlp != nlp) atomicAdd(flags, 1);  // emcee raises on NaN log-probability
+  const double lnpdiff = factors[i] + nlp - logp[w];
+  if (lnpdiff > logu[i]) {
+#pragma unroll
+    for (int dd = 0; dd < DPAD; ++dd) X[w * DPAD + dd] = q[i * DPAD + dd];
+    logp[w] = nlp;
+    naccept[w] += 1;
+  }
+}
+
+__global__ void record_kernel(const double *__restrict__ X, const double *__restrict__ logp,
+                              double *__restrict__ chain, double *__restrict__ lpchain, int W, int d) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < W * d) chain[idx] = X[(idx / d) * DPAD + idx % d];
+  if (idx < W) lpchain[idx] = logp[idx];
+}
+
+__global__ void pad_rows_kernel(const double *__restrict__ src, double *__restrict__ dst, int n, int d) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * DPAD) return;
+  int r = idx / DPAD, dd = idx % DPAD;
+  dst[idx] = dd < d ? src[r * d + dd] : 0.0;
+}
+
+__global__ void unpad_rows_kernel(const double *__restrict__ src, double *__restrict__ dst, int n, int d) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * d) return;
+  dst[idx] = src[(idx / d) * DPAD + idx % d];
+}
+
+// ---- host helpers ---------------------------------------------------------------------------------
+static int eval_logpost(gpemu_sampler *s, const double *dq, int64_t B, double *dout, hipStream_t st) {
+  for (size_t g = 0; g < s->groups.size(); ++g) {
+    int rc = logpost_padded(s->groups[g], B, dq, dout, g > 0 ? 1 : 0, st);
+    if (rc != GPEMU_OK) return rc;
+  }
+  return GPEMU_OK;
+}
+
+static int ensure_chain(gpemu_sampler *s, int64_t need) {
+  if (need <= s->chain_cap) return GPEMU_OK;
+  int64_t cap = s->chain_cap ? s->chain_cap : 256;
+  while (cap < need) cap *= 2;
+  double *nc = nullptr, *nl = nullptr;
+  GP_HIP(hipMalloc((void **)&nc, sizeof(double) * (size_t)(cap * s->W * s->d)));
+  GP_HIP(hipMalloc((void **)&nl, sizeof(double) * (size_t)(cap * s->W)));
+  if (s->chain_len > 0) {
+    GP_HIP(hipMemcpyAsync(nc, s->chain, sizeof(double) * (size_t)(s->chain_len * s->W * s->d),
+                          hipMemcpyDeviceToDevice, s->stream));
+    GP_HIP(hipMemcpyAsync(nl, s->lpchain, sizeof(double) * (size_t)(s->chain_len * s->W),
+                          hipMemcpyDeviceToDevice, s->stream));
+  }
+  GP_HIP(hipStreamSynchronize(s->stream));
+  (void)hipFree(s->chain);
+  (void)hipFree(s->lpchain);
+  s->chain = nc; s->lpchain = nl; s->chain_cap = cap;
+  return GPEMU_OK;
+}
+
+static int launch_rng(gpemu_sampler *s, hipStream_t st) {
+  int P = 1;
+  while (P < s->W) P <<= 1;
+  size_t shm = sizeof(unsigned long long) * P + sizeof(int) * s->W;
+  hipLaunchKernelGGL(rng_step_kernel, dim3(1), dim3(1024), shm, st, s->inds, s->idx, s->zz, s->logu,
+                     s->rint, (int)s->W, (int)s->ns[0], (int)s->ns[1], s->a, (uint32_t)s->seed,
+                     (uint32_t)(s->seed >> 32), (uint32_t)s->step_counter,
+                     (uint32_t)(s->step_counter >> 32));
+  GP_HIP(hipGetLastError());
+  return GPEMU_OK;
+}
+
+static int launch_propose(gpemu_sampler *s, int h, hipStream_t st) {
+  const int ns = (int)s->ns[h];
+  hipLaunchKernelGGL(propose_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, s->X, s->idx + h * s->W,
+                     s->idx + (1 - h) * s->W, s->zz + h * s->W, s->rint + h * s->W, s->q, s->factors, ns,
+                     (int)s->d);
+  GP_HIP(hipGetLastError());
+  return GPEMU_OK;
+}
+
+static int launch_accept(gpemu_sampler *s, int h, const double *dnewlp, hipStream_t st) {
+  const int ns = (int)s->ns[h];
+  hipLaunchKernelGGL(accept_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, s->X, s->logp,
+                     s->idx + h * s->W, s->q, s->factors, dnewlp, s->logu + h * s->W, s->naccept,
+                     s->flags, ns);
+  GP_HIP(hipGetLastError());
+  return GPEMU_OK;
+}
+
+static int end_step(gpemu_sampler *s, int store_chain, hipStream_t st) {
+  if (store_chain) {
+    int rc = ensure_chain(s, s->chain_len + 1);
+    if (rc != GPEMU_OK) return rc;
+    const int n = (int)(s->W * s->d);
+    hipLaunchKernelGGL(record_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->X, s->logp,
+                       s->chain + s->chain_len * s->W * s->d, s->lpchain + s->chain_len * s->W,
+                       (int)s->W, (int)s->d);
+    GP_HIP(hipGetLastError());
+    s->chain_len += 1;
+  }
+  s->iterations += 1;
+  s->step_counter += 1;
+  return GPEMU_OK;
+}
+
+}  // namespace gpemu
+
+using namespace gpemu;
+#define GP_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != GPEMU_OK) return rc__; \
+  } while (0)
+
+extern "C" {
+
+int gpemu_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                     uint32_t *out4) {
+  GP_ARG(out4, "out4");
+  u32x4 r = philox4x32_10(u32x4{c0, c1, c2, c3}, k0, k1);
+  out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w;
+  return GPEMU_OK;
+}
+
+int gpemu_sampler_create(gpemu_sampler **out, gpemu_model *const *groups, int n_groups, int64_t W,
+                         double a, uint64_t seed) {
+  GP_ARG(out && groups && n_groups > 0, "groups");
+  *out = nullptr;
+  GP_ARG(a > 1.0, "stretch scale a must be > 1");
+  for (int g = 0; g < n_groups; ++g) {
+    GP_ARG(groups[g], "null group");
+    GP_ARG(groups[g]->d == groups[0]->d && groups[g]->device == groups[0]->device,
+           "groups must share the parameter dimension and the device");
+    if (!groups[g]->lik_ready) { set_error("gpemu_likelihood_setup must be called on every group first"); return GPEMU_ERR_STATE; }
+  }
+  const int64_t d = groups[0]->d;
+  GP_ARG(W >= 2 && W <= 8192, "n_walkers must be in [2, 8192]");
+  GP_HIP(hipSetDevice(groups[0]->device));
+  gpemu_sampler *s = new gpemu_sampler();
+  s->device = groups[0]->device;
+  s->groups.assign(groups, groups + n_groups);
+  s->W = W; s->d = d; s->a = a; s->seed = seed;
+  s->ns[0] = (W + 1) / 2; s->ns[1] = W / 2;
+  s->qcap = round_up(s->ns[0], TILE) + TILE;
+  s->stream = groups[0]->stream;
+  hipError_t e = hipSuccess;
+  auto A = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 8); };
+  A((void **)&s->X, sizeof(double) * W * DPAD);
+  A((void **)&s->logp, sizeof(double) * W);
+  A((void **)&s->inds, sizeof(int) * W);
+  A((void **)&s->idx, sizeof(int) * 2 * W);
+  A((void **)&s->zz, sizeof(double) * 2 * W);
+  A((void **)&s->logu, sizeof(double) * 2 * W);
+  A((void **)&s->rint, sizeof(int) * 2 * W);
+  A((void **)&s->q, sizeof(double) * s->qcap * DPAD);
+  A((void **)&s->factors, sizeof(double) * W);
+  A((void **)&s->newlp, sizeof(double) * s->qcap);
+  A((void **)&s->naccept, sizeof(long long) * W);
+  A((void **)&s->flags, sizeof(int));
+  if (e == hipSuccess) e = hipMemsetAsync(s->q, 0, sizeof(double) * s->qcap * DPAD, s->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(s->naccept, 0, sizeof(long long) * W, s->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(s->flags, 0, sizeof(int), s->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(s->X, 0, sizeof(double) * W * DPAD, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  if (e != hipSuccess) {
+    set_error("sampler_create: %s", hipGetErrorString(e));
+    gpemu_sampler_destroy(s);
+    return GPEMU_ERR_HIP;
+  }
+  *out = s;
+  return GPEMU_OK;
+}
+
+int gpemu_sampler_destroy(gpemu_sampler *s) {
+  if (!s) return GPEMU_OK;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  (void)hipFree(s->X); (void)hipFree(s->logp); (void)hipFree(s->inds); (void)hipFree(s->idx);
+  (void)hipFree(s->zz); (void)hipFree(s->logu); (void)hipFree(s->rint); (void)hipFree(s->q);
+  (void)hipFree(s->factors); (void)hipFree(s->newlp); (void)hipFree(s->naccept); (void)hipFree(s->flags);
+  (void)hipFree(s->chain); (void)hipFree(s->lpchain);
+  delete s;
+  return GPEMU_OK;
+}
+
+int gpemu_sampler_set_state(gpemu_sampler *s, const double *X0, const double *logp0) {
+  GP_ARG(s && X0, "null pointer");
+  GP_HIP(hipSetDevice(s->device));
+  hipStream_t st = s->stream;
+  const int64_t W = s->W, d = s->d;
+  double *tmp = nullptr;
+  GP_HIP(hipMalloc((void **)&tmp, sizeof(double) * W * d));
+  hipError_t e = hipMemcpyAsync(tmp, X0, sizeof(double) * W * d, hipMemcpyHostToDevice, st);
+  int rc = GPEMU_OK;
+  if (e != hipSuccess) { set_error("set_state: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
+  if (rc == GPEMU_OK) {
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((W * DPAD + 255) / 256)), dim3(256), 0, st, tmp,
+                       s->X, (int)W, (int)d);
+    if (logp0) {
+      e = hipMemcpyAsync(s->logp, logp0, sizeof(double) * W, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) { set_error("set_state: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
+    } else {
+      // evaluate all walkers; X has exactly W rows, so go through a padded scratch copy in chunks
+      for (int64_t off = 0; off < W && rc == GPEMU_OK; off += s->ns[0]) {
+        int64_t nb = (W - off < s->ns[0]) ? (W - off) : s->ns[0];
+        e = hipMemcpyAsync(s->q, s->X + off * DPAD, sizeof(double) * nb * DPAD, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) { set_error("set_state: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; break; }
+        rc = eval_logpost(s, s->q, nb, s->newlp, st);
+        if (rc == GPEMU_OK) {
+          e = hipMemcpyAsync(s->logp + off, s->newlp, sizeof(double) * nb, hipMemcpyDeviceToDevice, st);
+          if (e != hipSuccess) { set_error("set_state: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
+        }
+      }
+    }
+  }
+  e = hipStreamSynchronize(st);
+  if (rc == GPEMU_OK && e != hipSuccess) { set_error("set_state: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
+  (void)hipFree(tmp);
+  return rc;
+}
+
+int gpemu_sampler_get_state(gpemu_sampler *s, double *X, double *logp) {
+  GP_ARG(s, "sampler");
+  GP_HIP(hipSetDevice(s->device));
+  hipStream_t st = s->stream;
+  const int64_t W = s->W, d = s->d;
+  if (X) {
+    double *tmp = nullptr;
+    GP_HIP(hipMalloc((void **)&tmp, sizeof(double) * W * d));
+    hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)((W * d + 255) / 256)), dim3(256), 0, st, s->X,
+                       tmp, (int)W, (int)d);
+    hipError_t e = hipMemcpyAsync(X, tmp, sizeof(double) * W * d, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) { set_error("get_state: %s", hipGetErrorString(e)); return GPEMU_ERR_HIP; }
+  }
+  if (logp) {
+    GP_HIP(hipMemcpyAsync(logp, s->logp, sizeof(double) * W, hipMemcpyDeviceToHost, st));
+    GP_HIP(hipStreamSynchronize(st));
+  }
+  return GPEMU_OK;
+}
+
+int gpemu_sampler_reset(gpemu_sampler *s) {
+  GP_ARG(s, "sampler");
+  GP_HIP(hipSetDevice(s->device));
+  GP_HIP(hipMemsetAsync(s->naccept, 0, sizeof(long long) * s->W, s->stream));
+  GP_HIP(hipStreamSynchronize(s->stream));
+  s->chain_len = 0;
+  s->iterations = 0;
+  return GPEMU_OK;
+}
+
+static int check_nan(gpemu_sampler *s) {
+  int flag = 0;
+  GP_HIP(hipMemcpyAsync(&flag, s->flags, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  GP_HIP(hipStreamSynchronize(s->stream));
+  if (flag) {
+    (void)hipMemsetAsync(s->flags, 0, sizeof(int), s->stream);
+    set_error("log-probability returned NaN for %d proposals (emcee raises ValueError here)", flag);
+    return 1;
+  }
+  return GPEMU_OK;
+}
+
+int gpemu_sampler_run(gpemu_sampler *s, int64_t steps, int store_chain) {
+  GP_ARG(s && steps >= 0, "sampler / steps");
+  GP_HIP(hipSetDevice(s->device));
+  hipStream_t st = s->stream;
+  if (store_chain) GP_TRY(ensure_chain(s, s->chain_len + steps));
+  for (int64_t it = 0; it < steps; ++it) {
+    GP_TRY(launch_rng(s, st));
+    for (int h = 0; h < 2; ++h) {
+      if (s->ns[h] == 0) continue;
+      GP_TRY(launch_propose(s, h, st));
+      GP_TRY(eval_logpost(s, s->q, s->ns[h], s->newlp, st));
+      GP_TRY(launch_accept(s, h, s->newlp, st));
+    }
+    GP_TRY(end_step(s, store_chain, st));
+  }
+  return check_nan(s);
+}
+
+int gpemu_sampler_step_host_rng(gpemu_sampler *s, const int32_t *inds, const double *zz,
+                                const int64_t *rint, const double *logu, int store_chain) {
+  GP_ARG(s && inds && zz && rint && logu, "null pointer");
+  GP_HIP(hipSetDevice(s->device));
+  hipStream_t st = s->stream;
+  const int64_t W = s->W;
+  int64_t n0 = 0;
+  for (int64_t w = 0; w < W; ++w) {
+    GP_ARG(inds[w] == 0 || inds[w] == 1, "inds must be 0/1");
+    n0 += (inds[w] == 0);
+  }
+  GP_ARG(n0 == s->ns[0], "inds must hold ceil(W/2) zeros");
+  std::vector<int> hr(2 * W, 0);
+  std::vector<double> hz(2 * W, 1.0), hu(2 * W, 0.0);
+  for (int h = 0; h < 2; ++h) {
+    const int64_t off = h == 0 ? 0 : s->ns[0], nc = W - s->ns[h];
+    for (int64_t i = 0; i < s->ns[h]; ++i) {
+      GP_ARG(rint[off + i] >= 0 && rint[off + i] < nc, "rint out of range");
+      hr[h * W + i] = (int)rint[off + i];
+      hz[h * W + i] = zz[off + i];
+      hu[h * W + i] = logu[off + i];
+    }
+  }
+  GP_HIP(hipMemcpyAsync(s->inds, inds, sizeof(int) * W, hipMemcpyHostToDevice, st));
+  GP_HIP(hipMemcpyAsync(s->rint, hr.data(), sizeof(int) * 2 * W, hipMemcpyHostToDevice, st));
+  GP_HIP(hipMemcpyAsync(s->zz, hz.data(), sizeof(double) * 2 * W, hipMemcpyHostToDevice, st));
+  GP_HIP(hipMemcpyAsync(s->logu, hu.data(), sizeof(double) * 2 * W, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(build_sets_kernel, dim3(1), dim3(64), 0, st, s->inds, s->idx, (int)W);
+  for (int h = 0; h < 2; ++h) {
+    if (s->ns[h] == 0) continue;
+    GP_TRY(launch_propose(s, h, st));
+    GP_TRY(eval_logpost(s, s->q, s->ns[h], s->newlp, st));
+    GP_TRY(launch_accept(s, h, s->newlp, st));
+  }
+  GP_TRY(end_step(s, store_chain, st));
+  return check_nan(s);  // also synchronises, so the host staging vectors may go out of scope
+}
+
+int gpemu_sampler_get_chain(gpemu_sampler *s, int64_t first, int64_t n, double *chain_out,
+                            double *logp_out) {
+  GP_ARG(s && first >= 0 && n >= 0 && first + n <= s->chain_len, "chain range");
+  GP_HIP(hipSetDevice(s->device));
+  if (n == 0) return GPEMU_OK;
+  if (chain_out)
+    GP_HIP(hipMemcpyAsync(chain_out, s->chain + first * s->W * s->d, sizeof(double) * n * s->W * s->d,
+                          hipMemcpyDeviceToHost, s->stream));
+  if (logp_out)
+    GP_HIP(hipMemcpyAsync(logp_out, s->lpchain + first * s->W, sizeof(double) * n * s->W,
+                          hipMemcpyDeviceToHost, s->stream));
+  GP_HIP(hipStreamSynchronize(s->stream));
+  return GPEMU_OK;
+}
+
+int gpemu_sampler_get_counts(gpemu_sampler *s, int64_t *naccepted, int64_t *iterations,
+                             int64_t *chain_len) {
+  GP_ARG(s, "sampler");
+  GP_HIP(hipSetDevice(s->device));
+  if (naccepted) {
+    GP_HIP(hipMemcpyAsync(naccepted, s->naccept, sizeof(long long) * s->W, hipMemcpyDeviceToHost, s->stream));
+    GP_HIP(hipStreamSynchronize(s->stream));
+  }
+  if (iterations) *iterations = s->iterations;
+  if (chain_len) *chain_len = s->chain_len;
+  return GPEMU_OK;
+}
+
+// ---- phases for the multi-GPU driver (walkers sharded over ranks; RCCL all-gather in between) ----
+int gpemu_sampler_begin_step(gpemu_sampler *s) {
+  GP_ARG(s, "sampler");
+  GP_HIP(hipSetDevice(s->device));
+  return launch_rng(s, s->stream);
+}
+
+int gpemu_sampler_half_propose_eval(gpemu_sampler *s, int half, int64_t lo, int64_t hi,
+                                    double *dnewlp_slice) {
+  GP_ARG(s && (half == 0 || half == 1), "half");
+  GP_ARG(lo >= 0 && lo <= hi && hi <= s->ns[half] && dnewlp_slice, "slice");
+  GP_HIP(hipSetDevice(s->device));
+  GP_TRY(launch_propose(s, half, s->stream));
+  if (hi > lo) {
+    GP_TRY(eval_logpost(s, s->q + lo * DPAD, hi - lo, s->newlp, s->stream));
+    GP_HIP(hipMemcpyAsync(dnewlp_slice, s->newlp, sizeof(double) * (hi - lo), hipMemcpyDeviceToDevice,
+                          s->stream));
+  }
+  return GPEMU_OK;
+}
+
+int gpemu_sampler_half_accept(gpemu_sampler *s, int half, const double *dnewlp_all) {
+  GP_ARG(s && (half == 0 || half == 1) && dnewlp_all, "half / newlp");
+  GP_HIP(hipSetDevice(s->device));
+  return launch_accept(s, half, dnewlp_all, s->stream);
+}
+
+int gpemu_sampler_end_step(gpemu_sampler *s, int store_chain) {
+  GP_ARG(s, "sampler");
+  GP_HIP(hipSetDevice(s->device));
+  return end_step(s, store_chain, s->stream);
+}
+
+int gpemu_sampler_check(gpemu_sampler *s) {
+  GP_ARG(s, "sampler");
+  GP_HIP(hipSetDevice(s->device));
+  return check_nan(s);
+}
+
+int gpemu_sampler_set_stream(gpemu_sampler *s, void *stream) {
+  GP_ARG(s, "sampler");
+  GP_HIP(hipSetDevice(s->device));
+  GP_HIP(hipStreamSynchronize(s->stream));
+  s->stream = stream ? (hipStream_t)stream : s->groups[0]->stream;
+  return GPEMU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+"""ctypes binding of libgpemu.so (include/gpemu.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C bayesian-inference_amd/csrc``
+and lives next to this file.  There is no CPU implementation: if the shared object is missing, or
+no HIP device is visible, every compute call raises ``GpemuError`` -- loudly, never a silent
+fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpemu.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_i64 = C.c_int64
+
+
+class GpemuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libgpemu error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/gpemu.h one to one
+_SIGNATURES = {
+    "gpemu_version": (C.c_char_p, []),
+    "gpemu_last_error": (C.c_char_p, []),
+    "gpemu_device_count": (C.c_int, []),
+    "gpemu_device_name": (C.c_int, [C.c_int, C.c_char_p, c_i64]),
+    "gpemu_model_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, c_i64, c_i64, c_i64, c_i64,
+                                     C.c_int, C.c_double, C.c_int, C.c_int] + [C.c_void_p] * 10),
+    "gpemu_model_destroy": (C.c_int, [C.c_void_p]),
+    "gpemu_model_dims": (C.c_int, [C.c_void_p] + [C.POINTER(c_i64)] * 4),
+    "gpemu_model_device": (C.c_int, [C.c_void_p]),
+    "gpemu_model_sync": (C.c_int, [C.c_void_p]),
+    "gpemu_model_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "gpemu_model_profile_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpemu_gp_predict": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpemu_gp_predict_dev": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpemu_predict_full": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+    "gpemu_predict_full_dev": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_double, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    "gpemu_likelihood_setup": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_double]),
+    "gpemu_logpost": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_int]),
+    "gpemu_logpost_dev": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "gpemu_sampler_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, c_i64,
+                                       C.c_double, C.c_uint64]),
+    "gpemu_sampler_destroy": (C.c_int, [C.c_void_p]),
+    "gpemu_sampler_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gpemu_sampler_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpemu_sampler_get_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gpemu_sampler_reset": (C.c_int, [C.c_void_p]),
+    "gpemu_sampler_run": (C.c_int, [C.c_void_p, c_i64, C.c_int]),
+    "gpemu_sampler_step_host_rng": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int]),
+    "gpemu_sampler_get_chain": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p]),
+    "gpemu_sampler_get_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "gpemu_sampler_begin_step": (C.c_int, [C.c_void_p]),
+    "gpemu_sampler_half_propose_eval": (C.c_int, [C.c_void_p, C.c_int, c_i64, c_i64, C.c_void_p]),
+    "gpemu_sampler_half_accept": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "gpemu_sampler_end_step": (C.c_int, [C.c_void_p, C.c_int]),
+    "gpemu_sampler_check": (C.c_int, [C.c_void_p]),
+    "gpemu_philox4x32": (C.c_int, [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libgpemu.so once; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GpemuError(-100, f"{LIB_PATH} not found: build it with "
+                                   "`python -c 'import __graft_entry__ as g; g.build()'` "
+                                   "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise GpemuError(code, lib().gpemu_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    return int(lib().gpemu_device_count())
+
+
+def require_device():
+    n = device_count()
+    if n <= 0:
+        raise GpemuError(-3, "no HIP device visible; libgpemu has no CPU implementation")
+    return n
+
+
+def as_f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

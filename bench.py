@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- log-posterior evaluations per second of the device-resident stretch-move sampler.
+
+Workload (BASELINE.json configs[2], "C3"): N_design = 1000, N_obs = 500, 10 PCs, d = 6 parameters,
+1024 walkers, RBF + White kernel with fixed hyper-parameters.  One "step" = one
+stretch-move step = 2 half-ensemble updates = 1024 log-posterior evaluations.  Model state and the
+ensemble are resident in HBM before the timed region; the chain is kept on the device.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+With N > 1 the SAME 1024 walkers are sharded over the ranks (strong scaling): each rank evaluates
+its block of every half's proposals and the new log-probabilities are all-gathered with RCCL.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (trmm_vsq_kernel, the fp64
+triangular GEMM): algorithmic FLOPs per launch (k * N^2 per evaluation, SURVEY 8d, x evaluations per
+launch) / its mean launch duration measured with HIP events in a second pass of the same K steps.
+`cpu_baseline` times the CPU oracle (reference-form per-walker log_posterior) on this host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "bayesian-inference_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+N_DESIGN, N_OBS, N_PC, N_WALKERS = 1000, 500, 10, 1024
+FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix rate (the local guide lists none)
+
+
+def build_workload():
+    """Synthetic C3 model (numpy/scipy, setup only -- not timed): standardise, PCA, fixed-theta GP
+    factors.  Same generator and hyper-parameters as the goldens (gpemu/synthetic.py)."""
+    from scipy.linalg import cho_solve, cholesky, svd
+    from scipy.spatial.distance import pdist, squareform
+    from gpemu import synthetic
+    prob = synthetic.make_problem(N_DESIGN, N_OBS, seed=0)
+    Y, X = prob["Y"], prob["design"]
+    mean = Y.mean(0)
+    scale = Y.std(0)
+    Ys = (Y - mean) / scale
+    U, S, Vt = svd(Ys - Ys.mean(0), full_matrices=False)
+    sg = np.sign(Vt[np.arange(Vt.shape[0]), np.argmax(np.abs(Vt), axis=1)])
+    U, Vt = U * sg, Vt * sg[:, None]
+    ev = S ** 2 / (N_DESIGN - 1)
+    Ypca = (U * S)[:, :N_PC]
+    ls = (prob["hi"] - prob["lo"]) * 0.5
+    noise = 0.05
+    K = squareform(np.exp(-0.5 * pdist(X / ls, "sqeuclidean")))
+    np.fill_diagonal(K, 1.0)
+    K[np.diag_indices_from(K)] += noise + 1e-10
+    L = cholesky(K, lower=True)
+    alpha = np.stack([cho_solve((L, True), Ypca[:, i]) for i in range(N_PC)])
+    Sun = Vt.T[:, N_PC:]
+    cun = Sun @ (ev[N_PC:, None] * Sun.T)
+    return dict(prob=prob, ls=np.tile(ls, (N_PC, 1)), noise=np.full(N_PC, noise), alpha=alpha,
+                L=np.broadcast_to(L, (N_PC,) + L.shape).copy(), components=Vt[:N_PC], mean=mean,
+                scale=scale, cun=cun)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Reference-form per-walker log_posterior (oracle port, incl. the per-call recomputation of the
+    truncation covariance) over a spawn Pool, one walker per task (ref: mcmc.py:77-85)."""
+    import multiprocessing as mp
+    ncores = min(os.cpu_count() or 1, 16)
+    ctx = mp.get_context("spawn")
+    per_worker = 2
+    t_setup = time.time()
+    with ctx.Pool(ncores, initializer=_cpu_init) as pool:
+        pool.map(_cpu_eval, range(ncores))                      # warm-up: builds the model per worker
+        t_setup = time.time() - t_setup
+        n = ncores * per_worker
+        t0 = time.time()
+        pool.map(_cpu_eval, range(n), chunksize=1)
+        dt = time.time() - t0
+        if dt < seconds_budget / 3:                              # extend the sample if it was quick
+            reps = int(min(8, seconds_budget / max(dt, 1e-3) / 2))
+            t0 = time.time()
+            pool.map(_cpu_eval, range(n * reps), chunksize=1)
+            dt = time.time() - t0
+            n *= reps
+    return {"value": n / dt, "unit": "log-posterior evals/s", "cores": ncores, "kind": "port",
+            "sample": f"{n} per-walker reference-form evaluations of the C3 workload over a "
+                      f"{ncores}-process spawn pool, BLAS threads = 1 per process "
+                      f"(per-process model build {t_setup:.1f} s not timed)"}
+
+
+_CPU = {}
+
+
+def _cpu_init():
+    os.environ["OMP_NUM_THREADS"] = "1"
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    try:
+        from threadpoolctl import threadpool_limits
+        _CPU["limit"] = threadpool_limits(1)
+    except Exception:
+        pass
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_util as GU
+    from gpemu import synthetic
+    model, prob, _ = GU.fixed_theta_model(N_DESIGN, N_OBS, N_PC, seed=0)
+    _CPU.update(model=model, prob=prob, X=synthetic.make_walkers(N_WALKERS, seed=1))
+
+
+def _cpu_eval(i):
+    from oracle import gp_oracle as O
+    p = _CPU["prob"]
+    x = _CPU["X"][i % N_WALKERS]
+    return float(O.log_posterior(x, {"g": _CPU["model"]}, p["lo"], p["hi"], p["y_exp"], p["y_err"])[0])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+
+    from gpemu import synthetic
+    from gpemu.model import DeviceModel
+    from gpemu.sampler import DeviceSampler
+
+    wl = build_workload()
+    prob = wl["prob"]
+    dm = DeviceModel(X_train=prob["design"], ls=wl["ls"], alpha=wl["alpha"], L=wl["L"],
+                     components=wl["components"], scaler_mean=wl["mean"], scaler_scale=wl["scale"],
+                     kernel_kind=0, noise=wl["noise"], cov_unexplained=wl["cun"], device=dev_index)
+    dm.likelihood_setup(prob["y_exp"], prob["y_err"], prob["lo"], prob["hi"], 1.0)
+    ds = DeviceSampler([dm], N_WALKERS, a=2.0, seed=1)
+    ds.set_state(synthetic.make_walkers(N_WALKERS, seed=1))
+
+    def run(steps):
+        if world > 1:
+            ds.run_sharded(steps, store=True)
+        else:
+            ds.run(steps, store=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dm.sync()
+
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    evals = N_WALKERS * args.steps
+
+    # second pass of the same K steps with HIP events around every launch of the hot kernels
+    dm.profile(True)
+    run(args.steps)
+    barrier()
+    prof = dm.profile_read()
+    dm.profile(False)
+    ms_tot, n_launch = prof["trmm_vsq"]
+    roofline = None
+    if n_launch > 0:
+        evals_per_launch = (N_WALKERS * args.steps) / n_launch      # 512 at N = 1, 512 / world sharded
+        flop_per_launch = N_PC * N_DESIGN ** 2 * evals_per_launch
+        avg_s = ms_tot / n_launch * 1e-3
+        achieved = flop_per_launch / avg_s / 1e12
+        roofline = {"bound": "mfma", "kernel": "trmm_vsq_kernel", "achieved": achieved,
+                    "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_us": avg_s * 1e6, "launches": n_launch,
+                    "kstar_avg_launch_us": prof["kstar"][0] / max(prof["kstar"][1], 1) * 1e3}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline()
+        except Exception as e:  # the baseline is a reported figure; never lose the GPU line over it
+            cpu = {"value": None, "error": repr(e)}
+
+    nacc, iters, _ = ds.counts()
+    if rank == 0:
+        out = {"metric": "log-posterior evals/sec", "value": evals / dt, "unit": "evals/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "C3: N_design=1000 x N_obs=500, 10 PCs, d=6, 1024-walker "
+                                      "stretch-move MCMC, RBF+White fixed theta",
+                          "n_walkers": N_WALKERS, "evals_per_step": N_WALKERS,
+                          "parallelism": f"walkers sharded over {world} GPU(s)"},
+               "acceptance_fraction_mean": float((nacc / max(iters, 1)).mean()),
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    ds.close()
+    dm.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,158 @@
+/*
+ * gpemu.h -- C ABI of libgpemu.so: the MI355X (gfx950) implementation of the GP-emulator +
+ * MCMC log-posterior hot path of jdmulligan/bayesian-inference.
+ *
+ * The reference has no FFI of its own (it is pure Python); each entry point below replaces the
+ * arithmetic behind one reference call site, cited as  ref: <file>:<lines>  relative to
+ * /root/reference/src/bayesian_inference/, and  skl: <file>:<lines>  for the scikit-learn 1.7.2
+ * code the reference delegates to.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  All real arrays are row-major float64, indices int64.
+ *   - Buffers are caller-allocated.  Functions named *_dev take DEVICE pointers and a hipStream_t
+ *     (passed as void*; NULL = the handle's own stream) and do not synchronise; the others take
+ *     HOST pointers, copy, run and synchronise before returning.
+ *   - Every function returns int: 0 = ok, <0 = argument / runtime error, >0 = numerical failure
+ *     (e.g. index+1 of a non-positive Cholesky pivot).  gpemu_last_error() gives the thread-local
+ *     message of the last failure.
+ *   - Opaque handles own all device memory they allocate and are bound to one HIP device.  A handle
+ *     is not thread-safe (one host thread per handle); calls release no Python state, so ctypes may
+ *     drop the GIL around them.
+ *   - There is NO CPU implementation behind these symbols: without a HIP device every compute
+ *     entry point fails with GPEMU_ERR_NO_DEVICE.
+ */
+#ifndef GPEMU_H
+#define GPEMU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPEMU_OK 0
+#define GPEMU_ERR_ARG (-1)
+#define GPEMU_ERR_HIP (-2)
+#define GPEMU_ERR_NO_DEVICE (-3)
+#define GPEMU_ERR_STATE (-4)
+#define GPEMU_ERR_UNSUPPORTED (-5)
+
+/* kernel_kind (ref: emulation.py:133-149) */
+#define GPEMU_KERNEL_RBF 0    /* skl gaussian_process/kernels.py:1553-1582 */
+#define GPEMU_KERNEL_MATERN 1 /* skl gaussian_process/kernels.py:1708-1781, nu in {0.5,1.5,2.5} */
+
+/* gpemu_logpost mode */
+#define GPEMU_LOGPOST_LOWRANK 0 /* k x k Woodbury form, the throughput path          */
+#define GPEMU_LOGPOST_EXACT 1   /* materialise Sigma (F x F) + batched Cholesky, reference form  */
+
+typedef struct gpemu_model gpemu_model;     /* one emulation group on one device */
+typedef struct gpemu_sampler gpemu_sampler; /* stretch-move ensemble over >= 1 groups */
+
+/* ---- library / device ------------------------------------------------------------------- */
+const char *gpemu_version(void);
+const char *gpemu_last_error(void);
+int gpemu_device_count(void); /* number of HIP devices, 0 if none (never an error) */
+int gpemu_device_name(int device, char *buf, int64_t buflen);
+
+/* ---- model: one emulation group --------------------------------------------------------- */
+/* Replaces the per-worker state of ref: log_posterior.py:26-38 (initialize_pool_variables) and
+ * the sklearn objects in the results dict of ref: emulation.py:181-192.
+ *   X_train[N*d]     design (GaussianProcessRegressor.X_train_)
+ *   ls[k*d]          per-PC ARD length scales of kernel_ (not logs)
+ *   constv[k]        ConstantKernel value per PC   (read iff has_const)
+ *   noise[k]         WhiteKernel noise level per PC (read iff has_noise)
+ *   alpha[k*N]       GaussianProcessRegressor.alpha_
+ *   L[k*N*N]         GaussianProcessRegressor.L_ (lower; the strict upper triangle is ignored)
+ *   components[k*F]  pca.components_[:k]
+ *   scaler_mean[F], scaler_scale[F]   StandardScaler
+ *   cov_unexplained[F*F]  ref: emulation.py:246-249, or NULL (then 0)
+ * The factor is inverted on the device once (W = L^-1) so that prediction is a triangular GEMM.
+ */
+int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int64_t F, int64_t k,
+                       int kernel_kind, double nu, int has_const, int has_noise,
+                       const double *X_train, const double *ls, const double *constv,
+                       const double *noise, const double *alpha, const double *L,
+                       const double *components, const double *scaler_mean,
+                       const double *scaler_scale, const double *cov_unexplained);
+int gpemu_model_destroy(gpemu_model *m);
+int gpemu_model_dims(const gpemu_model *m, int64_t *N, int64_t *d, int64_t *F, int64_t *k);
+int gpemu_model_device(const gpemu_model *m);
+int gpemu_model_sync(gpemu_model *m); /* wait for the handle's stream */
+/* Measurement aid for bench.py: when enabled, every launch of the two hot kernels is bracketed by
+ * HIP events on the stream it is launched on.  read -> ms_total[2], launches[2]:
+ * [0] = trmm_vsq_kernel (triangular GEMM, MFMA f64), [1] = kstar_kernel (cross-kernel build). */
+int gpemu_model_profile(gpemu_model *m, int enable);
+int gpemu_model_profile_read(gpemu_model *m, double *ms_total, int64_t *launches);
+
+/* ref: emulation.py:494-499 -> skl _gpr.py:441-494 (predict(X, return_std=True), std squared):
+ * X[B*d] -> mean_out[B*k], var_out[B*k]  (negative variances clipped to 0, skl _gpr.py:479-485) */
+int gpemu_gp_predict(gpemu_model *m, int64_t B, const double *X, double *mean_out, double *var_out);
+int gpemu_gp_predict_dev(gpemu_model *m, int64_t B, const double *dX, double *dmean, double *dvar,
+                         void *stream);
+
+/* ref: emulation.py:466-548 (predict_emulation_group): central_value[B*F], cov[B*F*F];
+ * n_div = the reference's n_samples divisor of the truncation covariance (emulation.py:531-532). */
+int gpemu_predict_full(gpemu_model *m, int64_t B, const double *X, double n_div, double *cv_out,
+                       double *cov_out);
+int gpemu_predict_full_dev(gpemu_model *m, int64_t B, const double *dX, double n_div, double *dcv,
+                           double *dcov, void *stream);
+
+/* ref: log_posterior.py:63-64, 73-74, 92-94: box prior + experimental data for this group's
+ * features (already gathered into the group's column order).  n_div as above (1 for MCMC). */
+int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_err,
+                           const double *lo, const double *hi, double n_div);
+
+/* ref: log_posterior.py:42-101 + 104-146: X[B*d] -> out[B]; rows outside the open box -> -inf.
+ * A non-positive-definite covariance yields NaN (the reference does not detect it either,
+ * log_posterior.py:125-135). */
+int gpemu_logpost(gpemu_model *m, int64_t B, const double *X, double *out, int mode);
+int gpemu_logpost_dev(gpemu_model *m, int64_t B, const double *dX, double *dout, int mode,
+                      void *stream);
+
+/* ---- stretch-move ensemble sampler ------------------------------------------------------------
+ * Replaces ref: mcmc.py:77-107, 187-204: emcee.EnsembleSampler(n_walkers, ndim, log_posterior,
+ * pool=Pool()) with its default StretchMove(a=2) and the pool.map over walkers.  The ensemble,
+ * the proposals, the accept/reject and the chain live on the device; the log-posterior is the sum
+ * over the given emulation groups (block-diagonal covariance, ref: emulation.py:346-406), each with
+ * n_div = 1 (emcee evaluates one walker per call).
+ */
+int gpemu_sampler_create(gpemu_sampler **out, gpemu_model *const *groups, int n_groups, int64_t W,
+                         double a, uint64_t seed);
+int gpemu_sampler_destroy(gpemu_sampler *s);
+int gpemu_sampler_set_stream(gpemu_sampler *s, void *stream); /* NULL = the first group's stream */
+/* X0[W*d]; logp0[W] or NULL to evaluate it (ref: mcmc.py:88, emcee State(initial_state)) */
+int gpemu_sampler_set_state(gpemu_sampler *s, const double *X0, const double *logp0);
+int gpemu_sampler_get_state(gpemu_sampler *s, double *X, double *logp);
+int gpemu_sampler_reset(gpemu_sampler *s); /* emcee sampler.reset(): drop chain + acceptance counts */
+/* `steps` full stretch-move steps with device-side Philox randomness; returns 1 if any proposal's
+ * log-probability was NaN (emcee raises ValueError). */
+int gpemu_sampler_run(gpemu_sampler *s, int64_t steps, int store_chain);
+/* One step with host-supplied randomness in emcee's draw order: inds[W] = the shuffled split,
+ * then for split 0 (first ceil(W/2) entries) and split 1 (rest): zz = ((a-1)u+1)^2/a, rint in
+ * [0, Nc), logu = log(u').  Used to replay a numpy RandomState stream. */
+int gpemu_sampler_step_host_rng(gpemu_sampler *s, const int32_t *inds, const double *zz,
+                                const int64_t *rint, const double *logu, int store_chain);
+/* chain_out[n*W*d] (emcee get_chain()[first:first+n]), logp_out[n*W] (get_log_prob()) */
+int gpemu_sampler_get_chain(gpemu_sampler *s, int64_t first, int64_t n, double *chain_out,
+                            double *logp_out);
+int gpemu_sampler_get_counts(gpemu_sampler *s, int64_t *naccepted /*[W]*/, int64_t *iterations,
+                             int64_t *chain_len);
+/* Phases of one step for the multi-GPU driver: every rank holds the whole ensemble and draws the
+ * same randomness; rank r evaluates proposals [lo, hi) of the half and the ranks all-gather the
+ * new log-probabilities (RCCL, done by the caller on the sampler's stream) before accepting.
+ * dnewlp_* are DEVICE pointers. */
+int gpemu_sampler_begin_step(gpemu_sampler *s);
+int gpemu_sampler_half_propose_eval(gpemu_sampler *s, int half, int64_t lo, int64_t hi,
+                                    double *dnewlp_slice);
+int gpemu_sampler_half_accept(gpemu_sampler *s, int half, const double *dnewlp_all);
+int gpemu_sampler_end_step(gpemu_sampler *s, int store_chain);
+int gpemu_sampler_check(gpemu_sampler *s); /* synchronise; 1 if a NaN log-probability was seen */
+
+/* Philox4x32-10 block function (host copy of the device generator; for tests) */
+int gpemu_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                     uint32_t *out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPEMU_H */

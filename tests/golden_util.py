@@ -60,3 +60,22 @@ def fixed_theta_model(N, F, k, seed=0, ls_factor=0.5, noise=0.05, jitter=1e-10, 
                          explained_variance=pca["explained_variance"], scaler_mean=mean,
                          scaler_scale=scale, n_pc=k)
     return model, prob, pca
+
+
+def device_model(model, device=0, with_cov_unexplained=True):
+    """Upload an oracle GroupModel to the GPU through the C ABI (tests only)."""
+    from gpemu.model import DeviceModel
+    spec = model.spec
+    k = model.n_pc
+    return DeviceModel(
+        X_train=model.X_train,
+        ls=np.stack([gp.ls for gp in model.gps]),
+        alpha=np.stack([gp.alpha for gp in model.gps]),
+        L=np.stack([gp.L for gp in model.gps]),
+        components=model.components[:k],
+        scaler_mean=model.scaler_mean, scaler_scale=model.scaler_scale,
+        kernel_kind=spec.kind, nu=spec.nu,
+        const=np.array([gp.const for gp in model.gps]) if spec.has_const else None,
+        noise=np.array([gp.noise for gp in model.gps]) if spec.has_noise else None,
+        cov_unexplained=O.cov_unexplained(model) if with_cov_unexplained else None,
+        device=device)

@@ -1,0 +1,138 @@
+"""-m gpu parity tests: the HIP path (through the C ABI) against the CPU oracle and the goldens.
+
+Tolerance (BASELINE.json north_star): 1e-6 relative on GP predictive mean / covariance and on the
+log-posterior.  Observed errors are ~1e-12; the asserts use 1e-8 to leave no doubt.
+"""
+import numpy as np
+import pytest
+
+import golden_util as GU
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-8
+SYN = ["g1_rbf_noise", "g1_matern15_noise", "g1_matern25_const_noise", "g1_rbf_only", "g2_rbf_noise"]
+
+
+def relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _load(name):
+    g = GU.load(name)
+    design = GU.load("observables_fixture")["design"] if name.startswith("g3") else None
+    return g, GU.group_model(g, design=design)
+
+
+@pytest.mark.parametrize("name", SYN + ["g3_realdata_matern15"])
+def test_gp_predict_vs_golden_and_oracle(name):
+    g, model = _load(name)
+    dm = GU.device_model(model)
+    Xq = g["Xq"]
+    m, v = dm.gp_predict(Xq)
+    assert relerr(m, g["gp_mean"]) < TOL
+    # variances can be ~1e-10 at noise-free training points; compare on the kernel-diagonal scale
+    vscale = max(1.0, np.max(g["gp_var"]))
+    assert np.max(np.abs(v - g["gp_var"])) < TOL * vscale
+    mo, vo = O.gp_predict_all(Xq, model)
+    assert relerr(m, mo) < TOL and np.max(np.abs(v - vo)) < TOL * vscale
+    # ragged batches: B = 1 and B = 3 give the same rows
+    m1, v1 = dm.gp_predict(Xq[:1])
+    m3, v3 = dm.gp_predict(Xq[5:8])
+    np.testing.assert_allclose(m1, m[:1], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(v3, v[5:8], rtol=1e-13, atol=1e-13)
+    dm.close()
+
+
+@pytest.mark.parametrize("name", SYN + ["g3_realdata_matern15"])
+def test_predict_full_vs_golden(name):
+    g, model = _load(name)
+    dm = GU.device_model(model)
+    Xq = g["Xq"]
+    cv, cov = dm.predict_full(Xq)          # n_div = B, the reference's batch semantics
+    assert relerr(cv, g["batch_central_value"]) < TOL
+    nh = g["batch_cov_head"].shape[0]
+    assert relerr(cov[:nh], g["batch_cov_head"]) < TOL
+    for i in range(g["single_cov_head"].shape[0]):
+        cv1, cov1 = dm.predict_full(Xq[i:i + 1])
+        assert relerr(cv1[0], g["single_central_value"][i]) < TOL
+        assert relerr(cov1[0], g["single_cov_head"][i]) < TOL
+    # full oracle comparison incl. symmetry
+    po = O.predict_group(Xq[:8], model)
+    cv8, cov8 = dm.predict_full(Xq[:8])
+    assert relerr(cov8, po["cov"]) < TOL and relerr(cv8, po["central_value"]) < TOL
+    assert np.max(np.abs(cov8 - np.swapaxes(cov8, 1, 2))) <= 1e-14 * np.max(np.abs(cov8))
+    dm.close()
+
+
+@pytest.mark.parametrize("name", SYN + ["g3_realdata_matern15"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_logpost_vs_golden(name, mode):
+    g, model = _load(name)
+    dm = GU.device_model(model)
+    Xq = g["Xq"]
+    lo, hi = g["lo"], g["hi"]
+    # MCMC semantics: n_div = 1, whole batch in one launch == per-walker reference calls
+    dm.likelihood_setup(g["y_exp"], g["y_err"], lo, hi, n_div=1.0)
+    nper = g["logpost_per_walker"].shape[0]
+    lp = dm.logpost(Xq[:nper], mode=mode)
+    np.testing.assert_allclose(lp, g["logpost_per_walker"], rtol=TOL)
+    # batch semantics of the reference: cov_unexplained / n_in_bounds
+    dm.likelihood_setup(g["y_exp"], g["y_err"], lo, hi, n_div=float(Xq.shape[0]))
+    np.testing.assert_allclose(dm.logpost(Xq, mode=mode), g["logpost_batched"], rtol=TOL)
+    # rows outside the open box -> -inf; in-bounds rows use n_div = number of in-bounds rows
+    Xm, ref = g["X_mixed"], g["logpost_mixed"]
+    n_in = int(np.isfinite(ref).sum())
+    dm.likelihood_setup(g["y_exp"], g["y_err"], lo, hi, n_div=float(n_in))
+    lm = dm.logpost(Xm, mode=mode)
+    assert np.array_equal(np.isneginf(lm), np.isneginf(ref))
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(lm[fin], ref[fin], rtol=TOL)
+    dm.close()
+
+
+def test_c3_shape_golden_and_properties():
+    """N=1000, F=500, k=10 (BASELINE config 3): golden values + size-independent properties."""
+    g = GU.load("g4_c3_fixed_theta")
+    model, prob, _ = GU.fixed_theta_model(int(g["N"]), int(g["F"]), int(g["n_pc"]), seed=int(g["seed"]))
+    dm = GU.device_model(model)
+    Xq = g["Xq"]
+    m, v = dm.gp_predict(Xq)
+    assert relerr(m, g["gp_mean"]) < TOL and np.max(np.abs(v - g["gp_var"])) < TOL
+    dm.likelihood_setup(g["y_exp"], g["y_err"], prob["lo"], prob["hi"], 1.0)
+    np.testing.assert_allclose(dm.logpost(Xq), g["logpost_per_walker"], rtol=TOL)
+    np.testing.assert_allclose(dm.logpost(Xq, mode=1), g["logpost_per_walker"], rtol=TOL)
+    cv1, cov1 = dm.predict_full(Xq[:1])
+    assert relerr(cv1[0], g["single_central_value"][0]) < TOL
+    assert relerr(np.diag(cov1[0]), g["single_cov_diag"][0]) < TOL
+    assert relerr(cov1[0][0], g["single_cov_row0"][0]) < TOL
+    # full BASELINE batch (1024 walkers): batch-composition independence + training-point property
+    from gpemu import synthetic
+    W = synthetic.make_walkers(1024, seed=1)
+    lp_all = dm.logpost(W)
+    lp_a = dm.logpost(W[:512])
+    lp_b = dm.logpost(W[512:])
+    np.testing.assert_array_equal(lp_all, np.r_[lp_a, lp_b])       # bit-identical
+    sub = np.arange(0, 1024, 37)
+    lo = np.array([O.log_posterior(W[i], {"g": model}, prob["lo"], prob["hi"], g["y_exp"], g["y_err"])[0]
+                   for i in sub[:6]])
+    np.testing.assert_allclose(lp_all[sub[:6]], lo, rtol=TOL)
+    # at the training inputs the predictive mean reproduces K alpha (interpolation property)
+    Xt = prob["design"][:64]
+    mt, vt = dm.gp_predict(Xt)
+    mo, vo = O.gp_predict_all(Xt, model)
+    assert relerr(mt, mo) < TOL and np.max(np.abs(vt - vo)) < TOL
+    dm.close()
+
+
+def test_argument_errors():
+    from gpemu._lib import GpemuError
+    g, model = _load("g1_rbf_noise")
+    dm = GU.device_model(model)
+    with pytest.raises(GpemuError):
+        dm.logpost(g["Xq"])          # likelihood_setup not called -> state error, not a crash
+    with pytest.raises(ValueError):
+        dm.gp_predict(np.zeros((3, 5)))
+    dm.close()
