@@ -256,6 +256,7 @@ int gpemu_model_destroy(gpemu_model *m) {
   hipFree(m->alpha); hipFree(m->Wt); hipFree(m->comp); hipFree(m->smean); hipFree(m->sscale);
   hipFree(m->cunexpl); hipFree(m->yexp); hipFree(m->yerr); hipFree(m->lo); hipFree(m->hi);
   hipFree(m->G); hipFree(m->g0); hipFree(m->scal); hipFree(m->exact_scratch);
+  hipFree(m->blk_start); hipFree(m->blk_of);
   free_workspace(m->ws);
   for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
   if (m->stream) hipStreamDestroy(m->stream);
@@ -345,17 +346,40 @@ int gpemu_gp_predict(gpemu_model *m, int64_t B, const double *X, double *mean_ou
 
 // ---- likelihood ----------------------------------------------------------------------------------
 int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_err,
-                           const double *lo, const double *hi, double n_div) {
+                           const double *lo, const double *hi, double n_div, int64_t n_blocks,
+                           const int64_t *block_start) {
   GP_ARG(m && y_exp && y_err && lo && hi, "null pointer");
   GP_ARG(n_div >= 1.0, "n_div must be >= 1");
   GP_HIP(hipSetDevice(m->device));
   hipStream_t st = m->stream;
   const int64_t F = m->F, k = m->k;
+  // observable blocks (default: one block = the whole group)
+  std::vector<int> hstart, hof((size_t)F, 0);
+  if (n_blocks <= 0 || !block_start) {
+    hstart = {0, (int)F};
+  } else {
+    GP_ARG(block_start[0] == 0 && block_start[n_blocks] == F, "block_start must cover [0, F]");
+    for (int64_t o = 0; o <= n_blocks; ++o) {
+      if (o > 0) GP_ARG(block_start[o] > block_start[o - 1], "block_start must be increasing");
+      hstart.push_back((int)block_start[o]);
+    }
+  }
+  const int64_t nblk = (int64_t)hstart.size() - 1;
+  for (int64_t o = 0; o < nblk; ++o)
+    for (int f = hstart[o]; f < hstart[o + 1]; ++f) hof[f] = (int)o;
+  GP_HIP(hipStreamSynchronize(st));
   if (!m->yexp) {
     GP_TRY(dev_alloc(&m->yexp, F)); GP_TRY(dev_alloc(&m->yerr, F));
     GP_TRY(dev_alloc(&m->lo, DPAD)); GP_TRY(dev_alloc(&m->hi, DPAD));
-    GP_TRY(dev_alloc(&m->G, k * k)); GP_TRY(dev_alloc(&m->g0, k)); GP_TRY(dev_alloc(&m->scal, 2));
+    GP_TRY(dev_alloc(&m->blk_of, F));
   }
+  (void)hipFree(m->G); (void)hipFree(m->g0); (void)hipFree(m->scal); (void)hipFree(m->blk_start);
+  m->G = m->g0 = m->scal = nullptr; m->blk_start = nullptr;
+  GP_TRY(dev_alloc(&m->G, nblk * k * k)); GP_TRY(dev_alloc(&m->g0, nblk * k));
+  GP_TRY(dev_alloc(&m->scal, 2 * nblk)); GP_TRY(dev_alloc(&m->blk_start, nblk + 1));
+  m->nblk = nblk;
+  GP_HIP(hipMemcpyAsync(m->blk_start, hstart.data(), sizeof(int) * (nblk + 1), hipMemcpyHostToDevice, st));
+  GP_HIP(hipMemcpyAsync(m->blk_of, hof.data(), sizeof(int) * F, hipMemcpyHostToDevice, st));
   m->lik_ready = false;
   m->n_div = n_div;
   double hlo[DPAD], hhi[DPAD];
@@ -366,21 +390,24 @@ int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_
   double *dA = nullptr, *dPT = nullptr, *dZ = nullptr;
   int *dinfo = nullptr;
   int rc = dev_alloc(&dA, F * F);
-  if (rc == GPEMU_OK) rc = dev_alloc(&dPT, chol_scratch_size(F));
+  if (rc == GPEMU_OK) rc = dev_alloc(&dPT, nblk * chol_scratch_size(F));
   if (rc == GPEMU_OK) rc = dev_alloc(&dZ, F * (k + 1));
-  if (rc == GPEMU_OK) rc = dev_alloc(&dinfo, 1);
-  int info = 0;
+  if (rc == GPEMU_OK) rc = dev_alloc(&dinfo, nblk);
+  std::vector<int> info((size_t)nblk, 0);
   if (rc == GPEMU_OK) rc = launch_lik_setup(m, dA, dPT, dZ, dinfo, st);
   if (rc == GPEMU_OK) {
-    hipError_t e = hipMemcpyAsync(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost, st);
+    hipError_t e = hipMemcpyAsync(info.data(), dinfo, sizeof(int) * nblk, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { set_error("likelihood_setup: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
   }
   hipFree(dA); hipFree(dPT); hipFree(dZ); hipFree(dinfo);
   if (rc != GPEMU_OK) return rc;
-  if (info != 0) {
-    set_error("likelihood_setup: A = C_unexpl/n o ss^T + diag(y_err^2) is not positive definite (pivot %d)", info);
-    return info;
+  for (int64_t o = 0; o < nblk; ++o) {
+    if (info[o] != 0) {
+      set_error("likelihood_setup: A = C_unexpl/n o ss^T + diag(y_err^2) is not positive definite "
+                "(observable block %lld, pivot %d)", (long long)o, info[o]);
+      return hstart[o] + info[o];
+    }
   }
   m->lik_ready = true;
   return GPEMU_OK;

@@ -79,9 +79,12 @@ struct gpemu_model {
   bool lik_ready = false;
   double n_div = 1.0;
   double *yexp = nullptr, *yerr = nullptr, *lo = nullptr, *hi = nullptr;  // [F],[F],[DPAD],[DPAD]
-  double *G = nullptr;         // [k][k]   U^T A^-1 U
-  double *g0 = nullptr;        // [k]      U^T A^-1 r0
-  double *scal = nullptr;      // [2]      q0, logdetA
+  int64_t nblk = 1;            // observable blocks of the (block-diagonal) covariance
+  int *blk_start = nullptr;    // [nblk+1] first feature of each block
+  int *blk_of = nullptr;       // [F]      block index of each feature
+  double *G = nullptr;         // [nblk][k][k]   U_o^T A_o^-1 U_o
+  double *g0 = nullptr;        // [nblk][k]      U_o^T A_o^-1 r0_o
+  double *scal = nullptr;      // [nblk][2]      q0_o, logdet A_o
 
   // exact-form (validation) scratch: per-workgroup Sigma, panel and residual
   double *exact_scratch = nullptr;

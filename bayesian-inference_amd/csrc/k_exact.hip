@@ -109,7 +109,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void loglik_exact_kernel(
     const double *__restrict__ kdiag, const double *__restrict__ comp,
     const double *__restrict__ smean, const double *__restrict__ sscale,
     const double *__restrict__ cun, const double *__restrict__ yexp, const double *__restrict__ yerr,
-    double *__restrict__ scratch, double *__restrict__ out, int64_t B, int64_t Bcap, int d, int F,
+    const int *__restrict__ blk_of, double *__restrict__ scratch, double *__restrict__ out, int64_t B,
+    int64_t Bcap, int d, int F,
     int k, int nchunk, int nrb, double inv_ndiv) {
   __shared__ double s_mu[64], s_var[64];
   __shared__ int s_inside;
@@ -143,6 +144,10 @@ __global__ __launch_bounds__(CHOL_THREADS) void loglik_exact_kernel(
     for (int64_t idx = tid; idx < (int64_t)F * F; idx += nthr) {
       int f = (int)(idx / F), g = (int)(idx - (int64_t)f * F);
       if (g > f) continue;
+      if (blk_of[f] != blk_of[g]) {  // cross-observable covariance is dropped by the reference's merge
+        S[idx] = 0.0;
+        continue;
+      }
       double acc = 0.0;
       for (int p = 0; p < k; ++p) acc = fma(comp[(int64_t)p * F + f] * s_var[p], comp[(int64_t)p * F + g], acc);
       double v = (acc + cun[idx] * inv_ndiv) * (sscale[f] * sscale[g]);
@@ -182,7 +187,7 @@ int launch_loglik_exact(gpemu_model *m, int64_t B, const double *dXq, double *do
   const Workspace &w = m->ws;
   hipLaunchKernelGGL(loglik_exact_kernel, dim3((unsigned)nwg), dim3(CHOL_THREADS), 0, st, dXq, m->lo,
                      m->hi, w.mean_part, w.vsq_part, m->kdiag, m->comp, m->smean, m->sscale,
-                     m->cunexpl, m->yexp, m->yerr, m->exact_scratch, dout, B, w.Bcap, (int)m->d,
+                     m->cunexpl, m->yexp, m->yerr, m->blk_of, m->exact_scratch, dout, B, w.Bcap, (int)m->d,
                      F, (int)m->k, (int)(m->Npad / JCHUNK), (int)(m->Npad / TILE), 1.0 / m->n_div);
   GP_HIP(hipGetLastError());
   return GPEMU_OK;

@@ -9,6 +9,11 @@
 //             -1/2 [ log det A + 2 sum log diag L_M ],     M = I + D^1/2 G D^1/2 = L_M L_M^T,
 // with G = U^T A^-1 U, g0 = U^T A^-1 r0, q0 = r0^T A^-1 r0 computed once per (model, n_div) on the
 // device (setup kernel below).  The symmetric D^1/2 form stays finite when a variance is clipped to 0.
+//
+// Observable blocks: the reference's merge step keeps only the within-observable blocks of the
+// covariance (ref: emulation.py:370-388, SortEmulationGroupObservables.convert + nd_block_diag), so
+// Sigma is block diagonal over the observables of the group and the likelihood is a sum over
+// blocks o, each of the form above with its own (G_o, g0_o, q0_o, logdet A_o) and the same m, var.
 #include "internal.h"
 #include "linalg_dev.h"
 
@@ -26,31 +31,37 @@ __global__ void build_A_kernel(const double *__restrict__ cun, const double *__r
   A[idx] = v;
 }
 
-// one workgroup: chol(A); Z = C^-1 [U | r0]; G = Zu^T Zu; g0 = Zu^T zr; q0 = zr^T zr; logdetA
+// one workgroup per observable block o (features f0..f1): chol(A_o); Z = C^-1 [U_o | r0_o];
+// G_o = Zu^T Zu; g0_o = Zu^T zr; q0_o = zr^T zr; logdet A_o
 __global__ __launch_bounds__(CHOL_THREADS) void lik_setup_kernel(
     double *A, double *PT, double *Z /*[F][k+1]*/, const double *__restrict__ comp,
     const double *__restrict__ s, const double *__restrict__ smean, const double *__restrict__ yexp,
-    double *G, double *g0, double *scal, int F, int k, int *info) {
+    const int *__restrict__ blk_start, double *G, double *g0, double *scal, int F, int k, int *info) {
   const int tid = threadIdx.x, nthr = blockDim.x;
+  const int o = blockIdx.x;
+  const int f0 = blk_start[o], nf = blk_start[o + 1] - f0;
   const int k1 = k + 1;
-  for (int idx = tid; idx < F * k1; idx += nthr) {
-    int f = idx / k1, p = idx - f * k1;
-    Z[idx] = (p < k) ? s[f] * comp[(int64_t)p * F + f] : (smean[f] - yexp[f]);
+  double *Ao = A + (int64_t)f0 * F + f0;
+  double *Zo = Z + (int64_t)f0 * k1;
+  double *PTo = PT + (int64_t)o * chol_scratch_size(F);
+  for (int idx = tid; idx < nf * k1; idx += nthr) {
+    int f = f0 + idx / k1, p = idx % k1;
+    Zo[idx] = (p < k) ? s[f] * comp[(int64_t)p * F + f] : (smean[f] - yexp[f]);
   }
-  wg_cholesky_lower(A, F, F, PT, info);
-  wg_forward_solve_multi(A, F, F, Z, k1, k1);
+  wg_cholesky_lower(Ao, nf, F, PTo, info + o);
+  wg_forward_solve_multi(Ao, nf, F, Zo, k1, k1);
   for (int idx = tid; idx < k1 * k1; idx += nthr) {
     int p = idx / k1, q = idx - p * k1;
     double acc = 0.0;
-    for (int f = 0; f < F; ++f) acc = fma(Z[(int64_t)f * k1 + p], Z[(int64_t)f * k1 + q], acc);
-    if (p < k && q < k) G[p * k + q] = acc;
-    else if (p < k && q == k) g0[p] = acc;
-    else if (p == k && q == k) scal[0] = acc;
+    for (int f = 0; f < nf; ++f) acc = fma(Zo[(int64_t)f * k1 + p], Zo[(int64_t)f * k1 + q], acc);
+    if (p < k && q < k) G[((int64_t)o * k + p) * k + q] = acc;
+    else if (p < k && q == k) g0[(int64_t)o * k + p] = acc;
+    else if (p == k && q == k) scal[2 * o] = acc;
   }
   double ld = 0.0;
-  for (int f = tid; f < F; f += nthr) ld += log(A[(int64_t)f * F + f]);
+  for (int f = tid; f < nf; f += nthr) ld += log(Ao[(int64_t)f * F + f]);
   ld = wg_sum(ld);
-  if (tid == 0) scal[1] = 2.0 * ld;
+  if (tid == 0) scal[2 * o + 1] = 2.0 * ld;
 }
 
 int launch_lik_setup(gpemu_model *m, double *dA, double *dPT, double *dZ, int *dinfo, hipStream_t st) {
@@ -58,8 +69,9 @@ int launch_lik_setup(gpemu_model *m, double *dA, double *dPT, double *dZ, int *d
   int64_t n = (int64_t)F * F;
   hipLaunchKernelGGL(build_A_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->cunexpl,
                      m->sscale, m->yerr, dA, F, 1.0 / m->n_div);
-  hipLaunchKernelGGL(lik_setup_kernel, dim3(1), dim3(CHOL_THREADS), 0, st, dA, dPT, dZ, m->comp,
-                     m->sscale, m->smean, m->yexp, m->G, m->g0, m->scal, F, (int)m->k, dinfo);
+  hipLaunchKernelGGL(lik_setup_kernel, dim3((unsigned)m->nblk), dim3(CHOL_THREADS), 0, st, dA, dPT, dZ,
+                     m->comp, m->sscale, m->smean, m->yexp, m->blk_start, m->G, m->g0, m->scal, F,
+                     (int)m->k, dinfo);
   GP_HIP(hipGetLastError());
   return GPEMU_OK;
 }
@@ -73,7 +85,7 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
     const double *__restrict__ kdiag, const double *__restrict__ G, const double *__restrict__ g0,
     const double *__restrict__ scal, double *__restrict__ out, double *__restrict__ mean_out,
     double *__restrict__ var_out, int64_t B, int64_t Bcap, int d, int k, int nchunk, int nrb,
-    int accumulate) {
+    int nblk, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -102,59 +114,63 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
     if (lane == 0) out[b] = -INFINITY;
     return;
   }
-  // h = G m + g0 ; quadA = m.(h + g0) + q0
-  double h = 0.0, gl = (lane < k) ? g0[lane] : 0.0;
-  for (int q = 0; q < k; ++q) {
-    double mq = __shfl(mu, q);
-    if (lane < k) h = fma(G[lane * k + q], mq, h);
-  }
-  h += gl;
-  double t = (lane < k) ? mu * (h + gl) : 0.0;
-  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-  const double quadA = t + scal[0];
-  // M = I + D^1/2 G D^1/2 (row `lane`)
-  for (int q = 0; q < k; ++q) {
-    double sq = __shfl(sd, q);
-    if (lane < k) M[lane * ldm + q] = ((lane == q) ? 1.0 : 0.0) + sd * G[lane * k + q] * sq;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  // in-wave Cholesky of M (k x k, lane = row), right-looking
-  double logdiag = 0.0;
-  for (int j = 0; j < k; ++j) {
-    double piv = sqrt(M[j * ldm + j]);
-    __builtin_amdgcn_wave_barrier();
-    if (lane == j) {
-      M[j * ldm + j] = piv;
-      logdiag = log(piv);
+  double total = 0.0;
+  for (int o = 0; o < nblk; ++o) {
+    const double *Go = G + (int64_t)o * k * k;
+    // h = G_o m + g0_o ; quadA = m.(h + g0_o) + q0_o
+    double h = 0.0, gl = (lane < k) ? g0[(int64_t)o * k + lane] : 0.0;
+    for (int q = 0; q < k; ++q) {
+      double mq = __shfl(mu, q);
+      if (lane < k) h = fma(Go[lane * k + q], mq, h);
     }
-    if (lane > j && lane < k) M[lane * ldm + j] = M[lane * ldm + j] / piv;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane > j && lane < k) {
-      double lij = M[lane * ldm + j];
-      for (int c = j + 1; c <= lane; ++c) M[lane * ldm + c] -= lij * M[c * ldm + j];
+    h += gl;
+    double t = (lane < k) ? mu * (h + gl) : 0.0;
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    const double quadA = t + scal[2 * o];
+    // M = I + D^1/2 G_o D^1/2 (row `lane`)
+    for (int q = 0; q < k; ++q) {
+      double sq = __shfl(sd, q);
+      if (lane < k) M[lane * ldm + q] = ((lane == q) ? 1.0 : 0.0) + sd * Go[lane * k + q] * sq;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // in-wave Cholesky of M (k x k, lane = row), right-looking
+    double logdiag = 0.0;
+    for (int j = 0; j < k; ++j) {
+      double piv = sqrt(M[j * ldm + j]);
+      __builtin_amdgcn_wave_barrier();
+      if (lane == j) {
+        M[j * ldm + j] = piv;
+        logdiag = log(piv);
+      }
+      if (lane > j && lane < k) M[lane * ldm + j] = M[lane * ldm + j] / piv;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane > j && lane < k) {
+        double lij = M[lane * ldm + j];
+        for (int c = j + 1; c <= lane; ++c) M[lane * ldm + c] -= lij * M[c * ldm + j];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // w = L_M^-1 (sd o h)
+    double y = (lane < k) ? sd * h : 0.0;
+    for (int j = 0; j < k; ++j) {
+      double zj = __shfl(y, j) / M[j * ldm + j];
+      if (lane == j) y = zj;
+      if (lane > j && lane < k) y = fma(-M[lane * ldm + j], zj, y);
+    }
+    double ww = (lane < k) ? y * y : 0.0;
+    double ldsum = logdiag;
+    for (int off = 32; off > 0; off >>= 1) {
+      ww += __shfl_xor(ww, off);
+      ldsum += __shfl_xor(ldsum, off);
+    }
+    total += -0.5 * (quadA - ww) - 0.5 * (scal[2 * o + 1] + 2.0 * ldsum);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  // w = L_M^-1 (sd o h)
-  double y = (lane < k) ? sd * h : 0.0;
-  for (int j = 0; j < k; ++j) {
-    double zj = __shfl(y, j) / M[j * ldm + j];
-    if (lane == j) y = zj;
-    if (lane > j && lane < k) y = fma(-M[lane * ldm + j], zj, y);
-  }
-  double ww = (lane < k) ? y * y : 0.0;
-  double ldsum = logdiag;
-  for (int off = 32; off > 0; off >>= 1) {
-    ww += __shfl_xor(ww, off);
-    ldsum += __shfl_xor(ldsum, off);
-  }
-  if (lane == 0) {
-    double lp = -0.5 * (quadA - ww) - 0.5 * (scal[1] + 2.0 * ldsum);
-    out[b] = accumulate ? out[b] + lp : lp;
-  }
+  if (lane == 0) out[b] = accumulate ? out[b] + total : total;
 }
 
 int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq, double *dout, int accumulate,
@@ -165,7 +181,7 @@ int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq, double *
   hipLaunchKernelGGL(loglik_lowrank_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), shm, st, dXq,
                      m->lo, m->hi, w.mean_part, w.vsq_part, m->kdiag, m->G, m->g0, m->scal, dout,
                      w.mean, w.var, B, w.Bcap, (int)m->d, k, (int)(m->Npad / JCHUNK),
-                     (int)(m->Npad / TILE), accumulate);
+                     (int)(m->Npad / TILE), (int)m->nblk, accumulate);
   GP_HIP(hipGetLastError());
   return GPEMU_OK;
 }

@@ -106,14 +106,21 @@ class DeviceModel:
                                             ptr(cv), ptr(cov)))
         return cv, cov
 
-    def likelihood_setup(self, y_exp, y_err, lo, hi, n_div=1.0):
+    def likelihood_setup(self, y_exp, y_err, lo, hi, n_div=1.0, block_start=None):
+        """Data, box prior and the observable block boundaries of this group (``block_start`` =
+        first feature of each observable plus F at the end; None = a single block)."""
         y_exp = as_f64(y_exp, (self.F,))
         y_err = as_f64(y_err, (self.F,))
         lo = as_f64(lo, (self.d,))
         hi = as_f64(hi, (self.d,))
+        bs = None
+        nb = 0
+        if block_start is not None:
+            bs = np.ascontiguousarray(block_start, dtype=np.int64)
+            nb = bs.size - 1
         check(_lib.lib().gpemu_likelihood_setup(self._h, ptr(y_exp), ptr(y_err), ptr(lo), ptr(hi),
-                                                float(n_div)))
-        self._lik_key = float(n_div)
+                                                float(n_div), nb, ptr(bs)))
+        self._lik_key = (float(n_div), None if bs is None else tuple(bs.tolist()))
 
     def logpost(self, X, mode=LOWRANK):
         X = self._X(X)

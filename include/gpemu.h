@@ -98,9 +98,13 @@ int gpemu_predict_full_dev(gpemu_model *m, int64_t B, const double *dX, double n
                            double *dcov, void *stream);
 
 /* ref: log_posterior.py:63-64, 73-74, 92-94: box prior + experimental data for this group's
- * features (already gathered into the group's column order).  n_div as above (1 for MCMC). */
+ * features (already gathered into the group's column order).  n_div as above (1 for MCMC).
+ * block_start[n_blocks+1]: first feature of every observable of the group (ascending, 0 .. F).
+ * The reference's merge keeps only within-observable covariance blocks (ref: emulation.py:370-388),
+ * so the likelihood factorises over these blocks.  n_blocks <= 0 or NULL = one block (whole group). */
 int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_err,
-                           const double *lo, const double *hi, double n_div);
+                           const double *lo, const double *hi, double n_div, int64_t n_blocks,
+                           const int64_t *block_start);
 
 /* ref: log_posterior.py:42-101 + 104-146: X[B*d] -> out[B]; rows outside the open box -> -inf.
  * A non-positive-definite covariance yields NaN (the reference does not detect it either,

@@ -353,3 +353,23 @@ def loglik_lowrank(m, var, st):
     w = solve_triangular(LM, sd * h, lower=True, check_finite=False)
     quad = m @ G @ m + 2 * m @ g0 + q0 - w @ w
     return -0.5 * quad - 0.5 * (st["logdetA"] + 2 * np.log(np.diag(LM)).sum())
+
+
+def lowrank_setup_blocks(model: GroupModel, y_exp, y_err, block_start, n_div=1, cov_unexpl=None):
+    """Per-observable low-rank setups: the reference's merge keeps only the within-observable
+    covariance blocks (ref: emulation.py:370-388), so Sigma is block diagonal over observables."""
+    full = lowrank_setup(model, y_exp, y_err, n_div, cov_unexpl)
+    out = []
+    for o in range(len(block_start) - 1):
+        sl = slice(int(block_start[o]), int(block_start[o + 1]))
+        A, U, r0 = full["A"][sl, sl], full["U"][sl], full["r0"][sl]
+        cA = cholesky(A, lower=True, check_finite=False)
+        AiU = cho_solve((cA, True), U, check_finite=False)
+        Air0 = cho_solve((cA, True), r0, check_finite=False)
+        out.append(dict(G=U.T @ AiU, g0=U.T @ Air0, q0=float(r0 @ Air0),
+                        logdetA=float(2 * np.log(np.diag(cA)).sum())))
+    return out
+
+
+def loglik_lowrank_blocks(m, var, setups):
+    return sum(loglik_lowrank(m, var, st) for st in setups)

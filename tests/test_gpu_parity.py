@@ -127,6 +127,22 @@ def test_c3_shape_golden_and_properties():
     dm.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_multigroup_observable_blocks_vs_reference_merge(mode):
+    """Two groups, three observables: sum over groups of the block-structured likelihood equals the
+    reference's merged log_posterior (ref: emulation.py:346-406), per walker and batched."""
+    g = GU.load("g5_multigroup")
+    Xq = g["Xq"]
+    for n_div, key in ((1.0, "logpost_per_walker"), (float(Xq.shape[0]), "logpost_batched")):
+        total = np.zeros(Xq.shape[0])
+        for grp, cols, bs in (("g1", g["cols_g1"], [0, 10, 22]), ("g2", g["cols_g2"], [0, 8])):
+            dm = GU.device_model(GU.group_model(g, prefix=grp + "_"))
+            dm.likelihood_setup(g["y_exp"][cols], g["y_err"][cols], g["lo"], g["hi"], n_div, block_start=bs)
+            total += dm.logpost(Xq, mode=mode)
+            dm.close()
+        np.testing.assert_allclose(total, g[key], rtol=TOL)
+
+
 def test_argument_errors():
     from gpemu._lib import GpemuError
     g, model = _load("g1_rbf_noise")

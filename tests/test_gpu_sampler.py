@@ -80,9 +80,9 @@ def test_multigroup_sampler_sums_groups():
     mapping = {"A": ("g1", slice(0, 10), slice(0, 10)), "B": ("g2", slice(10, 18), slice(0, 8)),
                "C": ("g1", slice(18, 30), slice(10, 22))}
     dms = []
-    for grp, cols in (("g1", g["cols_g1"]), ("g2", g["cols_g2"])):
+    for grp, cols, bs in (("g1", g["cols_g1"], [0, 10, 22]), ("g2", g["cols_g2"], [0, 8])):
         dm = GU.device_model(models[grp])
-        dm.likelihood_setup(g["y_exp"][cols], g["y_err"][cols], g["lo"], g["hi"], 1.0)
+        dm.likelihood_setup(g["y_exp"][cols], g["y_err"][cols], g["lo"], g["hi"], 1.0, block_start=bs)
         dms.append(dm)
     W = 16
     ds = DeviceSampler(dms, W, seed=7)

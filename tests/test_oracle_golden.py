@@ -124,6 +124,19 @@ def test_multigroup_merge():
     np.testing.assert_allclose(per, g["logpost_per_walker"], rtol=1e-8)
 
 
+def test_multigroup_lowrank_blocks_equal_reference_merge():
+    """Sum over groups and observable blocks of the low-rank form == the reference's merged value."""
+    g = GU.load("g5_multigroup")
+    Xq = g["Xq"]
+    total = np.zeros(Xq.shape[0])
+    for grp, cols, bs in (("g1", g["cols_g1"], [0, 10, 22]), ("g2", g["cols_g2"], [0, 8])):
+        model = GU.group_model(g, prefix=grp + "_")
+        m, v = O.gp_predict_all(Xq, model)
+        sts = O.lowrank_setup_blocks(model, g["y_exp"][cols], g["y_err"][cols], bs, n_div=1)
+        total += np.array([O.loglik_lowrank_blocks(m[i], v[i], sts) for i in range(Xq.shape[0])])
+    np.testing.assert_allclose(total, g["logpost_per_walker"], rtol=1e-9)
+
+
 def test_c3_fixed_theta_golden():
     """C3 shape (N=1000, F=500, k=10): factors regenerated by the oracle from the seed."""
     g = GU.load("g4_c3_fixed_theta")
