@@ -81,12 +81,11 @@ def cpu_baseline(seconds_budget=20.0):
         t0 = time.time()
         pool.map(_cpu_eval, range(n), chunksize=1)
         dt = time.time() - t0
-        if dt < seconds_budget / 3:                              # extend the sample if it was quick
-            reps = int(min(8, seconds_budget / max(dt, 1e-3) / 2))
-            t0 = time.time()
-            pool.map(_cpu_eval, range(n * reps), chunksize=1)
-            dt = time.time() - t0
-            n *= reps
+        # size the timed sample for ~seconds_budget/2 of wall time (>= 10 s of CPU work on >= 2 cores)
+        n = int(max(n, min(20000, n * (seconds_budget / 2) / max(dt, 1e-3))))
+        t0 = time.time()
+        pool.map(_cpu_eval, range(n), chunksize=4)
+        dt = time.time() - t0
     return {"value": n / dt, "unit": "log-posterior evals/s", "cores": ncores, "kind": "port",
             "sample": f"{n} per-walker reference-form evaluations of the C3 workload over a "
                       f"{ncores}-process spawn pool, BLAS threads = 1 per process "
