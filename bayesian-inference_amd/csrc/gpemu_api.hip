@@ -55,12 +55,12 @@ int ensure_workspace(gpemu_model *m, int64_t B) {
   GP_TRY(dev_alloc(&w.Xq, need * DPAD));
   GP_TRY(dev_alloc(&w.KS, k * m->Npad * need));
   GP_TRY(dev_alloc(&w.mean_part, k * (m->Npad / JCHUNK) * need));
-  GP_TRY(dev_alloc(&w.vsq_part, k * (m->Npad / TILE) * need));
+  GP_TRY(dev_alloc(&w.vsq_part, k * m->vsq_nrb * need));
   GP_TRY(dev_alloc(&w.mean, need * k));
   GP_TRY(dev_alloc(&w.var, need * k));
   GP_TRY(dev_alloc(&w.logp, need));
   GP_HIP(hipMemsetAsync(w.KS, 0, sizeof(double) * (size_t)(k * m->Npad * need), m->stream));
-  GP_HIP(hipMemsetAsync(w.vsq_part, 0, sizeof(double) * (size_t)(k * (m->Npad / TILE) * need), m->stream));
+  GP_HIP(hipMemsetAsync(w.vsq_part, 0, sizeof(double) * (size_t)(k * m->vsq_nrb * need), m->stream));
   w.Bcap = need;
   return GPEMU_OK;
 }
@@ -122,13 +122,13 @@ namespace gpemu {
 // Log-posterior of B query rows already in the padded [rows >= round_up(B,128)][DPAD] layout
 // (the sampler writes its proposals in that layout).  accumulate != 0 adds to dout (multi-group).
 int logpost_padded(gpemu_model *m, int64_t B, const double *dXq, double *dout, int accumulate,
-                   hipStream_t st) {
+                   hipStream_t st, const AcceptArgs *aa) {
   if (!m->lik_ready) { set_error("gpemu_likelihood_setup has not been called"); return GPEMU_ERR_STATE; }
   int rc = ensure_workspace(m, B);
   if (rc == GPEMU_OK) rc = launch_kstar(m, B, dXq, st);
   if (rc == GPEMU_OK) rc = launch_trmm_vsq(m, B, st);
   if (rc != GPEMU_OK) return rc;
-  return launch_loglik_lowrank(m, B, dXq, dout, accumulate, st);
+  return launch_loglik_lowrank(m, B, dXq, dout, accumulate, st, aa);
 }
 }  // namespace gpemu
 
@@ -178,6 +178,13 @@ int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int6
   m->device = device;
   m->N = N; m->d = d; m->F = F; m->k = k;
   m->Npad = round_up(N, TILE);
+  m->trmm_variant = getenv("GPEMU_TRMM_VARIANT") ? atoi(getenv("GPEMU_TRMM_VARIANT")) : 4;
+  m->vsq_nrb = m->trmm_variant >= 2 ? m->Npad / 64 : m->Npad / TILE;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+      m->num_cu = prop.multiProcessorCount;
+  }
   m->kernel_kind = kernel_kind; m->nu = nu;
   m->has_const = has_const ? 1 : 0; m->has_noise = has_noise ? 1 : 0;
   const int64_t Np = m->Npad;
@@ -211,6 +218,7 @@ int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int6
     for (int64_t j = 0; j < N; ++j) hal[p * Np + j] = alpha[p * N + j];
   }
 #define GP_STEP(expr) if ((rc = (expr)) != GPEMU_OK) return fail(rc)
+  GP_STEP(dev_alloc(&m->work_counter, 4));
   GP_STEP(dev_alloc(&m->Xs, k * Np * DPAD));
   GP_STEP(dev_alloc(&m->ls, k * DPAD));
   GP_STEP(dev_alloc(&m->constv, k));
@@ -256,7 +264,7 @@ int gpemu_model_destroy(gpemu_model *m) {
   hipFree(m->alpha); hipFree(m->Wt); hipFree(m->comp); hipFree(m->smean); hipFree(m->sscale);
   hipFree(m->cunexpl); hipFree(m->yexp); hipFree(m->yerr); hipFree(m->lo); hipFree(m->hi);
   hipFree(m->G); hipFree(m->g0); hipFree(m->scal); hipFree(m->exact_scratch);
-  hipFree(m->blk_start); hipFree(m->blk_of);
+  hipFree(m->blk_start); hipFree(m->blk_of); hipFree(m->work_counter);
   free_workspace(m->ws);
   for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
   if (m->stream) hipStreamDestroy(m->stream);

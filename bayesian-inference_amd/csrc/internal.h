@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -55,6 +56,10 @@ struct gpemu_model {
   int device = 0;
   int64_t N = 0, d = 0, F = 0, k = 0;
   int64_t Npad = 0;            // N rounded up to TILE
+  int trmm_variant = 3;        // 1: 128x128 tiles, 2: 64x128 tiles, 3: 2 + persistent work queue
+  int num_cu = 256;
+  int *work_counter = nullptr; // [1] item counter of the persistent triangular GEMM
+  int64_t vsq_nrb = 0;         // row blocks of partial ||W k_*||^2 the triangular GEMM writes
   int kernel_kind = 0;
   double nu = 0;
   int has_const = 0, has_noise = 0;
@@ -111,10 +116,23 @@ int launch_kstar(gpemu_model *m, int64_t B, const double *dXq_padded, hipStream_
 int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st);
 int launch_reduce_mean_var(gpemu_model *m, int64_t B, double *dmean, double *dvar, hipStream_t st);
 int launch_pad_queries(gpemu_model *m, int64_t B, const double *dX, hipStream_t st);
+// optional fused stretch-move finish (accept / reject + chain record) for the walker of each proposal
+struct AcceptArgs {
+  int enabled = 0;
+  double *X = nullptr;            // [W][DPAD] ensemble positions (updated in place)
+  double *logp = nullptr;         // [W]
+  const int *idx_s = nullptr;     // [ns] walker of proposal i
+  const double *factors = nullptr;  // [ns] (d-1) log zz
+  const double *logu = nullptr;   // [ns] log of the accept uniform
+  long long *naccept = nullptr;   // [W]
+  int *flags = nullptr;           // [1] NaN counter
+  double *chain = nullptr;        // [W][d] row of this step, or null
+  double *lpchain = nullptr;      // [W]
+};
 int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq_padded, double *dout,
-                          int accumulate, hipStream_t st);
+                          int accumulate, hipStream_t st, const AcceptArgs *aa = nullptr);
 int logpost_padded(gpemu_model *m, int64_t B, const double *dXq, double *dout, int accumulate,
-                   hipStream_t st);
+                   hipStream_t st, const AcceptArgs *aa = nullptr);
 // profiling helpers: record an event on `st` and return its pool index (-1 when profiling is off)
 int prof_mark(gpemu_model *m, hipStream_t st);
 void prof_pair(gpemu_model *m, int which, int e0, int e1);

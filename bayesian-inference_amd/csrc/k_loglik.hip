@@ -77,111 +77,231 @@ int launch_lik_setup(gpemu_model *m, double *dA, double *dPT, double *dZ, int *d
 }
 
 // ---- per-walker evaluation --------------------------------------------------------------------
-// One wave per walker (lane = PC index, k <= 64), 4 walkers per workgroup.  Sums the partial means
-// and partial ||W k_*||^2 written by kstar_kernel / trmm_vsq_kernel, so no separate reduce launch.
+// One wave per walker, lane = PC index p (k <= KMAX <= 64), 4 walkers per workgroup.  Row p of the
+// k x k matrices lives in lane p's registers; columns are exchanged with wave shuffles, so the k x k
+// Cholesky and the triangular solve are throughput- rather than LDS-latency-bound.  The kernel also
+//   * sums the partial means / partial ||W k_*||^2 written by kstar_kernel / trmm_vsq_kernel,
+//   * applies the strict box prior (ref: log_posterior.py:63-64),
+//   * optionally finishes the stretch move for its walker (accept / reject, state update, chain
+//     record: emcee moves/red_blue.py), so a half-step needs no further launch.
+// sums the partials of walker b; returns (mu, sd) of PC `lane`
+__device__ __forceinline__ void walker_mean_sd(const double *__restrict__ mean_part,
+                                               const double *__restrict__ vsq_part,
+                                               const double *__restrict__ kdiag, double *mean_out,
+                                               double *var_out, int64_t b, int64_t Bcap, int k,
+                                               int nchunk, int nrb, int lane, double &mu, double &sd) {
+  mu = 0.0;
+  sd = 0.0;
+  if (lane < k) {
+    double vs = 0.0;
+    for (int c = 0; c < nchunk; ++c) mu += mean_part[((int64_t)lane * nchunk + c) * Bcap + b];
+    for (int r = 0; r < nrb; ++r) vs += vsq_part[((int64_t)lane * nrb + r) * Bcap + b];
+    double v = kdiag[lane] - vs;
+    if (v < 0.0) v = 0.0;     // skl _gpr.py:479-485
+    sd = sqrt(v);
+    if (mean_out) mean_out[b * k + lane] = mu;
+    if (var_out) var_out[b * k + lane] = sd * sd;
+  }
+}
+
+// writes the log-posterior of proposal b and, if enabled, finishes the stretch move for its walker
+__device__ __forceinline__ void finish_walker(double total, const double *__restrict__ Xq,
+                                              double *__restrict__ out, int64_t b, int d, int lane,
+                                              int accumulate, const AcceptArgs &aa) {
+  if (accumulate) total += out[b];
+  if (!aa.enabled) {
+    if (lane == 0) out[b] = total;
+    return;
+  }
+  const int w = aa.idx_s[b];
+  const double oldlp = aa.logp[w];
+  if (total != total && lane == 0) atomicAdd(aa.flags, 1);  // emcee raises on NaN
+  const bool acc = (aa.factors[b] + total - oldlp) > aa.logu[b];
+  double xold = 0.0;
+  if (lane < DPAD) xold = aa.X[(int64_t)w * DPAD + lane];
+  if (lane < DPAD && acc) aa.X[(int64_t)w * DPAD + lane] = Xq[b * DPAD + lane];
+  if (lane == 0) {
+    out[b] = total;
+    if (acc) {
+      aa.logp[w] = total;
+      aa.naccept[w] += 1;
+    }
+  }
+  if (aa.chain) {
+    if (lane < d) aa.chain[(int64_t)w * d + lane] = acc ? Xq[b * DPAD + lane] : xold;
+    if (lane == 0) aa.lpchain[w] = acc ? total : oldlp;
+  }
+}
+
+template <int KMAX>
 __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
     const double *__restrict__ Xq, const double *__restrict__ lo, const double *__restrict__ hi,
     const double *__restrict__ mean_part, const double *__restrict__ vsq_part,
     const double *__restrict__ kdiag, const double *__restrict__ G, const double *__restrict__ g0,
     const double *__restrict__ scal, double *__restrict__ out, double *__restrict__ mean_out,
     double *__restrict__ var_out, int64_t B, int64_t Bcap, int d, int k, int nchunk, int nrb,
-    int nblk, int accumulate) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+    int nblk, int accumulate, AcceptArgs aa) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * 4 + wave;
   if (b >= B) return;  // whole wave exits together; no workgroup barriers below
-  double *M = smem + (size_t)wave * k * (k + 1);
-  const int ldm = k + 1;
 
-  // strict box prior (ref: log_posterior.py:63-64)
   bool in = true;
   if (lane < d) in = (Xq[b * DPAD + lane] > lo[lane]) && (Xq[b * DPAD + lane] < hi[lane]);
   const bool inside = __all(in);
 
-  double mu = 0.0, sd = 0.0;
-  if (lane < k) {
-    double vs = 0.0;
-    for (int c = 0; c < nchunk; ++c) mu += mean_part[((int64_t)lane * nchunk + c) * Bcap + b];
-    for (int r = 0; r < nrb; ++r) vs += vsq_part[((int64_t)lane * nrb + r) * Bcap + b];
-    double v = kdiag[lane] - vs;
-    if (v < 0.0) v = 0.0;
-    sd = sqrt(v);
-    if (mean_out) mean_out[b * k + lane] = mu;
-    if (var_out) var_out[b * k + lane] = sd * sd;
-  }
-  if (!inside) {
-    if (lane == 0) out[b] = -INFINITY;
-    return;
-  }
-  double total = 0.0;
-  for (int o = 0; o < nblk; ++o) {
-    const double *Go = G + (int64_t)o * k * k;
-    // h = G_o m + g0_o ; quadA = m.(h + g0_o) + q0_o
-    double h = 0.0, gl = (lane < k) ? g0[(int64_t)o * k + lane] : 0.0;
-    for (int q = 0; q < k; ++q) {
-      double mq = __shfl(mu, q);
-      if (lane < k) h = fma(Go[lane * k + q], mq, h);
-    }
-    h += gl;
-    double t = (lane < k) ? mu * (h + gl) : 0.0;
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-    const double quadA = t + scal[2 * o];
-    // M = I + D^1/2 G_o D^1/2 (row `lane`)
-    for (int q = 0; q < k; ++q) {
-      double sq = __shfl(sd, q);
-      if (lane < k) M[lane * ldm + q] = ((lane == q) ? 1.0 : 0.0) + sd * Go[lane * k + q] * sq;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // in-wave Cholesky of M (k x k, lane = row), right-looking
-    double logdiag = 0.0;
-    for (int j = 0; j < k; ++j) {
-      double piv = sqrt(M[j * ldm + j]);
-      __builtin_amdgcn_wave_barrier();
-      if (lane == j) {
-        M[j * ldm + j] = piv;
-        logdiag = log(piv);
+  double mu, sd;
+  walker_mean_sd(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
+  double total = -INFINITY;
+  if (inside) {
+    total = 0.0;
+    for (int o = 0; o < nblk; ++o) {
+      const double *Go = G + (int64_t)o * k * k;
+      // row `lane` of G_o (symmetric: read column-wise so that the wave's loads coalesce)
+      double row[KMAX];
+      double h = 0.0;
+#pragma unroll
+      for (int q = 0; q < KMAX; ++q) {
+        double gq = (q < k && lane < k) ? Go[q * k + lane] : 0.0;
+        h = fma(gq, __shfl(mu, q), h);
+        row[q] = ((lane == q) ? 1.0 : 0.0) + sd * gq * __shfl(sd, q);   // M = I + D^1/2 G D^1/2
       }
-      if (lane > j && lane < k) M[lane * ldm + j] = M[lane * ldm + j] / piv;
+      const double gl = (lane < k) ? g0[(int64_t)o * k + lane] : 0.0;
+      h += gl;
+      double t = (lane < k) ? mu * (h + gl) : 0.0;
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+      const double quadA = t + scal[2 * o];
+      // right-looking Cholesky, lane = row; y = L_M^-1 (sd o h) by forward substitution alongside
+      double y = (lane < k) ? sd * h : 0.0;
+      double logdiag = 0.0;
+#pragma unroll
+      for (int jx = 0; jx < KMAX; ++jx) {
+        if (jx < k) {
+          const double piv = sqrt(__shfl(row[jx], jx));
+          const double lj = (lane == jx) ? piv : row[jx] / piv;      // column jx of L (lanes >= jx)
+          if (lane == jx) logdiag = log(piv);
+          const double zj = __shfl(y, jx) / piv;
+          if (lane == jx) y = zj;
+          if (lane > jx) y = fma(-lj, zj, y);
+#pragma unroll
+          for (int c = jx + 1; c < KMAX; ++c) {
+            if (c < k) {
+              const double lc = __shfl(lj, c);
+              if (lane >= c) row[c] = fma(-lj, lc, row[c]);
+            }
+          }
+        }
+      }
+      double ww = (lane < k) ? y * y : 0.0;
+      double ldsum = logdiag;
+      for (int off = 32; off > 0; off >>= 1) {
+        ww += __shfl_xor(ww, off);
+        ldsum += __shfl_xor(ldsum, off);
+      }
+      total += -0.5 * (quadA - ww) - 0.5 * (scal[2 * o + 1] + 2.0 * ldsum);
+    }
+  }
+  finish_walker(total, Xq, out, b, d, lane, accumulate, aa);
+}
+
+// General k (17..64): the k x k matrix of each walker lives in LDS (one wave per walker, lane = row).
+__global__ __launch_bounds__(256) void loglik_lowrank_lds_kernel(
+    const double *__restrict__ Xq, const double *__restrict__ lo, const double *__restrict__ hi,
+    const double *__restrict__ mean_part, const double *__restrict__ vsq_part,
+    const double *__restrict__ kdiag, const double *__restrict__ G, const double *__restrict__ g0,
+    const double *__restrict__ scal, double *__restrict__ out, double *__restrict__ mean_out,
+    double *__restrict__ var_out, int64_t B, int64_t Bcap, int d, int k, int nchunk, int nrb,
+    int nblk, int accumulate, AcceptArgs aa) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  double *M = smem + (size_t)wave * k * (k + 1);
+  const int ldm = k + 1;
+  bool in = true;
+  if (lane < d) in = (Xq[b * DPAD + lane] > lo[lane]) && (Xq[b * DPAD + lane] < hi[lane]);
+  const bool inside = __all(in);
+  double mu, sd;
+  walker_mean_sd(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
+  double total = -INFINITY;
+  if (inside) {
+    total = 0.0;
+    for (int o = 0; o < nblk; ++o) {
+      const double *Go = G + (int64_t)o * k * k;
+      double h = 0.0, gl = (lane < k) ? g0[(int64_t)o * k + lane] : 0.0;
+      for (int q = 0; q < k; ++q) {
+        double gq = (lane < k) ? Go[q * k + lane] : 0.0;
+        h = fma(gq, __shfl(mu, q), h);
+        double sq = __shfl(sd, q);
+        if (lane < k) M[lane * ldm + q] = ((lane == q) ? 1.0 : 0.0) + sd * gq * sq;
+      }
+      h += gl;
+      double t = (lane < k) ? mu * (h + gl) : 0.0;
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+      const double quadA = t + scal[2 * o];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (lane > j && lane < k) {
-        double lij = M[lane * ldm + j];
-        for (int c = j + 1; c <= lane; ++c) M[lane * ldm + c] -= lij * M[c * ldm + j];
+      double logdiag = 0.0;
+      for (int j = 0; j < k; ++j) {
+        double piv = sqrt(M[j * ldm + j]);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == j) {
+          M[j * ldm + j] = piv;
+          logdiag = log(piv);
+        }
+        if (lane > j && lane < k) M[lane * ldm + j] = M[lane * ldm + j] / piv;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane > j && lane < k) {
+          double lij = M[lane * ldm + j];
+          for (int c = j + 1; c <= lane; ++c) M[lane * ldm + c] -= lij * M[c * ldm + j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
+      double y = (lane < k) ? sd * h : 0.0;
+      for (int j = 0; j < k; ++j) {
+        double zj = __shfl(y, j) / M[j * ldm + j];
+        if (lane == j) y = zj;
+        if (lane > j && lane < k) y = fma(-M[lane * ldm + j], zj, y);
+      }
+      double ww = (lane < k) ? y * y : 0.0;
+      double ldsum = logdiag;
+      for (int off = 32; off > 0; off >>= 1) {
+        ww += __shfl_xor(ww, off);
+        ldsum += __shfl_xor(ldsum, off);
+      }
+      total += -0.5 * (quadA - ww) - 0.5 * (scal[2 * o + 1] + 2.0 * ldsum);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    // w = L_M^-1 (sd o h)
-    double y = (lane < k) ? sd * h : 0.0;
-    for (int j = 0; j < k; ++j) {
-      double zj = __shfl(y, j) / M[j * ldm + j];
-      if (lane == j) y = zj;
-      if (lane > j && lane < k) y = fma(-M[lane * ldm + j], zj, y);
-    }
-    double ww = (lane < k) ? y * y : 0.0;
-    double ldsum = logdiag;
-    for (int off = 32; off > 0; off >>= 1) {
-      ww += __shfl_xor(ww, off);
-      ldsum += __shfl_xor(ldsum, off);
-    }
-    total += -0.5 * (quadA - ww) - 0.5 * (scal[2 * o + 1] + 2.0 * ldsum);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
-  if (lane == 0) out[b] = accumulate ? out[b] + total : total;
+  finish_walker(total, Xq, out, b, d, lane, accumulate, aa);
 }
 
 int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq, double *dout, int accumulate,
-                          hipStream_t st) {
+                          hipStream_t st, const AcceptArgs *aa) {
   const Workspace &w = m->ws;
   const int k = (int)m->k;
-  size_t shm = sizeof(double) * 4 * (size_t)k * (k + 1);
-  hipLaunchKernelGGL(loglik_lowrank_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), shm, st, dXq,
-                     m->lo, m->hi, w.mean_part, w.vsq_part, m->kdiag, m->G, m->g0, m->scal, dout,
-                     w.mean, w.var, B, w.Bcap, (int)m->d, k, (int)(m->Npad / JCHUNK),
-                     (int)(m->Npad / TILE), (int)m->nblk, accumulate);
+  AcceptArgs a = aa ? *aa : AcceptArgs();
+  const dim3 grid((unsigned)((B + 3) / 4)), block(256);
+#define GP_LAUNCH_LL(KM)                                                                            \
+  hipLaunchKernelGGL(loglik_lowrank_kernel<KM>, grid, block, 0, st, dXq, m->lo, m->hi, w.mean_part,  \
+                     w.vsq_part, m->kdiag, m->G, m->g0, m->scal, dout, w.mean, w.var, B, w.Bcap,     \
+                     (int)m->d, k, (int)(m->Npad / JCHUNK), (int)m->vsq_nrb, (int)m->nblk, accumulate, a)
+  if (k <= 16) {
+    GP_LAUNCH_LL(16);
+  } else {
+    size_t shm = sizeof(double) * 4 * (size_t)k * (k + 1);
+    if (shm > 64 * 1024)
+      GP_HIP(hipFuncSetAttribute((const void *)loglik_lowrank_lds_kernel,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(loglik_lowrank_lds_kernel, grid, block, shm, st, dXq, m->lo, m->hi, w.mean_part,
+                       w.vsq_part, m->kdiag, m->G, m->g0, m->scal, dout, w.mean, w.var, B, w.Bcap,
+                       (int)m->d, k, (int)(m->Npad / JCHUNK), (int)m->vsq_nrb, (int)m->nblk, accumulate, a);
+  }
+#undef GP_LAUNCH_LL
   GP_HIP(hipGetLastError());
   return GPEMU_OK;
 }

@@ -53,11 +53,13 @@ struct gpemu_sampler {
   hipStream_t stream = nullptr;
   double *X = nullptr;         // [W][DPAD]
   double *logp = nullptr;      // [W]
-  int *inds = nullptr;         // [W] split of each walker
-  int *idx = nullptr;          // [2][W] members of each set, ascending walker index
-  double *zz = nullptr;        // [2][W]
-  double *logu = nullptr;      // [2][W]
-  int *rint = nullptr;         // [2][W]
+  // per-step randomness, ring of RNG_RING steps (slot = step_counter % RNG_RING)
+  int *inds = nullptr;         // [RING][W] split of each walker
+  int *idx = nullptr;          // [RING][2][W] members of each set, ascending walker index
+  double *zz = nullptr;        // [RING][2][W]
+  double *logu = nullptr;      // [RING][2][W]
+  int *rint = nullptr;         // [RING][2][W]
+  uint64_t rng_ready_until = 0; // steps [.., rng_ready_until) of the device stream are in the ring
   double *q = nullptr;         // [qcap][DPAD]
   double *factors = nullptr;   // [W]
   double *newlp = nullptr;     // [qcap]
@@ -71,50 +73,60 @@ struct gpemu_sampler {
 namespace gpemu {
 
 // ---- kernels ------------------------------------------------------------------------------------
-// One workgroup: random balanced split (sort W random keys), set member lists, and the step's
-// zz / rint / log u draws for both halves.
-__global__ __launch_bounds__(1024) void rng_step_kernel(int *inds, int *idx, double *zz, double *logu,
-                                                        int *rint, int W, int n0, int n1, double a,
-                                                        uint32_t k0, uint32_t k1, uint32_t step_lo,
-                                                        uint32_t step_hi) {
-  extern __shared__ unsigned long long keys[];  // P = next pow2 >= W entries, then W ints for the scan
+// One workgroup per step (grid = steps generated ahead): random balanced split (rank of W random
+// keys by counting), set member lists (ballot prefix sums), and the step's zz / rint / log u draws
+// for both halves.  Step s writes slot s % RNG_RING of the ring buffers.
+constexpr int RNG_RING = 16;
+
+__global__ __launch_bounds__(1024) void rng_step_kernel(int *inds_r, int *idx_r, double *zz_r,
+                                                        double *logu_r, int *rint_r, int W, int n0,
+                                                        int n1, double a, uint32_t k0, uint32_t k1,
+                                                        unsigned long long step0) {
+  extern __shared__ unsigned long long keys[];  // [W]
+  __shared__ int wcnt[2][16];
   const int tid = threadIdx.x, nthr = blockDim.x;
-  int P = 1;
-  while (P < W) P <<= 1;
-  for (int w = tid; w < P; w += nthr) {
+  const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+  const unsigned long long step = step0 + blockIdx.x;
+  const uint32_t step_lo = (uint32_t)step, step_hi = (uint32_t)(step >> 32);
+  const int slot = (int)(step % RNG_RING);
+  int *inds = inds_r + (size_t)slot * W;
+  int *idx = idx_r + (size_t)slot * 2 * W;
+  double *zz = zz_r + (size_t)slot * 2 * W;
+  double *logu = logu_r + (size_t)slot * 2 * W;
+  int *rint = rint_r + (size_t)slot * 2 * W;
+
+  for (int w = tid; w < W; w += nthr) {
+    u32x4 r = philox4x32_10(u32x4{(uint32_t)w, 0u, step_lo, step_hi}, k0, k1);
+    keys[w] = ((unsigned long long)r.x << 32) | (unsigned)w;
+  }
+  __syncthreads();
+  // split[w] = rank(w) & 1  == (arange(W) % 2) after a uniform shuffle; lists in ascending w
+  int base0 = 0, base1 = 0;
+  for (int c0 = 0; c0 < W; c0 += nthr) {
+    const int w = c0 + tid;
+    int sp = -1;
     if (w < W) {
-      u32x4 r = philox4x32_10(u32x4{(uint32_t)w, 0u, step_lo, step_hi}, k0, k1);
-      keys[w] = ((unsigned long long)r.x << 32) | (unsigned)w;
-    } else {
-      keys[w] = ~0ull;
+      const unsigned long long kw = keys[w];
+      int rank = 0;
+#pragma unroll 8
+      for (int jx = 0; jx < W; ++jx) rank += (keys[jx] < kw) ? 1 : 0;
+      sp = rank & 1;
+      inds[w] = sp;
     }
-  }
-  __syncthreads();
-  for (int size = 2; size <= P; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < P / 2; t += nthr) {
-        int lo = (t / stride) * 2 * stride + (t % stride);
-        int hi = lo + stride;
-        bool up = ((lo & size) == 0);
-        unsigned long long x = keys[lo], y = keys[hi];
-        if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
-      }
-      __syncthreads();
+    const unsigned long long b0 = __ballot(sp == 0), b1 = __ballot(sp == 1);
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (lane == 0) { wcnt[0][wave] = __popcll(b0); wcnt[1][wave] = __popcll(b1); }
+    __syncthreads();
+    int off0 = base0, off1 = base1, tot0 = 0, tot1 = 0;
+    for (int v = 0; v < nwave; ++v) {
+      if (v < wave) { off0 += wcnt[0][v]; off1 += wcnt[1][v]; }
+      tot0 += wcnt[0][v]; tot1 += wcnt[1][v];
     }
+    if (sp == 0) idx[off0 + __popcll(b0 & lt)] = w;
+    if (sp == 1) idx[W + off1 + __popcll(b1 & lt)] = w;
+    base0 += tot0; base1 += tot1;
+    __syncthreads();
   }
-  int *split = reinterpret_cast<int *>(keys + P);  // [W]
-  for (int pos = tid; pos < W; pos += nthr) {
-    int w = (int)(keys[pos] & 0xffffffffu);
-    split[w] = pos & 1;   // == (arange(W) % 2) after a uniform shuffle
-  }
-  __syncthreads();
-  // member lists in ascending walker order (serial scan by one thread per set; W is small)
-  if (tid < 2) {
-    int c = 0;
-    for (int w = 0; w < W; ++w)
-      if (split[w] == tid) idx[tid * W + c++] = w;
-  }
-  for (int w = tid; w < W; w += nthr) inds[w] = split[w];
   for (int h = 0; h < 2; ++h) {
     const int ns = h == 0 ? n0 : n1, nc = W - ns;
     for (int i = tid; i < ns; i += nthr) {
@@ -194,9 +206,11 @@ __global__ void unpad_rows_kernel(const double *__restrict__ src, double *__rest
 }
 
 // ---- host helpers ---------------------------------------------------------------------------------
-static int eval_logpost(gpemu_sampler *s, const double *dq, int64_t B, double *dout, hipStream_t st) {
-  for (size_t g = 0; g < s->groups.size(); ++g) {
-    int rc = logpost_padded(s->groups[g], B, dq, dout, g > 0 ? 1 : 0, st);
+static int eval_logpost(gpemu_sampler *s, const double *dq, int64_t B, double *dout, hipStream_t st,
+                        const AcceptArgs *aa = nullptr) {
+  const size_t ng = s->groups.size();
+  for (size_t g = 0; g < ng; ++g) {
+    int rc = logpost_padded(s->groups[g], B, dq, dout, g > 0 ? 1 : 0, st, g + 1 == ng ? aa : nullptr);
     if (rc != GPEMU_OK) return rc;
   }
   return GPEMU_OK;
@@ -222,38 +236,66 @@ static int ensure_chain(gpemu_sampler *s, int64_t need) {
   return GPEMU_OK;
 }
 
-static int launch_rng(gpemu_sampler *s, hipStream_t st) {
-  int P = 1;
-  while (P < s->W) P <<= 1;
-  size_t shm = sizeof(unsigned long long) * P + sizeof(int) * s->W;
-  hipLaunchKernelGGL(rng_step_kernel, dim3(1), dim3(1024), shm, st, s->inds, s->idx, s->zz, s->logu,
-                     s->rint, (int)s->W, (int)s->ns[0], (int)s->ns[1], s->a, (uint32_t)s->seed,
-                     (uint32_t)(s->seed >> 32), (uint32_t)s->step_counter,
-                     (uint32_t)(s->step_counter >> 32));
+// make sure the randomness of step s->step_counter is in the ring; generates up to `ahead` steps
+// (bounded by the ring) in one launch.  Stream order keeps earlier steps' reads before the refill.
+static int launch_rng(gpemu_sampler *s, hipStream_t st, int64_t ahead = 1) {
+  if (s->step_counter < s->rng_ready_until) return GPEMU_OK;
+  int64_t n = ahead < 1 ? 1 : (ahead > RNG_RING ? RNG_RING : ahead);
+  size_t shm = sizeof(unsigned long long) * s->W;
+  hipLaunchKernelGGL(rng_step_kernel, dim3((unsigned)n), dim3(1024), shm, st, s->inds, s->idx, s->zz,
+                     s->logu, s->rint, (int)s->W, (int)s->ns[0], (int)s->ns[1], s->a, (uint32_t)s->seed,
+                     (uint32_t)(s->seed >> 32), (unsigned long long)s->step_counter);
   GP_HIP(hipGetLastError());
+  s->rng_ready_until = s->step_counter + (uint64_t)n;
   return GPEMU_OK;
 }
 
+static inline size_t rslot(const gpemu_sampler *s) { return (size_t)(s->step_counter % RNG_RING); }
+
 static int launch_propose(gpemu_sampler *s, int h, hipStream_t st) {
   const int ns = (int)s->ns[h];
-  hipLaunchKernelGGL(propose_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, s->X, s->idx + h * s->W,
-                     s->idx + (1 - h) * s->W, s->zz + h * s->W, s->rint + h * s->W, s->q, s->factors, ns,
-                     (int)s->d);
+  const size_t o2 = rslot(s) * 2 * s->W;
+  hipLaunchKernelGGL(propose_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, s->X,
+                     s->idx + o2 + h * s->W, s->idx + o2 + (1 - h) * s->W, s->zz + o2 + h * s->W,
+                     s->rint + o2 + h * s->W, s->q, s->factors, ns, (int)s->d);
   GP_HIP(hipGetLastError());
   return GPEMU_OK;
 }
 
 static int launch_accept(gpemu_sampler *s, int h, const double *dnewlp, hipStream_t st) {
   const int ns = (int)s->ns[h];
+  const size_t o2 = rslot(s) * 2 * s->W;
   hipLaunchKernelGGL(accept_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, s->X, s->logp,
-                     s->idx + h * s->W, s->q, s->factors, dnewlp, s->logu + h * s->W, s->naccept,
-                     s->flags, ns);
+                     s->idx + o2 + h * s->W, s->q, s->factors, dnewlp, s->logu + o2 + h * s->W,
+                     s->naccept, s->flags, ns);
   GP_HIP(hipGetLastError());
   return GPEMU_OK;
 }
 
-static int end_step(gpemu_sampler *s, int store_chain, hipStream_t st) {
+// propose + log-posterior + (fused) accept / record of one half on this device
+static int half_step_fused(gpemu_sampler *s, int h, int store_chain, hipStream_t st) {
+  int rc = launch_propose(s, h, st);
+  if (rc != GPEMU_OK) return rc;
+  const size_t o2 = rslot(s) * 2 * s->W;
+  AcceptArgs aa;
+  aa.enabled = 1;
+  aa.X = s->X; aa.logp = s->logp;
+  aa.idx_s = s->idx + o2 + h * s->W;
+  aa.factors = s->factors;
+  aa.logu = s->logu + o2 + h * s->W;
+  aa.naccept = s->naccept; aa.flags = s->flags;
   if (store_chain) {
+    aa.chain = s->chain + s->chain_len * s->W * s->d;
+    aa.lpchain = s->lpchain + s->chain_len * s->W;
+  }
+  return eval_logpost(s, s->q, s->ns[h], s->newlp, st, &aa);
+}
+
+// bookkeeping after both halves; `recorded` = the chain row was already written by the fused kernels
+static int end_step(gpemu_sampler *s, int store_chain, hipStream_t st, bool recorded = false) {
+  if (store_chain && recorded) {
+    s->chain_len += 1;
+  } else if (store_chain) {
     int rc = ensure_chain(s, s->chain_len + 1);
     if (rc != GPEMU_OK) return rc;
     const int n = (int)(s->W * s->d);
@@ -312,11 +354,11 @@ int gpemu_sampler_create(gpemu_sampler **out, gpemu_model *const *groups, int n_
   auto A = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 8); };
   A((void **)&s->X, sizeof(double) * W * DPAD);
   A((void **)&s->logp, sizeof(double) * W);
-  A((void **)&s->inds, sizeof(int) * W);
-  A((void **)&s->idx, sizeof(int) * 2 * W);
-  A((void **)&s->zz, sizeof(double) * 2 * W);
-  A((void **)&s->logu, sizeof(double) * 2 * W);
-  A((void **)&s->rint, sizeof(int) * 2 * W);
+  A((void **)&s->inds, sizeof(int) * W * RNG_RING);
+  A((void **)&s->idx, sizeof(int) * 2 * W * RNG_RING);
+  A((void **)&s->zz, sizeof(double) * 2 * W * RNG_RING);
+  A((void **)&s->logu, sizeof(double) * 2 * W * RNG_RING);
+  A((void **)&s->rint, sizeof(int) * 2 * W * RNG_RING);
   A((void **)&s->q, sizeof(double) * s->qcap * DPAD);
   A((void **)&s->factors, sizeof(double) * W);
   A((void **)&s->newlp, sizeof(double) * s->qcap);
@@ -434,14 +476,9 @@ int gpemu_sampler_run(gpemu_sampler *s, int64_t steps, int store_chain) {
   hipStream_t st = s->stream;
   if (store_chain) GP_TRY(ensure_chain(s, s->chain_len + steps));
   for (int64_t it = 0; it < steps; ++it) {
-    GP_TRY(launch_rng(s, st));
-    for (int h = 0; h < 2; ++h) {
-      if (s->ns[h] == 0) continue;
-      GP_TRY(launch_propose(s, h, st));
-      GP_TRY(eval_logpost(s, s->q, s->ns[h], s->newlp, st));
-      GP_TRY(launch_accept(s, h, s->newlp, st));
-    }
-    GP_TRY(end_step(s, store_chain, st));
+    GP_TRY(launch_rng(s, st, steps - it));
+    for (int h = 0; h < 2; ++h) GP_TRY(half_step_fused(s, h, store_chain, st));
+    GP_TRY(end_step(s, store_chain, st, true));
   }
   return check_nan(s);
 }
@@ -469,18 +506,16 @@ int gpemu_sampler_step_host_rng(gpemu_sampler *s, const int32_t *inds, const dou
       hu[h * W + i] = logu[off + i];
     }
   }
-  GP_HIP(hipMemcpyAsync(s->inds, inds, sizeof(int) * W, hipMemcpyHostToDevice, st));
-  GP_HIP(hipMemcpyAsync(s->rint, hr.data(), sizeof(int) * 2 * W, hipMemcpyHostToDevice, st));
-  GP_HIP(hipMemcpyAsync(s->zz, hz.data(), sizeof(double) * 2 * W, hipMemcpyHostToDevice, st));
-  GP_HIP(hipMemcpyAsync(s->logu, hu.data(), sizeof(double) * 2 * W, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(build_sets_kernel, dim3(1), dim3(64), 0, st, s->inds, s->idx, (int)W);
-  for (int h = 0; h < 2; ++h) {
-    if (s->ns[h] == 0) continue;
-    GP_TRY(launch_propose(s, h, st));
-    GP_TRY(eval_logpost(s, s->q, s->ns[h], s->newlp, st));
-    GP_TRY(launch_accept(s, h, s->newlp, st));
-  }
-  GP_TRY(end_step(s, store_chain, st));
+  const size_t sl = rslot(s);
+  s->rng_ready_until = 0;  // host-supplied draws replace whatever the device generated ahead
+  GP_HIP(hipMemcpyAsync(s->inds + sl * W, inds, sizeof(int) * W, hipMemcpyHostToDevice, st));
+  GP_HIP(hipMemcpyAsync(s->rint + sl * 2 * W, hr.data(), sizeof(int) * 2 * W, hipMemcpyHostToDevice, st));
+  GP_HIP(hipMemcpyAsync(s->zz + sl * 2 * W, hz.data(), sizeof(double) * 2 * W, hipMemcpyHostToDevice, st));
+  GP_HIP(hipMemcpyAsync(s->logu + sl * 2 * W, hu.data(), sizeof(double) * 2 * W, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(build_sets_kernel, dim3(1), dim3(64), 0, st, s->inds + sl * W, s->idx + sl * 2 * W, (int)W);
+  GP_TRY(ensure_chain(s, s->chain_len + 1));
+  for (int h = 0; h < 2; ++h) GP_TRY(half_step_fused(s, h, store_chain, st));
+  GP_TRY(end_step(s, store_chain, st, true));
   return check_nan(s);  // also synchronises, so the host staging vectors may go out of scope
 }
 
@@ -516,7 +551,7 @@ int gpemu_sampler_get_counts(gpemu_sampler *s, int64_t *naccepted, int64_t *iter
 int gpemu_sampler_begin_step(gpemu_sampler *s) {
   GP_ARG(s, "sampler");
   GP_HIP(hipSetDevice(s->device));
-  return launch_rng(s, s->stream);
+  return launch_rng(s, s->stream, RNG_RING);
 }
 
 int gpemu_sampler_half_propose_eval(gpemu_sampler *s, int half, int64_t lo, int64_t hi,

@@ -143,6 +143,24 @@ def test_multigroup_observable_blocks_vs_reference_merge(mode):
         np.testing.assert_allclose(total, g[key], rtol=TOL)
 
 
+@pytest.mark.parametrize("k", [17, 40])
+def test_many_pcs_lds_likelihood_path(k):
+    """k > 16 principal components take the LDS-resident k x k path of the likelihood kernel."""
+    model, prob, _ = GU.fixed_theta_model(120, 60, k, seed=2)
+    dm = GU.device_model(model)
+    from gpemu import synthetic
+    X = synthetic.make_walkers(24, seed=4)
+    dm.likelihood_setup(prob["y_exp"], prob["y_err"], prob["lo"], prob["hi"], 1.0)
+    ref = np.array([O.log_posterior(x, {"g": model}, prob["lo"], prob["hi"], prob["y_exp"], prob["y_err"])[0]
+                    for x in X])
+    np.testing.assert_allclose(dm.logpost(X, mode=0), ref, rtol=TOL)
+    np.testing.assert_allclose(dm.logpost(X, mode=1), ref, rtol=TOL)
+    m, v = dm.gp_predict(X)
+    mo, vo = O.gp_predict_all(X, model)
+    assert relerr(m, mo) < TOL and np.max(np.abs(v - vo)) < TOL
+    dm.close()
+
+
 def test_argument_errors():
     from gpemu._lib import GpemuError
     g, model = _load("g1_rbf_noise")
