@@ -178,8 +178,7 @@ int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int6
   m->device = device;
   m->N = N; m->d = d; m->F = F; m->k = k;
   m->Npad = round_up(N, TILE);
-  m->trmm_variant = getenv("GPEMU_TRMM_VARIANT") ? atoi(getenv("GPEMU_TRMM_VARIANT")) : 4;
-  m->vsq_nrb = m->trmm_variant >= 2 ? m->Npad / 64 : m->Npad / TILE;
+  m->vsq_nrb = m->Npad / 64;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -218,7 +217,6 @@ int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int6
     for (int64_t j = 0; j < N; ++j) hal[p * Np + j] = alpha[p * N + j];
   }
 #define GP_STEP(expr) if ((rc = (expr)) != GPEMU_OK) return fail(rc)
-  GP_STEP(dev_alloc(&m->work_counter, 4));
   GP_STEP(dev_alloc(&m->Xs, k * Np * DPAD));
   GP_STEP(dev_alloc(&m->ls, k * DPAD));
   GP_STEP(dev_alloc(&m->constv, k));
@@ -264,7 +262,7 @@ int gpemu_model_destroy(gpemu_model *m) {
   hipFree(m->alpha); hipFree(m->Wt); hipFree(m->comp); hipFree(m->smean); hipFree(m->sscale);
   hipFree(m->cunexpl); hipFree(m->yexp); hipFree(m->yerr); hipFree(m->lo); hipFree(m->hi);
   hipFree(m->G); hipFree(m->g0); hipFree(m->scal); hipFree(m->exact_scratch);
-  hipFree(m->blk_start); hipFree(m->blk_of); hipFree(m->work_counter);
+  hipFree(m->blk_start); hipFree(m->blk_of); hipFree(m->sched_items); hipFree(m->sched_cnt);
   free_workspace(m->ws);
   for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
   if (m->stream) hipStreamDestroy(m->stream);

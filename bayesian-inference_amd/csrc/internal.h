@@ -43,8 +43,8 @@ struct Workspace {
   int64_t Bcap = 0;            // padded batch capacity (multiple of TILE)
   double *Xq = nullptr;        // [Bcap][DPAD]   query points (padded with 0)
   double *KS = nullptr;        // [k][Npad][Bcap] cross-kernel K_*^T per PC
-  double *mean_part = nullptr; // [k][nchunk][Bcap] partial K_* . alpha
-  double *vsq_part = nullptr;  // [k][nrb][Bcap]    partial ||W k_*||^2 per row block
+  double *mean_part = nullptr; // [Bcap][k][nchunk] partial K_* . alpha per 128-row chunk
+  double *vsq_part = nullptr;  // [Bcap][k][nrb]    partial ||W k_*||^2 per 64-row block
   double *mean = nullptr;      // [Bcap][k]
   double *var = nullptr;       // [Bcap][k]
   double *logp = nullptr;      // [Bcap]
@@ -56,9 +56,11 @@ struct gpemu_model {
   int device = 0;
   int64_t N = 0, d = 0, F = 0, k = 0;
   int64_t Npad = 0;            // N rounded up to TILE
-  int trmm_variant = 3;        // 1: 128x128 tiles, 2: 64x128 tiles, 3: 2 + persistent work queue
   int num_cu = 256;
-  int *work_counter = nullptr; // [1] item counter of the persistent triangular GEMM
+  // LPT schedule of the persistent triangular GEMM for the current number of column tiles
+  void *sched_items = nullptr; // TrmmItem[sched_workers][sched_max_items]
+  int *sched_cnt = nullptr;    // [sched_workers]
+  int sched_ncb = -1, sched_max_items = 0, sched_workers = 0;
   int64_t vsq_nrb = 0;         // row blocks of partial ||W k_*||^2 the triangular GEMM writes
   int kernel_kind = 0;
   double nu = 0;

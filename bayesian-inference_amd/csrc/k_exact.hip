@@ -128,8 +128,8 @@ __global__ __launch_bounds__(CHOL_THREADS) void loglik_exact_kernel(
     }
     if (tid < k) {
       double mu = 0.0, vs = 0.0;
-      for (int c = 0; c < nchunk; ++c) mu += mean_part[((int64_t)tid * nchunk + c) * Bcap + b];
-      for (int r = 0; r < nrb; ++r) vs += vsq_part[((int64_t)tid * nrb + r) * Bcap + b];
+      for (int c = 0; c < nchunk; ++c) mu += mean_part[(b * k + tid) * nchunk + c];
+      for (int r = 0; r < nrb; ++r) vs += vsq_part[(b * k + tid) * nrb + r];
       double v = kdiag[tid] - vs;
       if (v < 0.0) v = 0.0;
       double sd = sqrt(v);

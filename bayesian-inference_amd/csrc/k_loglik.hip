@@ -94,8 +94,11 @@ __device__ __forceinline__ void walker_mean_sd(const double *__restrict__ mean_p
   sd = 0.0;
   if (lane < k) {
     double vs = 0.0;
-    for (int c = 0; c < nchunk; ++c) mu += mean_part[((int64_t)lane * nchunk + c) * Bcap + b];
-    for (int r = 0; r < nrb; ++r) vs += vsq_part[((int64_t)lane * nrb + r) * Bcap + b];
+    // parts of one (walker, PC) are contiguous: the loop walks one or two cache lines
+    const double *mp = mean_part + (b * k + lane) * nchunk;
+    const double *vp = vsq_part + (b * k + lane) * nrb;
+    for (int c = 0; c < nchunk; ++c) mu += mp[c];
+    for (int r = 0; r < nrb; ++r) vs += vp[r];
     double v = kdiag[lane] - vs;
     if (v < 0.0) v = 0.0;     // skl _gpr.py:479-485
     sd = sqrt(v);

@@ -8,8 +8,10 @@
 // the epilogue -- V is never written to memory.
 //
 //   kstar_kernel      K_*^T[p][j][b] (HBM/L2 workspace) + partial means   (VALU f64, HBM-write)
-//   trmm_vsq_kernel   sum_i (W_p K_*^T)[i][b]^2 per 128-row block          (MFMA f64)
+//   trmm_vsq_kernel   sum_i (W_p K_*^T)[i][b]^2 per 64-row block           (MFMA f64)
 //   reduce_kernel     sums the partials, var = kdiag - vsq, clip, std^2
+#include <algorithm>
+
 #include "internal.h"
 
 namespace gpemu {
@@ -55,9 +57,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void kstar_kernel(
     const double *__restrict__ Xq, const double *__restrict__ Xs, const double *__restrict__ ls,
     const double *__restrict__ constv, const double *__restrict__ alpha, double *__restrict__ KS,
-    double *__restrict__ mean_part, int64_t N, int64_t Npad, int64_t Bcap, int has_const,
-    int *__restrict__ work_counter) {
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *work_counter = 0;
+    double *__restrict__ mean_part, int64_t N, int64_t Npad, int64_t Bcap, int has_const) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = blockIdx.z;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void kstar_kernel(
   __syncthreads();
   if (wave == 0) {
     double s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    mean_part[((int64_t)p * nchunk + chunk) * Bcap + b] = s;
+    mean_part[(b * gridDim.z + p) * nchunk + chunk] = s;
   }
 }
 
@@ -107,7 +107,7 @@ int launch_kstar(gpemu_model *m, int64_t B, const double *dXq, hipStream_t st) {
   if (m->kernel_kind == GPEMU_KERNEL_MATERN) kind = (m->nu == 0.5) ? 1 : (m->nu == 1.5 ? 2 : 3);
 #define GP_LAUNCH_KSTAR(KD)                                                                      \
   hipLaunchKernelGGL(kstar_kernel<KD>, grid, block, 0, st, dXq, m->Xs, m->ls, m->constv, m->alpha, \
-                     w.KS, w.mean_part, m->N, m->Npad, w.Bcap, m->has_const, m->work_counter)
+                     w.KS, w.mean_part, m->N, m->Npad, w.Bcap, m->has_const)
   switch (kind) {
     case 0: GP_LAUNCH_KSTAR(0); break;
     case 1: GP_LAUNCH_KSTAR(1); break;
@@ -123,351 +123,28 @@ int launch_kstar(gpemu_model *m, int64_t B, const double *dXq, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // Triangular GEMM with fused column sum-of-squares.
 //   V[i][b] = sum_{j<=i} Wt[j][i] * KS[j][b]      (per PC p; both operands are k-major)
-//   out[p][rb][b] = sum_{i in row block rb} V[i][b]^2
-// Workgroup = 256 threads = 4 waves (2 x 2), tile 128 x 128, K step 16, LDS double buffered.
+//   out[b][p][rb] = sum_{i in 64-row block rb} V[i][b]^2
 // MFMA v_mfma_f64_16x16x4_f64: lane l supplies A[i = l&15][k = l>>4], B[k = l>>4][n = l&15];
-// D[reg] is row (l>>4) + 4*reg, column l&15.
-constexpr int KT = 16;
-constexpr int LSTR = 144;  // LDS row stride in doubles: (2*LSTR) % 64 == 32 -> conflict-free b64 reads
+// D[reg] is row (l>>4) + 4*reg, column l&15 (verified by tools/mfma_f64_peak).
+//
+// One 512-thread workgroup per CU: 8 waves = 2 per SIMD, arranged 2 (M) x 4 (N), 32 x 32 per wave
+// (2 x 2 MFMA tiles, 16 accumulator registers) on a 64 x 128 tile with K step 32, LDS double
+// buffered (112 KiB, which also pins residency at one workgroup per CU).  Work items (row block, PC,
+// column block) are ordered by decreasing K extent, so the hardware dispatcher hands heavy items out
+// first and light ones fill the tail.  Measured history (C3, B = 512): 128x128 tiles / 4 waves
+// 182 us (accumulators bounced through AGPRs, 1 wave/SIMD); 64x128 / 2 workgroups per CU 123 us;
+// this kernel 117 us; of that ~98 us is the bare MFMA stream of the same item schedule.
+constexpr int TM = 64;      // rows per item
+constexpr int KT = 32;      // K step
+constexpr int LSTRA = 80;   // LDS row strides in doubles: (2 * stride) % 64 == 32, so the two 16-lane
+constexpr int LSTRB = 144;  // groups of a half-wave hit disjoint 32-bank windows (ds_read_b64)
 
-__global__ __launch_bounds__(256) void trmm_vsq_kernel(const double *__restrict__ Wt,
-                                                       const double *__restrict__ KS,
-                                                       double *__restrict__ out, int64_t Npad,
-                                                       int64_t Bcap, int k, int nrb, int ncb) {
-  __shared__ __attribute__((aligned(16))) double sA[2][KT][LSTR];
-  __shared__ __attribute__((aligned(16))) double sB[2][KT][LSTR];
-  __shared__ double red[2][TILE];
-
-  // heavy row blocks first (work per block ~ rb + 1)
-  const int bid = blockIdx.x;
-  const int rbi = bid / (k * ncb);
-  const int rem = bid - rbi * (k * ncb);
-  const int p = rem / ncb;
-  const int cb = rem - p * ncb;
-  const int rb = nrb - 1 - rbi;
-  const int64_t i0 = (int64_t)rb * TILE, b0 = (int64_t)cb * TILE;
-  const double *A = Wt + (int64_t)p * Npad * Npad + i0;
-  const double *Bm = KS + (int64_t)p * Npad * Bcap + b0;
-  const int ntile = (int)((i0 + TILE) / KT);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int lr = lane & 15, lk = lane >> 4;
-
-  // global -> register staging: 4 x 16 B per operand per thread; one wave-load = one 1 KiB row
-  d2 ra[4], rbv[4];
-  auto gload = [&](int t) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int idx = tid + 256 * r;
-      int row = idx >> 6, c2 = idx & 63;
-      ra[r] = *reinterpret_cast<const d2 *>(A + (int64_t)(t * KT + row) * Npad + 2 * c2);
-      rbv[r] = *reinterpret_cast<const d2 *>(Bm + (int64_t)(t * KT + row) * Bcap + 2 * c2);
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int idx = tid + 256 * r;
-      int row = idx >> 6, c2 = idx & 63;
-      *reinterpret_cast<d2 *>(&sA[buf][row][2 * c2]) = ra[r];
-      *reinterpret_cast<d2 *>(&sB[buf][row][2 * c2]) = rbv[r];
-    }
-  };
-
-  d4 acc[4][4];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
-
-  gload(0);
-  sstore(0);
-  __syncthreads();
-  for (int t = 0; t < ntile; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntile) gload(t + 1);
-#pragma unroll
-    for (int ks = 0; ks < KT / 4; ++ks) {
-      double a[4], b[4];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) a[mi] = sA[buf][ks * 4 + lk][wm * 64 + mi * 16 + lr];
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) b[ni] = sB[buf][ks * 4 + lk][wn * 64 + ni * 16 + lr];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-    }
-    if (t + 1 < ntile) sstore(buf ^ 1);
-    __syncthreads();
-  }
-
-  // epilogue: column sums of V^2 over this wave's 64 rows
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    double s = 0.0;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s = fma(acc[mi][ni][r], acc[mi][ni][r], s);
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    if (lk == 0) red[wm][wn * 64 + ni * 16 + lr] = s;
-  }
-  __syncthreads();
-  if (tid < TILE) out[((int64_t)p * nrb + rb) * Bcap + b0 + tid] = red[0][tid] + red[1][tid];
-}
-
-
-// ------------------------------------------------------------------------------------------
-// v2: 64-row x 128-column tile, 4 waves (2 x 2, 32 x 64 per wave = 2 x 4 MFMA tiles, 64 accumulator
-// registers), two workgroups per CU (2 waves/SIMD).  Smaller work items (<= 4 "units" instead of 8)
-// balance the triangular work over 256 CUs, and the accumulators stay in VGPRs for the whole loop.
-constexpr int TM2 = 64;
-constexpr int LSTRA2 = 80;   // (2*80) % 64 == 32
-
-__global__ __launch_bounds__(256, 2) void trmm_vsq_kernel_v2(const double *__restrict__ Wt,
-                                                             const double *__restrict__ KS,
-                                                             double *__restrict__ out, int64_t Npad,
-                                                             int64_t Bcap, int k, int nrb2, int ncb,
-                                                             int nrb_out, int xcd_map) {
-  __shared__ __attribute__((aligned(16))) double sA[2][KT][LSTRA2];
-  __shared__ __attribute__((aligned(16))) double sB[2][KT][LSTR];
-  __shared__ double red[2][TILE];
-
-  // Work-item order: heavy (long K) row blocks first.  XCD affinity: workgroups are dealt round-robin
-  // over the 8 XCDs (bid % 8), so give every XCD whole (PC, column-block) combos: the 16 row blocks
-  // of a combo stream the same K_* tiles in step and share them through that XCD's L2 (speed only).
-  const int ncombo = k * ncb;
-  int rbi, combo;
-  if (xcd_map) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, cpx = ncombo >> 3;
-    rbi = slot / cpx;
-    combo = (slot - rbi * cpx) * 8 + xcd;
-  } else {
-    rbi = blockIdx.x / ncombo;
-    combo = blockIdx.x - rbi * ncombo;
-  }
-  const int p = combo / ncb;
-  const int cb = combo - p * ncb;
-  const int rb = nrb2 - 1 - rbi;
-  const int64_t i0 = (int64_t)rb * TM2, b0 = (int64_t)cb * TILE;
-  const double *A = Wt + (int64_t)p * Npad * Npad + i0;
-  const double *Bm = KS + (int64_t)p * Npad * Bcap + b0;
-  const int ntile = (int)((i0 + TM2) / KT);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int lr = lane & 15, lk = lane >> 4;
-
-  // staging: A tile 16 x 64 doubles = 512 x 16 B (2 per thread), B tile 16 x 128 = 1024 x 16 B (4)
-  d2 ra[2], rbv[4];
-  auto gload = [&](int t) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      int idx = tid + 256 * r;
-      int row = idx >> 5, c2 = idx & 31;
-      ra[r] = *reinterpret_cast<const d2 *>(A + (int64_t)(t * KT + row) * Npad + 2 * c2);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int idx = tid + 256 * r;
-      int row = idx >> 6, c2 = idx & 63;
-      rbv[r] = *reinterpret_cast<const d2 *>(Bm + (int64_t)(t * KT + row) * Bcap + 2 * c2);
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      int idx = tid + 256 * r;
-      int row = idx >> 5, c2 = idx & 31;
-      *reinterpret_cast<d2 *>(&sA[buf][row][2 * c2]) = ra[r];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int idx = tid + 256 * r;
-      int row = idx >> 6, c2 = idx & 63;
-      *reinterpret_cast<d2 *>(&sB[buf][row][2 * c2]) = rbv[r];
-    }
-  };
-
-  d4 acc[2][4];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
-
-  gload(0);
-  sstore(0);
-  __syncthreads();
-  for (int t = 0; t < ntile; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntile) gload(t + 1);
-#pragma unroll
-    for (int ks = 0; ks < KT / 4; ++ks) {
-      double a[2], b[4];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) a[mi] = sA[buf][ks * 4 + lk][wm * 32 + mi * 16 + lr];
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) b[ni] = sB[buf][ks * 4 + lk][wn * 64 + ni * 16 + lr];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-    }
-    if (t + 1 < ntile) sstore(buf ^ 1);
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    double s = 0.0;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s = fma(acc[mi][ni][r], acc[mi][ni][r], s);
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    if (lk == 0) red[wm][wn * 64 + ni * 16 + lr] = s;
-  }
-  __syncthreads();
-  if (tid < TILE) out[((int64_t)p * nrb_out + rb) * Bcap + b0 + tid] = red[0][tid] + red[1][tid];
-}
-
-// ------------------------------------------------------------------------------------------
-// v3 = v2's tile (64 x 128, 4 waves, 2 workgroups per CU) made persistent: the grid is 2 x #CU
-// workgroups that pull (row block, PC, column block) items from a device counter, heaviest first, so
-// the triangular work is balanced whatever the dispatcher's placement (LPT scheduling).  The counter
-// is zeroed by kstar_kernel, which always runs before this kernel on the same stream.  Operand
-// fragments of k-step ks+1 are read from LDS before the MFMAs of k-step ks are issued.
-__global__ __launch_bounds__(256, 2) void trmm_vsq_kernel_v3(const double *__restrict__ Wt,
-                                                             const double *__restrict__ KS,
-                                                             double *__restrict__ out,
-                                                             int *__restrict__ counter, int64_t Npad,
-                                                             int64_t Bcap, int k, int nrb2, int ncb,
-                                                             int nitems) {
-  __shared__ __attribute__((aligned(16))) double sA[2][KT][LSTRA2];
-  __shared__ __attribute__((aligned(16))) double sB[2][KT][LSTR];
-  __shared__ double red[2][TILE];
-  __shared__ int s_item;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int lr = lane & 15, lk = lane >> 4;
-  const int ncombo = k * ncb;
-  // staging coordinates (A: 2 x 16 B per thread, B: 4 x 16 B per thread)
-  const int arow = tid >> 5, ac2 = tid & 31;   // + 8 rows for the second load
-  const int brow = tid >> 6, bc2 = tid & 63;   // + 4 rows per further load
-
-  for (;;) {
-    if (tid == 0) s_item = atomicAdd(counter, 1);
-    __syncthreads();
-    const int item = s_item;
-    if (item >= nitems) break;   // uniform
-    const int rbi = item / ncombo;
-    const int combo = item - rbi * ncombo;
-    const int p = combo / ncb;
-    const int cb = combo - p * ncb;
-    const int rb = nrb2 - 1 - rbi;
-    const int64_t i0 = (int64_t)rb * TM2, b0 = (int64_t)cb * TILE;
-    const int ntile = (int)((i0 + TM2) / KT);
-    const double *pa = Wt + (int64_t)p * Npad * Npad + i0 + (int64_t)arow * Npad + 2 * ac2;
-    const double *pb = KS + (int64_t)p * Npad * Bcap + b0 + (int64_t)brow * Bcap + 2 * bc2;
-    const int64_t astep = (int64_t)KT * Npad, bstep = (int64_t)KT * Bcap;
-
-    d2 ra[2], rbv[4];
-    auto gload = [&]() {
-      ra[0] = *reinterpret_cast<const d2 *>(pa);
-      ra[1] = *reinterpret_cast<const d2 *>(pa + 8 * Npad);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) rbv[r] = *reinterpret_cast<const d2 *>(pb + (int64_t)(4 * r) * Bcap);
-      pa += astep;
-      pb += bstep;
-    };
-    auto sstore = [&](int buf) {
-      *reinterpret_cast<d2 *>(&sA[buf][arow][2 * ac2]) = ra[0];
-      *reinterpret_cast<d2 *>(&sA[buf][arow + 8][2 * ac2]) = ra[1];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) *reinterpret_cast<d2 *>(&sB[buf][brow + 4 * r][2 * bc2]) = rbv[r];
-    };
-
-    d4 acc[2][4];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
-
-    gload();
-    sstore(0);
-    __syncthreads();
-    for (int t = 0; t < ntile; ++t) {
-      const int buf = t & 1;
-      if (t + 1 < ntile) gload();
-      double a[2][2], b[2][4];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) a[0][mi] = sA[buf][lk][wm * 32 + mi * 16 + lr];
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) b[0][ni] = sB[buf][lk][wn * 64 + ni * 16 + lr];
-#pragma unroll
-      for (int ks = 0; ks < KT / 4; ++ks) {
-        const int cur = ks & 1, nxt = cur ^ 1;
-        if (ks + 1 < KT / 4) {
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) a[nxt][mi] = sA[buf][(ks + 1) * 4 + lk][wm * 32 + mi * 16 + lr];
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) b[nxt][ni] = sB[buf][(ks + 1) * 4 + lk][wn * 64 + ni * 16 + lr];
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][mi], b[cur][ni], acc[mi][ni], 0, 0, 0);
-      }
-      if (t + 1 < ntile) sstore(buf ^ 1);
-      __syncthreads();
-    }
-
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      double s = 0.0;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s = fma(acc[mi][ni][r], acc[mi][ni][r], s);
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      if (lk == 0) red[wm][wn * 64 + ni * 16 + lr] = s;
-    }
-    __syncthreads();
-    if (tid < TILE) out[((int64_t)p * nrb2 + rb) * Bcap + b0 + tid] = red[0][tid] + red[1][tid];
-    // the next item's first __syncthreads (after the counter read) orders the reuse of red / s_item
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// v4: one 512-thread workgroup per CU (8 waves = 2 per SIMD, 2 (M) x 4 (N), 32 x 32 per wave) on a
-// 64 x 128 tile with K step 32.  All 8 waves work on ONE item, so an item runs at the CU's full MFMA
-// rate (with two independent workgroups per CU the longest item ran at half rate and set the
-// makespan).  112 KiB of LDS pins residency at one workgroup per CU; the hardware dispatcher hands
-// the heavy-first ordered items to CUs as they free up.
-constexpr int KT4 = 32;
-
-template <int DBG>
-__global__ __launch_bounds__(512, 2) void trmm_vsq_kernel_v4(const double *__restrict__ Wt,
-                                                             const double *__restrict__ KS,
-                                                             double *__restrict__ out, int64_t Npad,
-                                                             int64_t Bcap, int k, int nrb2, int ncb) {
-  __shared__ __attribute__((aligned(16))) double sA[2][KT4][LSTRA2];
-  __shared__ __attribute__((aligned(16))) double sB[2][KT4][LSTR];
+__global__ __launch_bounds__(512, 2) void trmm_vsq_kernel(const double *__restrict__ Wt,
+                                                          const double *__restrict__ KS,
+                                                          double *__restrict__ out, int64_t Npad,
+                                                          int64_t Bcap, int k, int nrb, int ncb) {
+  __shared__ __attribute__((aligned(16))) double sA[2][KT][LSTRA];
+  __shared__ __attribute__((aligned(16))) double sB[2][KT][LSTRB];
   __shared__ double red[2][TILE];
 
   const int ncombo = k * ncb;
@@ -475,21 +152,22 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_kernel_v4(const double *__res
   const int combo = blockIdx.x - rbi * ncombo;
   const int p = combo / ncb;
   const int cb = combo - p * ncb;
-  const int rb = nrb2 - 1 - rbi;  // heavy (long K) row blocks first
-  const int64_t i0 = (int64_t)rb * TM2, b0 = (int64_t)cb * TILE;
-  const int ntile = (int)((i0 + TM2 + KT4 - 1) / KT4);
+  const int rb = nrb - 1 - rbi;  // heavy (long K) row blocks first
+  const int64_t i0 = (int64_t)rb * TM, b0 = (int64_t)cb * TILE;
+  const int ntile = (int)((i0 + TM + KT - 1) / KT);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int lr = lane & 15, lk = lane >> 4;
-  // staging: A tile 32 x 64 doubles = 1024 x 16 B (2 per thread), B tile 32 x 128 = 2048 x 16 B (4)
+  // staging: A tile 32 x 64 doubles = 1024 x 16 B (2 per thread), B tile 32 x 128 = 2048 x 16 B (4);
+  // every wave-load is one contiguous 512 B / 1 KiB row segment
   const int arow = tid >> 5, ac2 = tid & 31;   // rows arow, arow + 16
   const int brow = tid >> 6, bc2 = tid & 63;   // rows brow + 8 r
   const double *pa = Wt + (int64_t)p * Npad * Npad + i0 + (int64_t)arow * Npad + 2 * ac2;
   const double *pb = KS + (int64_t)p * Npad * Bcap + b0 + (int64_t)brow * Bcap + 2 * bc2;
-  const int64_t astep = (int64_t)KT4 * Npad, bstep = (int64_t)KT4 * Bcap;
+  const int64_t astep = (int64_t)KT * Npad, bstep = (int64_t)KT * Bcap;
 
   d2 ra[2], rbv[4];
   auto gload = [&]() {
@@ -518,18 +196,17 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_kernel_v4(const double *__res
   __syncthreads();
   for (int t = 0; t < ntile; ++t) {
     const int buf = t & 1;
-    if (DBG != 1 && DBG != 3 && t + 1 < ntile) gload();
+    if (t + 1 < ntile) gload();
+    // operand fragments of k-step ks+1 are read from LDS before the MFMAs of k-step ks are issued
     double a[2][2], b[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) a[0][mi] = sA[buf][lk][wm * 32 + mi * 16 + lr];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) b[0][ni] = sB[buf][lk][wn * 32 + ni * 16 + lr];
 #pragma unroll
-    for (int ks = 0; ks < KT4 / 4; ++ks) {
+    for (int ks = 0; ks < KT / 4; ++ks) {
       const int cur = ks & 1, nxt = cur ^ 1;
-      if (DBG == 3) {
-        a[nxt][0] = a[cur][0]; a[nxt][1] = a[cur][1]; b[nxt][0] = b[cur][0]; b[nxt][1] = b[cur][1];
-      } else if (ks + 1 < KT4 / 4) {
+      if (ks + 1 < KT / 4) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) a[nxt][mi] = sA[buf][(ks + 1) * 4 + lk][wm * 32 + mi * 16 + lr];
 #pragma unroll
@@ -539,14 +216,13 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_kernel_v4(const double *__res
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
-          if (DBG != 2) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][mi], b[cur][ni], acc[mi][ni], 0, 0, 0);
-          else acc[mi][ni][0] += a[cur][mi] + b[cur][ni];
+          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][mi], b[cur][ni], acc[mi][ni], 0, 0, 0);
     }
-    if (DBG != 1 && DBG != 3 && t + 1 < ntile) sstore(buf ^ 1);
+    if (t + 1 < ntile) sstore(buf ^ 1);
     __syncthreads();
   }
 
-  // column sums of V^2: this wave's 32 rows x 32 columns
+  // column sums of V^2 over this wave's 32 rows x 32 columns, then over the two row halves
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     double s = 0.0;
@@ -559,42 +235,267 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_kernel_v4(const double *__res
     if (lk == 0) red[wm][wn * 32 + ni * 16 + lr] = s;
   }
   __syncthreads();
-  if (tid < TILE) out[((int64_t)p * nrb2 + rb) * Bcap + b0 + tid] = red[0][tid] + red[1][tid];
+  if (tid < TILE) out[((b0 + tid) * k + p) * nrb + rb] = red[0][tid] + red[1][tid];
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent form of the same tile: one workgroup per CU walks a host-built list of items (LPT
+// schedule over the known K extents, so the triangular work is balanced to within one small item)
+// as ONE software-pipelined stream of k-tiles:
+//   iteration s:  global loads of k-tile s+2 -> registers (two register sets)
+//                 MFMAs of k-tile s from LDS buffer s&1, with the LDS stores of k-tile s+1
+//                 (loaded during iteration s-1) interleaved between the MFMA groups
+//                 one barrier
+// so neither the global-load latency nor the LDS store pass (48 KiB per k-tile at ~80 B/clk) nor an
+// item's prologue sits on the MFMA critical path.  Items of the first quarter of the rows (short K)
+// are split into two 64-column halves to give the schedule small pieces for its tail.
+struct TrmmItem {
+  int p, rb, col0, half;  // PC, 64-row block, first column, 1 = 64-column item
+};
+
+__global__ __launch_bounds__(512, 2) void trmm_vsq_persistent_kernel(
+    const double *__restrict__ Wt, const double *__restrict__ KS, double *__restrict__ out,
+    const TrmmItem *__restrict__ sched, const int *__restrict__ sched_cnt, int max_items,
+    int64_t Npad, int64_t Bcap, int k, int nrb) {
+  __shared__ __attribute__((aligned(16))) double sA[2][KT][LSTRA];
+  __shared__ __attribute__((aligned(16))) double sB[2][KT][LSTRB];
+  __shared__ double red[2][TILE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int arow = tid >> 5, ac2 = tid & 31;   // A (and half-width B) staging: rows arow, arow + 16
+  const int brow = tid >> 6, bc2 = tid & 63;   // full-width B staging: rows brow + 8 r
+  const int64_t astep = (int64_t)KT * Npad, bstep = (int64_t)KT * Bcap;
+
+  const int nitems = sched_cnt[blockIdx.x];
+  const TrmmItem *my = sched + (int64_t)blockIdx.x * max_items;
+
+  // ---- load cursor (runs two k-tiles ahead of the compute cursor) ----
+  // Every call issues exactly six 16-byte loads and every staged k-tile is stored with exactly six
+  // LDS stores, unconditionally: with a fixed number of memory operations per iteration hipcc can
+  // count s_waitcnt vmcnt(N) precisely and the stores of k-tile s+1 wait only for ITS loads, not for
+  // the loads of k-tile s+2 issued just before.  Past the end of the list the cursor re-reads its
+  // last k-tile (harmless), and 64-column items stage the whole 128-column tile they live in.
+  int l_item = 0, l_t = 0, l_nt = 1;
+  const double *l_pa = Wt + (int64_t)arow * Npad + 2 * ac2;
+  const double *l_pb = KS + (int64_t)brow * Bcap + 2 * bc2;
+  auto l_open = [&]() {
+    const TrmmItem it = my[l_item];
+    const int64_t i0 = (int64_t)it.rb * TM;
+    l_nt = (int)((i0 + TM + KT - 1) / KT);
+    l_pa = Wt + (int64_t)it.p * Npad * Npad + i0 + (int64_t)arow * Npad + 2 * ac2;
+    l_pb = KS + (int64_t)it.p * Npad * Bcap + (it.col0 & ~(TILE - 1)) + (int64_t)brow * Bcap + 2 * bc2;
+    l_t = 0;
+  };
+  struct Stage {
+    d2 a[2], b[4];
+  };
+  Stage st0, st1;
+  auto gload = [&](Stage &sg) {
+    sg.a[0] = *reinterpret_cast<const d2 *>(l_pa);
+    sg.a[1] = *reinterpret_cast<const d2 *>(l_pa + 16 * Npad);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sg.b[r] = *reinterpret_cast<const d2 *>(l_pb + (int64_t)(8 * r) * Bcap);
+    if (l_item < nitems) {
+      if (++l_t == l_nt) {
+        if (++l_item < nitems) l_open();   // else: stay on the last k-tile
+      } else {
+        l_pa += astep;
+        l_pb += bstep;
+      }
+    }
+  };
+  // one of the six 16-byte LDS stores of a staged k-tile (part = 0..5, compile-time after unrolling)
+  auto sstore_part = [&](const Stage &sg, int buf, int part) {
+    if (part == 0) *reinterpret_cast<d2 *>(&sA[buf][arow][2 * ac2]) = sg.a[0];
+    else if (part == 1) *reinterpret_cast<d2 *>(&sA[buf][arow + 16][2 * ac2]) = sg.a[1];
+    else *reinterpret_cast<d2 *>(&sB[buf][brow + 8 * (part - 2)][2 * bc2]) = sg.b[part - 2];
+  };
+
+  if (nitems == 0) return;
+  l_open();
+  // prologue: k-tile 0 -> LDS buffer 0, k-tile 1 -> register set st1
+  gload(st0);
+#pragma unroll
+  for (int part = 0; part < 6; ++part) sstore_part(st0, 0, part);
+  gload(st1);
+  __syncthreads();
+
+  d4 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+
+  int c_item = 0, c_t = 0;
+  TrmmItem cur = my[0];
+  int c_nt = (int)(((int64_t)cur.rb * TM + TM + KT - 1) / KT);
+
+  // one k-tile: loads of k-tile +2 into `snew`, MFMAs from LDS buffer `buf`, LDS stores of `sold`
+  // (k-tile +1) into the other buffer; returns true when the worker's last item is finished
+  auto step = [&](int buf, Stage &snew, const Stage &sold) -> bool {
+    gload(snew);
+    if (cur.half) {
+      double a[2][2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[0][mi] = sA[buf][lk][wm * 32 + mi * 16 + lr];
+      const int hc = (cur.col0 & 64) + wn * 16 + lr;
+      b[0] = sB[buf][lk][hc];
+#pragma unroll
+      for (int ks = 0; ks < KT / 4; ++ks) {
+        const int cu = ks & 1, nx = cu ^ 1;
+        if (ks + 1 < KT / 4) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) a[nx][mi] = sA[buf][(ks + 1) * 4 + lk][wm * 32 + mi * 16 + lr];
+          b[nx] = sB[buf][(ks + 1) * 4 + lk][hc];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the next k-step's LDS reads ahead of these MFMAs
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[mi][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cu][mi], b[cu], acc[mi][0], 0, 0, 0);
+        if (ks >= 1 && ks <= 6) sstore_part(sold, buf ^ 1, ks - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      double a[2][2], b[2][2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[0][mi] = sA[buf][lk][wm * 32 + mi * 16 + lr];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) b[0][ni] = sB[buf][lk][wn * 32 + ni * 16 + lr];
+#pragma unroll
+      for (int ks = 0; ks < KT / 4; ++ks) {
+        const int cu = ks & 1, nx = cu ^ 1;
+        if (ks + 1 < KT / 4) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) a[nx][mi] = sA[buf][(ks + 1) * 4 + lk][wm * 32 + mi * 16 + lr];
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) b[nx][ni] = sB[buf][(ks + 1) * 4 + lk][wn * 32 + ni * 16 + lr];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the next k-step's LDS reads ahead of these MFMAs
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cu][mi], b[cu][ni], acc[mi][ni], 0, 0, 0);
+        if (ks >= 1 && ks <= 6) sstore_part(sold, buf ^ 1, ks - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    if (++c_t == c_nt) {
+      // item finished: column sums of V^2 over this wave's rows, then over the two row halves
+      const int ncols = cur.half ? 64 : TILE;
+      const int wcol = cur.half ? wn * 16 : wn * 32;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        if (ni == 0 || !cur.half) {
+          double sq = 0.0;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sq = fma(acc[mi][ni][r], acc[mi][ni][r], sq);
+          sq += __shfl_xor(sq, 16);
+          sq += __shfl_xor(sq, 32);
+          if (lk == 0) red[wm][wcol + ni * 16 + lr] = sq;
+        }
+      }
+      __syncthreads();
+      if (tid < ncols)
+        out[(((int64_t)cur.col0 + tid) * k + cur.p) * nrb + cur.rb] = red[0][tid] + red[1][tid];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+      if (++c_item == nitems) return true;
+      cur = my[c_item];
+      c_nt = (int)(((int64_t)cur.rb * TM + TM + KT - 1) / KT);
+      c_t = 0;
+      // `red` is rewritten only after at least one more barrier (the next k-tile's)
+    }
+    return false;
+  };
+  for (;;) {
+    if (step(0, st0, st1)) break;
+    if (step(1, st1, st0)) break;
+  }
+}
+
+// host side: LPT schedule of the items of one launch shape (cached per model and column-tile count)
+static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &flat, std::vector<int> &cnt,
+                                int &max_items, int &nworkers) {
+  const int nrb = (int)m->vsq_nrb, k = (int)m->k;
+  struct It { double cost; TrmmItem it; };
+  std::vector<It> items;
+  const int split_below = nrb / 4;   // row blocks with short K are issued as two 64-column halves
+  const double ov = 0.15;            // per-item cost of the epilogue, in k-tiles
+  for (int rb = 0; rb < nrb; ++rb) {
+    const double nt = (double)(((int64_t)rb * TM + TM + KT - 1) / KT);
+    for (int p = 0; p < k; ++p)
+      for (int cb = 0; cb < ncb; ++cb) {
+        if (rb < split_below) {
+          items.push_back({0.5 * nt + ov, TrmmItem{p, rb, cb * TILE, 1}});
+          items.push_back({0.5 * nt + ov, TrmmItem{p, rb, cb * TILE + 64, 1}});
+        } else {
+          items.push_back({nt + ov, TrmmItem{p, rb, cb * TILE, 0}});
+        }
+      }
+  }
+  std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.cost > b.cost; });
+  nworkers = m->num_cu < (int)items.size() ? m->num_cu : (int)items.size();
+  std::vector<std::vector<TrmmItem>> per(nworkers);
+  std::vector<double> load(nworkers, 0.0);
+  for (const It &x : items) {  // longest processing time first onto the least loaded worker
+    int best = 0;
+    for (int w = 1; w < nworkers; ++w)
+      if (load[w] < load[best]) best = w;
+    per[best].push_back(x.it);
+    load[best] += x.cost;
+  }
+  max_items = 1;
+  for (auto &v : per) max_items = v.size() > (size_t)max_items ? (int)v.size() : max_items;
+  flat.assign((size_t)nworkers * max_items, TrmmItem{0, 0, 0, 0});
+  cnt.assign(nworkers, 0);
+  for (int w = 0; w < nworkers; ++w) {
+    cnt[w] = (int)per[w].size();
+    for (size_t i = 0; i < per[w].size(); ++i) flat[(size_t)w * max_items + i] = per[w][i];
+  }
 }
 
 int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
   const Workspace &w = m->ws;
-  const int nrb = (int)(m->Npad / TILE);
+  const int nrb = (int)m->vsq_nrb;
   const int ncb = (int)(round_up(B, TILE) / TILE);  // only the column tiles that hold real queries
-  const int nblk = nrb * (int)m->k * ncb;
+  static const bool use_simple = getenv("GPEMU_TRMM_SIMPLE") != nullptr;
+  if (use_simple) {
+    const int pe0 = prof_mark(m, st);
+    hipLaunchKernelGGL(trmm_vsq_kernel, dim3((unsigned)(nrb * (int)m->k * ncb)), dim3(512), 0, st, m->Wt,
+                       w.KS, w.vsq_part, m->Npad, w.Bcap, (int)m->k, nrb, ncb);
+    GP_HIP(hipGetLastError());
+    prof_pair(m, 0, pe0, prof_mark(m, st));
+    return GPEMU_OK;
+  }
+  if (m->sched_ncb != ncb) {
+    std::vector<TrmmItem> flat;
+    std::vector<int> cnt;
+    int max_items = 0, nworkers = 0;
+    build_trmm_schedule(m, ncb, flat, cnt, max_items, nworkers);
+    GP_HIP(hipStreamSynchronize(st));
+    (void)hipFree(m->sched_items);
+    (void)hipFree(m->sched_cnt);
+    m->sched_items = nullptr; m->sched_cnt = nullptr; m->sched_ncb = -1;
+    GP_HIP(hipMalloc(&m->sched_items, sizeof(TrmmItem) * flat.size()));
+    GP_HIP(hipMalloc((void **)&m->sched_cnt, sizeof(int) * cnt.size()));
+    GP_HIP(hipMemcpy(m->sched_items, flat.data(), sizeof(TrmmItem) * flat.size(), hipMemcpyHostToDevice));
+    GP_HIP(hipMemcpy(m->sched_cnt, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice));
+    m->sched_ncb = ncb; m->sched_max_items = max_items; m->sched_workers = nworkers;
+  }
   const int pe0 = prof_mark(m, st);
-  if (m->trmm_variant == 4) {
-    const int nrb2 = (int)(m->Npad / TM2);
-    static const int dbg = getenv("GPEMU_TRMM_DBG") ? atoi(getenv("GPEMU_TRMM_DBG")) : 0;
-    const dim3 g4((unsigned)(nrb2 * (int)m->k * ncb));
-    if (dbg == 1)
-      hipLaunchKernelGGL(trmm_vsq_kernel_v4<1>, g4, dim3(512), 0, st, m->Wt, w.KS, w.vsq_part, m->Npad, w.Bcap, (int)m->k, nrb2, ncb);
-    else if (dbg == 3)
-      hipLaunchKernelGGL(trmm_vsq_kernel_v4<3>, g4, dim3(512), 0, st, m->Wt, w.KS, w.vsq_part, m->Npad, w.Bcap, (int)m->k, nrb2, ncb);
-    else if (dbg == 2)
-      hipLaunchKernelGGL(trmm_vsq_kernel_v4<2>, g4, dim3(512), 0, st, m->Wt, w.KS, w.vsq_part, m->Npad, w.Bcap, (int)m->k, nrb2, ncb);
-    else
-      hipLaunchKernelGGL(trmm_vsq_kernel_v4<0>, g4, dim3(512), 0, st, m->Wt, w.KS, w.vsq_part, m->Npad, w.Bcap, (int)m->k, nrb2, ncb);
-  } else if (m->trmm_variant == 3) {
-    const int nrb2 = (int)(m->Npad / TM2);
-    const int nitems = nrb2 * (int)m->k * ncb;
-    int grid = 2 * m->num_cu;
-    if (grid > nitems) grid = nitems;
-    hipLaunchKernelGGL(trmm_vsq_kernel_v3, dim3((unsigned)grid), dim3(256), 0, st, m->Wt, w.KS,
-                       w.vsq_part, m->work_counter, m->Npad, w.Bcap, (int)m->k, nrb2, ncb, nitems);
-  } else if (m->trmm_variant == 2) {
-    const int nrb2 = (int)(m->Npad / TM2);
-    hipLaunchKernelGGL(trmm_vsq_kernel_v2, dim3((unsigned)(nrb2 * (int)m->k * ncb)), dim3(256), 0, st,
-                       m->Wt, w.KS, w.vsq_part, m->Npad, w.Bcap, (int)m->k, nrb2, ncb, nrb2,
-                       (((int)m->k * ncb) % 8 == 0 && !getenv("GPEMU_NO_XCD_MAP")) ? 1 : 0);
-  } else
-  hipLaunchKernelGGL(trmm_vsq_kernel, dim3((unsigned)nblk), dim3(256), 0, st, m->Wt, w.KS,
-                     w.vsq_part, m->Npad, w.Bcap, (int)m->k, nrb, ncb);
+  hipLaunchKernelGGL(trmm_vsq_persistent_kernel, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
+                     w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
+                     m->Npad, w.Bcap, (int)m->k, nrb);
   GP_HIP(hipGetLastError());
   prof_pair(m, 0, pe0, prof_mark(m, st));
   return GPEMU_OK;
@@ -611,8 +512,8 @@ __global__ void reduce_mean_var_kernel(const double *__restrict__ mean_part,
   int p = (int)(idx / B);
   int64_t b = idx - (int64_t)p * B;
   double mu = 0.0, vs = 0.0;
-  for (int c = 0; c < nchunk; ++c) mu += mean_part[((int64_t)p * nchunk + c) * Bcap + b];
-  for (int r = 0; r < nrb; ++r) vs += vsq_part[((int64_t)p * nrb + r) * Bcap + b];
+  for (int c = 0; c < nchunk; ++c) mu += mean_part[(b * k + p) * nchunk + c];
+  for (int r = 0; r < nrb; ++r) vs += vsq_part[(b * k + p) * nrb + r];
   double v = kdiag[p] - vs;
   if (v < 0.0) v = 0.0;     // skl _gpr.py:479-485
   double sd = sqrt(v);      // predict returns std (skl _gpr.py:494) ...
