@@ -1,0 +1,23 @@
+// fp64 MFMA GEMM used by the fit-side kernels (see k_gemm.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace gpemu {
+
+struct GemmArgs {
+  const double *A = nullptr;
+  const double *B = nullptr;
+  double *C = nullptr;
+  int64_t lda = 0, ldb = 0, ldc = 0;
+  int64_t strideA = 0, strideB = 0, strideC = 0;  // per batch entry (blockIdx.z)
+  int M = 0, N = 0, K = 0;
+  double alpha = 1.0, beta = 0.0;
+  int lower_only = 0;  // skip 64 x 64 tiles strictly above the diagonal
+};
+
+// C = alpha op(A) op(B) + beta C; a_kmajor: A stored [k][m] else [m][k]; b_kmajor: B stored [k][n]
+// else [n][k].  M, N multiples of 64, K multiple of 32.
+int launch_gemm(const GemmArgs &g, bool a_kmajor, bool b_kmajor, int batch, hipStream_t st);
+
+}  // namespace gpemu

@@ -243,7 +243,27 @@ int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int6
     return fail(GPEMU_ERR_HIP);
   }
   GP_STEP(upload(dL, L, k * N * N, st));
-  GP_STEP(launch_trtri_lower_to_Wt(dL, m->Wt, k, N, Np, st));
+  {
+    // W_p = L_p^-1 by the blocked MFMA triangular inverse, written transposed into Wt[p]
+    const int64_t N64 = round_up(N, 64);
+    double *sA = nullptr, *sD = nullptr, *sW = nullptr, *sT = nullptr;
+    rc = dev_alloc(&sA, N64 * N64);
+    if (rc == GPEMU_OK) rc = dev_alloc(&sD, N64 * 64);
+    if (rc == GPEMU_OK) rc = dev_alloc(&sW, N64 * N64);
+    if (rc == GPEMU_OK) rc = dev_alloc(&sT, 64 * N64);
+    if (rc == GPEMU_OK && hipMemsetAsync(m->Wt, 0, sizeof(double) * (size_t)(k * Np * Np), st) != hipSuccess) {
+      set_error("hipMemsetAsync failed");
+      rc = GPEMU_ERR_HIP;
+    }
+    for (int64_t p = 0; p < k && rc == GPEMU_OK; ++p)
+      rc = device_invert_factor_to_Wt(dL + p * N * N, N, m->Wt + p * Np * Np, Np, sA, sD, sW, sT, st);
+    if (rc == GPEMU_OK && hipStreamSynchronize(st) != hipSuccess) {
+      set_error("model_create: triangular inverse failed: %s", hipGetErrorString(hipGetLastError()));
+      rc = GPEMU_ERR_HIP;
+    }
+    hipFree(sA); hipFree(sD); hipFree(sW); hipFree(sT);
+    if (rc != GPEMU_OK) return fail(rc);
+  }
 #undef GP_STEP
   if (hipStreamSynchronize(st) != hipSuccess) {
     set_error("model_create: device synchronisation failed: %s", hipGetErrorString(hipGetLastError()));

@@ -135,6 +135,9 @@ int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq_padded, d
                           int accumulate, hipStream_t st, const AcceptArgs *aa = nullptr);
 int logpost_padded(gpemu_model *m, int64_t B, const double *dXq, double *dout, int accumulate,
                    hipStream_t st, const AcceptArgs *aa = nullptr);
+// fit-side building blocks (k_fit.hip)
+int device_invert_factor_to_Wt(const double *dL, int64_t N, double *Wt, int64_t Npad, double *A, double *Dinv,
+                               double *W, double *T, hipStream_t st);
 // profiling helpers: record an event on `st` and return its pool index (-1 when profiling is off)
 int prof_mark(gpemu_model *m, hipStream_t st);
 void prof_pair(gpemu_model *m, int which, int e0, int e1);

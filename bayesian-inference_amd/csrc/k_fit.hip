@@ -1,0 +1,562 @@
+// Fit side of the GP emulator: kernel matrix, blocked Cholesky, triangular inverse, log-marginal
+// likelihood and its gradient.
+//
+// Replaces the arithmetic behind  ref: emulation.py:169-172  (GaussianProcessRegressor.fit):
+//   skl _gpr.py:580      K, dK = kernel_(X_train, eval_gradient=True)        -> kmat_kernel, grad kernel
+//   skl _gpr.py:585-587  K[diag] += alpha ; L = cholesky(K, lower)           -> blocked right-looking
+//   skl _gpr.py:597      alpha = cho_solve(L, y)                             -> W = L^-1, alpha = W^T (W y)
+//   skl _gpr.py:609-613  lml = -1/2 y.alpha - sum log diag L - N/2 log 2 pi
+//   skl _gpr.py:625-647  grad_i = 1/2 sum_jl (alpha alpha^T - K^-1)_jl dK_jl/dtheta_i,  K^-1 = W^T W
+// The optimiser itself (L-BFGS-B with restarts, skl _gpr.py:299-337) stays on the host and calls
+// gpemu_fit_lml once per evaluation.
+//
+// Blocked Cholesky, panel width 64 (matrix padded to a multiple of 64 with an identity tail):
+//   potrf_diag_kernel   factor the 64 x 64 diagonal block in LDS and invert it      (one wave)
+//   GEMM                panel = A21 . inv(L11)^T                                     (MFMA f64)
+//   GEMM (SYRK)         A22 -= panel . panel^T, lower tiles only                     (MFMA f64)
+// Triangular inverse W = L^-1 by block rows with two MFMA GEMMs per block row; the inverted
+// diagonal blocks come from the Cholesky step.
+#include <cmath>
+
+#include "gemm.h"
+#include "internal.h"
+
+namespace gpemu {
+
+constexpr int NB = 64;
+
+// ---- kernel matrix ---------------------------------------------------------------------------
+__device__ __forceinline__ double base_from_r2(int kind, double r2) {
+  if (kind == 0) return exp(-0.5 * r2);
+  double r = sqrt(r2);
+  if (kind == 1) return exp(-r);
+  if (kind == 2) {
+    double t = r * 1.7320508075688772;
+    return (1.0 + t) * exp(-t);
+  }
+  double t = r * 2.23606797749979;
+  return (1.0 + t + t * t / 3.0) * exp(-t);
+}
+
+// X [Np][DPAD] raw inputs; hp = {ls[DPAD], const, noise}; K[i][j] for i,j < N, identity tail
+__global__ void kmat_kernel(const double *__restrict__ X, const double *__restrict__ hp, double *__restrict__ K,
+                            int N, int Np, int kind, double jitter) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= Np) return;
+  double v;
+  if (i >= N || j >= N) {
+    v = (i == j) ? 1.0 : 0.0;
+  } else if (i == j) {
+    v = 1.0 + hp[DPAD] + hp[DPAD + 1] + jitter;   // np.fill_diagonal(K, 1) + const + noise + alpha
+  } else {
+    double r2 = 0.0;
+#pragma unroll
+    for (int dd = 0; dd < DPAD; ++dd) {
+      double df = X[i * DPAD + dd] / hp[dd] - X[j * DPAD + dd] / hp[dd];   // skl: X / length_scale
+      r2 = fma(df, df, r2);
+    }
+    v = base_from_r2(kind, r2) + hp[DPAD];
+  }
+  K[(int64_t)i * Np + j] = v;
+}
+
+// ---- 64 x 64 diagonal block: Cholesky + inverse ------------------------------------------------
+// One wave, lane = row.  do_factor = 0: the block already holds the factor (only invert).
+__global__ __launch_bounds__(64) void potrf_diag_kernel(double *A, int64_t lda, double *Dinv, int do_factor,
+                                                        int block_index, int *info) {
+  __shared__ double D[NB][NB + 1];
+  __shared__ double Inv[NB][NB + 1];
+  const int lane = threadIdx.x;
+  double *Ab = A + ((int64_t)blockIdx.x * NB) * lda + (int64_t)blockIdx.x * NB;
+  double *Db = Dinv + (int64_t)blockIdx.x * NB * NB;
+  for (int c = 0; c < NB; ++c) D[lane][c] = (c <= lane) ? Ab[(int64_t)lane * lda + c] : 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (do_factor) {
+    for (int j = 0; j < NB; ++j) {
+      double piv = D[j][j];
+      if (!(piv > 0.0) && lane == 0 && info && *info == 0) *info = (block_index + (int)blockIdx.x) * NB + j + 1;
+      piv = sqrt(piv);
+      __builtin_amdgcn_wave_barrier();
+      if (lane == j) D[j][j] = piv;
+      if (lane > j) D[lane][j] = D[lane][j] / piv;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane > j) {
+        const double lij = D[lane][j];
+        for (int c = j + 1; c <= lane; ++c) D[lane][c] -= lij * D[c][j];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    for (int c = 0; c < NB; ++c) Ab[(int64_t)lane * lda + c] = (c <= lane) ? D[lane][c] : 0.0;
+  }
+  // inverse: lane = column c of Inv; solve D x = e_c by forward substitution
+  {
+    const int c = lane;
+    for (int i = 0; i < NB; ++i) {
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int mm = c; mm < i; ++mm) s = fma(-D[i][mm], Inv[mm][c], s);
+      Inv[i][c] = (i >= c) ? s / D[i][i] : 0.0;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int c = 0; c < NB; ++c) Db[lane * NB + c] = Inv[lane][c];
+}
+
+__global__ void copy_block_kernel(const double *__restrict__ src, int64_t lds, double *__restrict__ dst,
+                                  int64_t ldd, int rows, int cols, double scale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (c < cols && r < rows) dst[(int64_t)r * ldd + c] = scale * src[(int64_t)r * lds + c];
+}
+
+static int copy_block(const double *src, int64_t lds, double *dst, int64_t ldd, int rows, int cols,
+                      double scale, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return GPEMU_OK;
+  hipLaunchKernelGGL(copy_block_kernel, dim3((unsigned)((cols + 255) / 256), (unsigned)rows), dim3(256), 0, st,
+                     src, lds, dst, ldd, rows, cols, scale);
+  GP_HIP(hipGetLastError());
+  return GPEMU_OK;
+}
+
+// In-place lower Cholesky of the Np x Np matrix A (Np multiple of 64); Dinv receives the inverted
+// diagonal blocks [Np/64][64][64]; Pbuf is an [Np][64] panel buffer.
+int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, double *Pbuf, int *dinfo, hipStream_t st) {
+  const int nblk = (int)(Np / NB);
+  for (int jb = 0; jb < nblk; ++jb) {
+    const int64_t j0 = (int64_t)jb * NB;
+    double *Ajj = A + j0 * Np + j0;
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, st, Ajj, Np, Dinv + (int64_t)jb * NB * NB, 1, jb, dinfo);
+    GP_HIP(hipGetLastError());
+    const int M = (int)(Np - j0 - NB);
+    if (M <= 0) break;
+    GemmArgs g;   // panel = A21 . inv(L11)^T
+    g.A = A + (j0 + NB) * Np + j0; g.lda = Np;
+    g.B = Dinv + (int64_t)jb * NB * NB; g.ldb = NB;
+    g.C = Pbuf; g.ldc = NB;
+    g.M = M; g.N = NB; g.K = NB;
+    int rc = launch_gemm(g, false, false, 1, st);
+    if (rc != GPEMU_OK) return rc;
+    rc = copy_block(Pbuf, NB, A + (j0 + NB) * Np + j0, Np, M, NB, 1.0, st);
+    if (rc != GPEMU_OK) return rc;
+    GemmArgs s;   // A22 -= panel . panel^T (lower tiles)
+    s.A = Pbuf; s.lda = NB; s.B = Pbuf; s.ldb = NB;
+    s.C = A + (j0 + NB) * Np + (j0 + NB); s.ldc = Np;
+    s.M = M; s.N = M; s.K = NB; s.alpha = -1.0; s.beta = 1.0; s.lower_only = 1;
+    rc = launch_gemm(s, false, false, 1, st);
+    if (rc != GPEMU_OK) return rc;
+  }
+  return GPEMU_OK;
+}
+
+// W = L^-1 (lower, Np x Np, zero above the diagonal) from L (lower triangle of `L`, ld Np) and the
+// inverted diagonal blocks.  T is a [64][Np] scratch.
+int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double *W, double *T, hipStream_t st) {
+  const int nblk = (int)(Np / NB);
+  GP_HIP(hipMemsetAsync(W, 0, sizeof(double) * (size_t)(Np * Np), st));
+  for (int ib = 0; ib < nblk; ++ib) {
+    const int64_t i0 = (int64_t)ib * NB;
+    int rc = copy_block(Dinv + (int64_t)ib * NB * NB, NB, W + i0 * Np + i0, Np, NB, NB, 1.0, st);
+    if (rc != GPEMU_OK) return rc;
+    if (ib == 0) continue;
+    GemmArgs g;   // T = L[i, 0:i0] . W[0:i0, 0:i0]
+    g.A = L + i0 * Np; g.lda = Np;
+    g.B = W; g.ldb = Np;
+    g.C = T; g.ldc = Np;
+    g.M = NB; g.N = (int)i0; g.K = (int)i0;
+    rc = launch_gemm(g, false, true, 1, st);
+    if (rc != GPEMU_OK) return rc;
+    GemmArgs h;   // W[i, 0:i0] = -inv(L_ii) . T
+    h.A = Dinv + (int64_t)ib * NB * NB; h.lda = NB;
+    h.B = T; h.ldb = Np;
+    h.C = W + i0 * Np; h.ldc = Np;
+    h.M = NB; h.N = (int)i0; h.K = NB; h.alpha = -1.0;
+    rc = launch_gemm(h, false, true, 1, st);
+    if (rc != GPEMU_OK) return rc;
+  }
+  return GPEMU_OK;
+}
+
+// ---- small vector kernels ------------------------------------------------------------------------
+// out[i] = sum_j M[i][j] v[j] (trans = 0, one wave per row) or sum_j M[j][i] v[j] (trans = 1)
+__global__ void gemv_kernel(const double *__restrict__ Mx, int64_t ld, const double *__restrict__ v,
+                            double *__restrict__ out, int n, int trans) {
+  if (!trans) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    double s = 0.0;
+    for (int j = lane; j < n; j += 64) s = fma(Mx[(int64_t)row * ld + j], v[j], s);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[row] = s;
+  } else {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n) return;
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s = fma(Mx[(int64_t)j * ld + col], v[j], s);
+    out[col] = s;
+  }
+}
+
+// scal[0] = y.alpha ; scal[1] = sum_{i<N} log L_ii   (one workgroup)
+__global__ __launch_bounds__(1024) void lml_terms_kernel(const double *__restrict__ y, const double *__restrict__ alpha,
+                                                         const double *__restrict__ L, int64_t ld, int N,
+                                                         double *__restrict__ scal) {
+  __shared__ double part[2][16];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    a = fma(y[i], alpha[i], a);
+    b += log(L[(int64_t)i * ld + i]);
+  }
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = a; part[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0.0, sb = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { sa += part[0][w]; sb += part[1][w]; }
+    scal[0] = sa; scal[1] = sb;
+  }
+}
+
+// ---- gradient contraction --------------------------------------------------------------------------
+// gpart[block][t] = 1/2 sum over this block's (j, l) of (alpha_j alpha_l - Kinv_jl) dK_jl/dtheta_t
+// theta order: log l_1..l_d, (log const), (log noise)   (skl kernels.py:733-760, Sum :861-866)
+constexpr int NTH_MAX = DPAD + 2;
+__global__ __launch_bounds__(256) void lml_grad_kernel(const double *__restrict__ X, const double *__restrict__ hp,
+                                                       const double *__restrict__ alpha,
+                                                       const double *__restrict__ Kinv, int64_t ld,
+                                                       double *__restrict__ gpart, int N, int d, int kind,
+                                                       int has_const, int has_noise) {
+  __shared__ double red[NTH_MAX][4];
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  double acc[NTH_MAX];
+#pragma unroll
+  for (int t = 0; t < NTH_MAX; ++t) acc[t] = 0.0;
+  if (l < N) {
+    const double wgt = alpha[j] * alpha[l] - Kinv[(int64_t)j * ld + l];
+    double D[DPAD], r2 = 0.0;
+#pragma unroll
+    for (int dd = 0; dd < DPAD; ++dd) {
+      double df = X[j * DPAD + dd] - X[l * DPAD + dd];
+      D[dd] = (df * df) / (hp[dd] * hp[dd]);   // (x - x')^2 / l^2   (skl kernels.py:1574, 1748)
+      r2 += D[dd];
+    }
+    double f;  // dK_base/dlog l_dd = f * D[dd]
+    if (kind == 0) {
+      f = (j == l) ? 1.0 : exp(-0.5 * r2);                       // K_gradient = D * K
+    } else if (kind == 1) {
+      double r = sqrt(r2);
+      f = (r > 0.0) ? exp(-r) / r : 0.0;                          // K * D / sqrt(sum D), 0 where r == 0
+    } else if (kind == 2) {
+      f = 3.0 * exp(-sqrt(3.0 * r2));                             // 3 D exp(-sqrt(3 sum D))
+    } else {
+      double tmp = sqrt(5.0 * r2);
+      f = 5.0 / 3.0 * (tmp + 1.0) * exp(-tmp);                    // 5/3 D (tmp + 1) exp(-tmp)
+    }
+#pragma unroll
+    for (int dd = 0; dd < DPAD; ++dd) acc[dd] = 0.5 * wgt * f * D[dd];
+    if (has_const) acc[d] = 0.5 * wgt * hp[DPAD];
+    if (has_noise && j == l) acc[d + has_const] = 0.5 * wgt * hp[DPAD + 1];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < NTH_MAX; ++t) {
+    double s = acc[t];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) red[t][wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NTH_MAX) {
+    const int t = threadIdx.x;
+    gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NTH_MAX + t] = (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+  }
+}
+
+__global__ __launch_bounds__(1024) void grad_reduce_kernel(const double *__restrict__ gpart, int nparts,
+                                                           double *__restrict__ grad, int nth) {
+  __shared__ double part[16];
+  for (int t = 0; t < nth; ++t) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += gpart[(int64_t)i * NTH_MAX + t];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += part[w];
+      grad[t] = tot;
+    }
+  }
+}
+
+// transpose the top-left N x N of W (ld Np) into Wt (ld Npad): Wt[j][i] = W[i][j]
+__global__ void transpose_kernel(const double *__restrict__ W, int64_t ldw, double *__restrict__ Wt, int64_t ldt, int n) {
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    int i = by + r, j = bx + threadIdx.x;
+    tile[r][threadIdx.x] = (i < n && j < n) ? W[(int64_t)i * ldw + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    int j = bx + r, i = by + threadIdx.x;
+    if (i < n && j < n) Wt[(int64_t)j * ldt + i] = tile[threadIdx.x][r];
+  }
+}
+
+int launch_transpose(const double *W, int64_t ldw, double *Wt, int64_t ldt, int n, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32)), dim3(32, 8), 0, st,
+                     W, ldw, Wt, ldt, n);
+  GP_HIP(hipGetLastError());
+  return GPEMU_OK;
+}
+
+// copy an N x N lower-triangular host-layout factor (ld N) into the padded Np x Np buffer (identity tail)
+__global__ void pad_lower_kernel(const double *__restrict__ L, int N, double *__restrict__ A, int Np) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= Np) return;
+  double v = 0.0;
+  if (i < N && j < N) v = (j <= i) ? L[(int64_t)i * N + j] : 0.0;
+  else if (i == j) v = 1.0;
+  A[(int64_t)i * Np + j] = v;
+}
+
+// W = L^-1 of one N x N lower factor (device pointer, ld N) written transposed into Wt (ld Npad).
+// scratch: A [Np*Np], Dinv [Np*64], W [Np*Np], T [64*Np]
+int device_invert_factor_to_Wt(const double *dL, int64_t N, double *Wt, int64_t Npad, double *A, double *Dinv,
+                               double *W, double *T, hipStream_t st) {
+  const int64_t Np = round_up(N, NB);
+  hipLaunchKernelGGL(pad_lower_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)Np), dim3(256), 0, st, dL, (int)N, A, (int)Np);
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3((unsigned)(Np / NB)), dim3(64), 0, st, A, Np, Dinv, 0, 0, (int *)nullptr);
+  GP_HIP(hipGetLastError());
+  int rc = device_trtri_blocked(A, Np, Dinv, W, T, st);
+  if (rc != GPEMU_OK) return rc;
+  return launch_transpose(W, Np, Wt, Npad, (int)N, st);
+}
+
+}  // namespace gpemu
+
+// ================================================================================================
+struct gpemu_fit {
+  int device = 0;
+  int64_t N = 0, d = 0, Np = 0;
+  int kind = 0, has_const = 0, has_noise = 0;
+  double jitter = 0.0;
+  hipStream_t stream = nullptr;
+  double *X = nullptr, *hp = nullptr, *K = nullptr, *Pbuf = nullptr, *Dinv = nullptr, *W = nullptr,
+         *T = nullptr, *Kinv = nullptr, *y = nullptr, *v = nullptr, *alpha = nullptr, *gpart = nullptr,
+         *scal = nullptr, *grad = nullptr;
+  int *info = nullptr;
+  int n_gparts = 0;
+};
+
+using namespace gpemu;
+#define GP_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != GPEMU_OK) return rc__; \
+  } while (0)
+
+static int kind_of(int kernel_kind, double nu) {
+  if (kernel_kind == GPEMU_KERNEL_RBF) return 0;
+  return nu == 0.5 ? 1 : (nu == 1.5 ? 2 : 3);
+}
+
+// K, Cholesky, W, alpha, lml terms for (theta, y); optional K^-1 + gradient
+static int fit_eval(gpemu_fit *f, const double *y, const double *theta, int64_t n_theta, bool want_grad,
+                    double *lml, double *grad) {
+  const int64_t N = f->N, Np = f->Np, d = f->d;
+  const int nth = (int)(d + f->has_const + f->has_noise);
+  GP_ARG(n_theta == nth, "n_theta must be d (+1 constant) (+1 noise)");
+  hipStream_t st = f->stream;
+  double hp[DPAD + 2];
+  for (int i = 0; i < DPAD; ++i) hp[i] = i < d ? std::exp(theta[i]) : 1.0;
+  hp[DPAD] = f->has_const ? std::exp(theta[d]) : 0.0;
+  hp[DPAD + 1] = f->has_noise ? std::exp(theta[d + f->has_const]) : 0.0;
+  std::vector<double> hy((size_t)Np, 0.0);
+  for (int64_t i = 0; i < N; ++i) hy[i] = y[i];
+  GP_HIP(hipMemcpyAsync(f->hp, hp, sizeof(hp), hipMemcpyHostToDevice, st));
+  GP_HIP(hipMemcpyAsync(f->y, hy.data(), sizeof(double) * Np, hipMemcpyHostToDevice, st));
+  GP_HIP(hipMemsetAsync(f->info, 0, sizeof(int), st));
+  hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)Np), dim3(256), 0, st, f->X, f->hp,
+                     f->K, (int)N, (int)Np, f->kind, f->jitter);
+  GP_HIP(hipGetLastError());
+  GP_TRY(device_cholesky_blocked(f->K, Np, f->Dinv, f->Pbuf, f->info, st));
+  GP_TRY(device_trtri_blocked(f->K, Np, f->Dinv, f->W, f->T, st));
+  // alpha = W^T (W y)
+  hipLaunchKernelGGL(gemv_kernel, dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, st, f->W, Np, f->y, f->v, (int)Np, 0);
+  hipLaunchKernelGGL(gemv_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, f->W, Np, f->v, f->alpha, (int)Np, 1);
+  hipLaunchKernelGGL(lml_terms_kernel, dim3(1), dim3(1024), 0, st, f->y, f->alpha, f->K, Np, (int)N, f->scal);
+  GP_HIP(hipGetLastError());
+  if (want_grad) {
+    GemmArgs g;  // K^-1 = W^T W
+    g.A = f->W; g.lda = Np; g.B = f->W; g.ldb = Np; g.C = f->Kinv; g.ldc = Np;
+    g.M = (int)Np; g.N = (int)Np; g.K = (int)Np;
+    GP_TRY(launch_gemm(g, true, true, 1, st));
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)N);
+    hipLaunchKernelGGL(lml_grad_kernel, grid, dim3(256), 0, st, f->X, f->hp, f->alpha, f->Kinv, Np, f->gpart, (int)N,
+                       (int)d, f->kind, f->has_const, f->has_noise);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(1), dim3(1024), 0, st, f->gpart, (int)(grid.x * grid.y), f->grad, nth);
+    GP_HIP(hipGetLastError());
+  }
+  double hs[2];
+  double hg[NTH_MAX];
+  int info = 0;
+  GP_HIP(hipMemcpyAsync(hs, f->scal, sizeof(hs), hipMemcpyDeviceToHost, st));
+  GP_HIP(hipMemcpyAsync(&info, f->info, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (want_grad) GP_HIP(hipMemcpyAsync(hg, f->grad, sizeof(double) * nth, hipMemcpyDeviceToHost, st));
+  GP_HIP(hipStreamSynchronize(st));
+  if (info != 0) {
+    set_error("kernel matrix is not positive definite (pivot %d): the kernel is not returning a positive "
+              "definite matrix; try increasing alpha", info);
+    return info;   // sklearn raises LinAlgError here (skl _gpr.py:350-358)
+  }
+  if (lml) *lml = -0.5 * hs[0] - hs[1] - 0.5 * (double)N * std::log(2.0 * M_PI);
+  if (want_grad && grad)
+    for (int t = 0; t < nth; ++t) grad[t] = hg[t];
+  return GPEMU_OK;
+}
+
+extern "C" {
+
+int gpemu_fit_create(gpemu_fit **out, int device, int64_t N, int64_t d, const double *X, int kernel_kind,
+                     double nu, int has_const, int has_noise, double jitter) {
+  GP_ARG(out && X, "null pointer");
+  *out = nullptr;
+  GP_ARG(N > 0 && d > 0 && d <= DPAD, "N > 0 and 0 < d <= 8 required");
+  GP_ARG(kernel_kind == GPEMU_KERNEL_RBF || kernel_kind == GPEMU_KERNEL_MATERN, "kernel_kind");
+  if (kernel_kind == GPEMU_KERNEL_MATERN) GP_ARG(nu == 0.5 || nu == 1.5 || nu == 2.5, "Matern nu must be 0.5, 1.5 or 2.5");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("no HIP device available: libgpemu has no CPU implementation");
+    return GPEMU_ERR_NO_DEVICE;
+  }
+  GP_ARG(device >= 0 && device < ndev, "device");
+  GP_HIP(hipSetDevice(device));
+  gpemu_fit *f = new gpemu_fit();
+  f->device = device; f->N = N; f->d = d; f->Np = round_up(N, NB);
+  f->kind = kind_of(kernel_kind, nu); f->has_const = has_const ? 1 : 0; f->has_noise = has_noise ? 1 : 0;
+  f->jitter = jitter;
+  const int64_t Np = f->Np;
+  f->n_gparts = (int)(((N + 255) / 256) * N);
+  hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
+  auto A = [&](double **p, int64_t n) { if (e == hipSuccess) e = hipMalloc((void **)p, sizeof(double) * (size_t)(n > 0 ? n : 1)); };
+  A(&f->X, Np * DPAD); A(&f->hp, DPAD + 2); A(&f->K, Np * Np); A(&f->Pbuf, Np * NB); A(&f->Dinv, Np * NB);
+  A(&f->W, Np * Np); A(&f->T, NB * Np); A(&f->Kinv, Np * Np); A(&f->y, Np); A(&f->v, Np); A(&f->alpha, Np);
+  A(&f->gpart, (int64_t)f->n_gparts * NTH_MAX); A(&f->scal, 4); A(&f->grad, NTH_MAX);
+  if (e == hipSuccess) e = hipMalloc((void **)&f->info, sizeof(int));
+  std::vector<double> hX((size_t)(Np * DPAD), 0.0);
+  for (int64_t i = 0; i < N; ++i)
+    for (int64_t dd = 0; dd < d; ++dd) hX[i * DPAD + dd] = X[i * d + dd];
+  if (e == hipSuccess) e = hipMemcpy(f->X, hX.data(), sizeof(double) * hX.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    set_error("fit_create: %s", hipGetErrorString(e));
+    gpemu_fit_destroy(f);
+    return GPEMU_ERR_HIP;
+  }
+  *out = f;
+  return GPEMU_OK;
+}
+
+int gpemu_fit_destroy(gpemu_fit *f) {
+  if (!f) return GPEMU_OK;
+  (void)hipSetDevice(f->device);
+  if (f->stream) (void)hipStreamSynchronize(f->stream);
+  double *ptrs[] = {f->X, f->hp, f->K, f->Pbuf, f->Dinv, f->W, f->T, f->Kinv, f->y, f->v, f->alpha, f->gpart, f->scal, f->grad};
+  for (double *p : ptrs) (void)hipFree(p);
+  (void)hipFree(f->info);
+  if (f->stream) (void)hipStreamDestroy(f->stream);
+  delete f;
+  return GPEMU_OK;
+}
+
+int gpemu_fit_lml(gpemu_fit *f, const double *y, const double *theta, int64_t n_theta, double *lml, double *grad) {
+  GP_ARG(f && y && theta && lml, "null pointer");
+  GP_HIP(hipSetDevice(f->device));
+  return fit_eval(f, y, theta, n_theta, grad != nullptr, lml, grad);
+}
+
+int gpemu_fit_factor(gpemu_fit *f, const double *y, const double *theta, int64_t n_theta, double *L_out,
+                     double *alpha_out, double *lml) {
+  GP_ARG(f && y && theta, "null pointer");
+  GP_HIP(hipSetDevice(f->device));
+  double l = 0.0;
+  GP_TRY(fit_eval(f, y, theta, n_theta, false, &l, nullptr));
+  if (lml) *lml = l;
+  const int64_t N = f->N, Np = f->Np;
+  if (alpha_out) GP_HIP(hipMemcpy(alpha_out, f->alpha, sizeof(double) * N, hipMemcpyDeviceToHost));
+  if (L_out) {
+    GP_HIP(hipMemcpy2D(L_out, sizeof(double) * N, f->K, sizeof(double) * Np, sizeof(double) * N, (size_t)N, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < N; ++i)
+      for (int64_t j = i + 1; j < N; ++j) L_out[i * N + j] = 0.0;   // only the lower triangle is the factor
+  }
+  return GPEMU_OK;
+}
+
+int gpemu_kernel_matrix(int device, int64_t N, int64_t d, const double *X, const double *theta, int64_t n_theta,
+                        int kernel_kind, double nu, int has_const, int has_noise, double jitter, double *K_out) {
+  GP_ARG(X && theta && K_out, "null pointer");
+  gpemu_fit *f = nullptr;
+  GP_TRY(gpemu_fit_create(&f, device, N, d, X, kernel_kind, nu, has_const, has_noise, jitter));
+  int rc = GPEMU_OK;
+  const int nth = (int)(d + f->has_const + f->has_noise);
+  if (n_theta != nth) { set_error("bad argument: n_theta"); rc = GPEMU_ERR_ARG; }
+  if (rc == GPEMU_OK) {
+    double hp[DPAD + 2];
+    for (int i = 0; i < DPAD; ++i) hp[i] = i < d ? std::exp(theta[i]) : 1.0;
+    hp[DPAD] = f->has_const ? std::exp(theta[d]) : 0.0;
+    hp[DPAD + 1] = f->has_noise ? std::exp(theta[d + f->has_const]) : 0.0;
+    hipError_t e = hipMemcpy(f->hp, hp, sizeof(hp), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)((f->Np + 255) / 256), (unsigned)f->Np), dim3(256), 0, f->stream,
+                       f->X, f->hp, f->K, (int)N, (int)f->Np, f->kind, jitter);
+    if (e == hipSuccess) e = hipStreamSynchronize(f->stream);
+    if (e == hipSuccess)
+      e = hipMemcpy2D(K_out, sizeof(double) * N, f->K, sizeof(double) * f->Np, sizeof(double) * N, (size_t)N, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error("kernel_matrix: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
+  }
+  gpemu_fit_destroy(f);
+  return rc;
+}
+
+int gpemu_cholesky(int device, int64_t N, double *A_inout) {
+  GP_ARG(A_inout && N > 0, "A / N");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("no HIP device available: libgpemu has no CPU implementation");
+    return GPEMU_ERR_NO_DEVICE;
+  }
+  GP_ARG(device >= 0 && device < ndev, "device");
+  GP_HIP(hipSetDevice(device));
+  const int64_t Np = round_up(N, NB);
+  double *A = nullptr, *Dinv = nullptr, *P = nullptr;
+  int *dinfo = nullptr;
+  hipError_t e = hipMalloc((void **)&A, sizeof(double) * Np * Np);
+  if (e == hipSuccess) e = hipMalloc((void **)&Dinv, sizeof(double) * Np * NB);
+  if (e == hipSuccess) e = hipMalloc((void **)&P, sizeof(double) * Np * NB);
+  if (e == hipSuccess) e = hipMalloc((void **)&dinfo, sizeof(int));
+  std::vector<double> h((size_t)(Np * Np), 0.0);
+  for (int64_t i = 0; i < Np; ++i)
+    for (int64_t j = 0; j <= i; ++j) h[i * Np + j] = (i < N && j < N) ? A_inout[i * N + j] : (i == j ? 1.0 : 0.0);
+  int rc = GPEMU_OK, info = 0;
+  if (e == hipSuccess) e = hipMemcpy(A, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(dinfo, 0, sizeof(int));
+  if (e == hipSuccess) rc = device_cholesky_blocked(A, Np, Dinv, P, dinfo, nullptr);
+  if (e == hipSuccess && rc == GPEMU_OK) e = hipDeviceSynchronize();
+  if (e == hipSuccess && rc == GPEMU_OK) e = hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && rc == GPEMU_OK) e = hipMemcpy(h.data(), A, sizeof(double) * h.size(), hipMemcpyDeviceToHost);
+  (void)hipFree(A); (void)hipFree(Dinv); (void)hipFree(P); (void)hipFree(dinfo);
+  if (e != hipSuccess) { set_error("cholesky: %s", hipGetErrorString(e)); return GPEMU_ERR_HIP; }
+  if (rc != GPEMU_OK) return rc;
+  if (info != 0) { set_error("matrix is not positive definite (pivot %d)", info); return info; }
+  for (int64_t i = 0; i < N; ++i)
+    for (int64_t j = 0; j < N; ++j) A_inout[i * N + j] = (j <= i) ? h[i * Np + j] : 0.0;
+  return GPEMU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// General fp64 GEMM on the matrix cores (v_mfma_f64_16x16x4_f64), the workhorse of the fit side:
+// Cholesky trailing updates (SYRK), panel solves, triangular inverse, K^-1 = W^T W.
+//
+//   C[M x N] = alpha * op(A)[M x K] * op(B)[K x N] + beta * C          (row-major, leading dims)
+//
+// Operand layouts are template flags so that every caller reads memory the way it lies:
+//   A_KMAJOR: A is stored [k][m] (i.e. op(A) = A^T of a row-major K x M array), else [m][k]
+//   B_KMAJOR: B is stored [k][n], else [n][k] (op(B) = B^T of a row-major N x K array)
+// All of M, N must be multiples of 64 and K a multiple of 32 (callers pad; the fit workspace is
+// padded to 64 with an identity tail).  Tile 64 x 64, 256 threads = 4 waves (2 x 2, 32 x 32 each),
+// K step 32, LDS double buffered.  `lower_only` skips tiles strictly above the diagonal (SYRK).
+#include "internal.h"
+#include "gemm.h"
+
+namespace gpemu {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int GT = 64;      // tile edge
+constexpr int GK = 32;      // K step
+constexpr int GSK = 80;     // LDS stride of a k-major tile  [32][80]   ((2*80) % 64 == 32)
+constexpr int GSM = 34;     // LDS stride of an m-major tile [64][34]   (rows 4 banks apart)
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double sA[2][GK * GSK];   // either layout fits: 2560 doubles
+  __shared__ __attribute__((aligned(16))) double sB[2][GK * GSK];
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  if (g.lower_only && n0 > m0) return;
+  const double *A = g.A + (int64_t)blockIdx.z * g.strideA;
+  const double *B = g.B + (int64_t)blockIdx.z * g.strideB;
+  double *C = g.C + (int64_t)blockIdx.z * g.strideC;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+
+  // staging: each operand tile is 64 x 32 doubles = 1024 x 16 B -> 4 per thread
+  //   k-major source [k][m]: 32 rows of 64 doubles  -> idx = tid + 256 r: row = idx >> 5, c2 = idx & 31
+  //   m-major source [m][k]: 64 rows of 32 doubles  -> idx = tid + 256 r: row = idx >> 4, c2 = idx & 15
+  d2 ra[4], rb[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = tid + 256 * r;
+      if (A_KMAJOR) ra[r] = *reinterpret_cast<const d2 *>(A + (int64_t)(kt * GK + (idx >> 5)) * g.lda + m0 + 2 * (idx & 31));
+      else ra[r] = *reinterpret_cast<const d2 *>(A + (int64_t)(m0 + (idx >> 4)) * g.lda + kt * GK + 2 * (idx & 15));
+      if (B_KMAJOR) rb[r] = *reinterpret_cast<const d2 *>(B + (int64_t)(kt * GK + (idx >> 5)) * g.ldb + n0 + 2 * (idx & 31));
+      else rb[r] = *reinterpret_cast<const d2 *>(B + (int64_t)(n0 + (idx >> 4)) * g.ldb + kt * GK + 2 * (idx & 15));
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = tid + 256 * r;
+      if (A_KMAJOR) *reinterpret_cast<d2 *>(&sA[buf][(idx >> 5) * GSK + 2 * (idx & 31)]) = ra[r];
+      else *reinterpret_cast<d2 *>(&sA[buf][(idx >> 4) * GSM + 2 * (idx & 15)]) = ra[r];
+      if (B_KMAJOR) *reinterpret_cast<d2 *>(&sB[buf][(idx >> 5) * GSK + 2 * (idx & 31)]) = rb[r];
+      else *reinterpret_cast<d2 *>(&sB[buf][(idx >> 4) * GSM + 2 * (idx & 15)]) = rb[r];
+    }
+  };
+
+  d4 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+
+  const int nk = g.K / GK;
+  if (nk > 0) {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < GK / 4; ++ks) {
+      double a[2], b[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int m = wm * 32 + mi * 16 + lr, kk = ks * 4 + lk;
+        a[mi] = A_KMAJOR ? sA[buf][kk * GSK + m] : sA[buf][m * GSM + kk];
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = wn * 32 + ni * 16 + lr, kk = ks * 4 + lk;
+        b[ni] = B_KMAJOR ? sB[buf][kk * GSK + n] : sB[buf][n * GSM + kk];
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (kt + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  // D[reg] is row (lane >> 4) + 4 * reg, column lane & 15 of each 16 x 16 tile
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 32 + mi * 16 + lk + 4 * r;
+        const int col = n0 + wn * 32 + ni * 16 + lr;
+        double *c = C + (int64_t)row * g.ldc + col;
+        const double v = g.alpha * acc[mi][ni][r];
+        *c = (g.beta == 0.0) ? v : fma(g.beta, *c, v);
+      }
+}
+
+int launch_gemm(const GemmArgs &g, bool a_kmajor, bool b_kmajor, int batch, hipStream_t st) {
+  if (g.M % GT || g.N % GT || g.K % GK) {
+    set_error("gemm: M, N must be multiples of 64 and K of 32 (got %d %d %d)", g.M, g.N, g.K);
+    return GPEMU_ERR_ARG;
+  }
+  if (g.M == 0 || g.N == 0) return GPEMU_OK;
+  dim3 grid((unsigned)(g.N / GT), (unsigned)(g.M / GT), (unsigned)batch), block(256);
+  if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, 0, st, g);
+  else if (a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, 0, st, g);
+  else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, 0, st, g);
+  else hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, st, g);
+  GP_HIP(hipGetLastError());
+  return GPEMU_OK;
+}
+
+}  // namespace gpemu

@@ -49,6 +49,15 @@ _SIGNATURES = {
     "gpemu_likelihood_setup": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_double, c_i64, C.c_void_p]),
     "gpemu_logpost": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_int]),
     "gpemu_logpost_dev": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "gpemu_fit_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, c_i64, c_i64, C.c_void_p, C.c_int, C.c_double,
+                                   C.c_int, C.c_int, C.c_double]),
+    "gpemu_fit_destroy": (C.c_int, [C.c_void_p]),
+    "gpemu_fit_lml": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.POINTER(C.c_double), C.c_void_p]),
+    "gpemu_fit_factor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_void_p,
+                                   C.POINTER(C.c_double)]),
+    "gpemu_kernel_matrix": (C.c_int, [C.c_int, c_i64, c_i64, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_double,
+                                      C.c_int, C.c_int, C.c_double, C.c_void_p]),
+    "gpemu_cholesky": (C.c_int, [C.c_int, c_i64, C.c_void_p]),
     "gpemu_sampler_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, c_i64,
                                        C.c_double, C.c_uint64]),
     "gpemu_sampler_destroy": (C.c_int, [C.c_void_p]),

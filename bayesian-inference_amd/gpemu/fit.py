@@ -1,0 +1,88 @@
+"""DeviceFit: the GP log-marginal likelihood / gradient / factorisation on the device (libgpemu
+``gpemu_fit_*``), plus thin wrappers of the stand-alone kernel-matrix and Cholesky entry points."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_f64, check, ptr
+
+
+class LinAlgError(np.linalg.LinAlgError):
+    pass
+
+
+class DeviceFit:
+    """Workspace for fitting GPs on one design matrix ``X`` (N x d) with a fixed kernel structure.
+
+    theta follows sklearn: log([l_1..l_d, (constant_value), (noise_level)]) (skl kernels.py:733-760).
+    """
+
+    def __init__(self, X, kernel_kind=0, nu=np.inf, has_const=False, has_noise=False, jitter=1e-10, device=0):
+        _lib.require_device()
+        X = as_f64(X)
+        self.N, self.d = X.shape
+        self.n_theta = self.d + int(has_const) + int(has_noise)
+        h = C.c_void_p()
+        check(_lib.lib().gpemu_fit_create(C.byref(h), int(device), self.N, self.d, ptr(X), int(kernel_kind),
+                                          float(nu) if np.isfinite(nu) else 0.0, int(has_const), int(has_noise),
+                                          float(jitter)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().gpemu_fit_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc > 0:
+            raise LinAlgError(_lib.lib().gpemu_last_error().decode())
+        check(rc)
+
+    def lml(self, y, theta, eval_gradient=True):
+        y = as_f64(y, (self.N,))
+        theta = as_f64(theta, (self.n_theta,))
+        val = C.c_double()
+        grad = np.empty(self.n_theta) if eval_gradient else None
+        self._check(_lib.lib().gpemu_fit_lml(self._h, ptr(y), ptr(theta), self.n_theta, C.byref(val), ptr(grad)))
+        return (val.value, grad) if eval_gradient else val.value
+
+    def factor(self, y, theta):
+        """(L_ (N,N) lower, alpha_ (N,), lml) at theta (skl _gpr.py:346-364)."""
+        y = as_f64(y, (self.N,))
+        theta = as_f64(theta, (self.n_theta,))
+        L = np.empty((self.N, self.N))
+        alpha = np.empty(self.N)
+        val = C.c_double()
+        self._check(_lib.lib().gpemu_fit_factor(self._h, ptr(y), ptr(theta), self.n_theta, ptr(L), ptr(alpha),
+                                                C.byref(val)))
+        return L, alpha, val.value
+
+
+def kernel_matrix(X, theta, kernel_kind=0, nu=np.inf, has_const=False, has_noise=False, jitter=0.0, device=0):
+    X = as_f64(X)
+    N, d = X.shape
+    theta = as_f64(theta)
+    K = np.empty((N, N))
+    check(_lib.lib().gpemu_kernel_matrix(int(device), N, d, ptr(X), ptr(theta), theta.size, int(kernel_kind),
+                                         float(nu) if np.isfinite(nu) else 0.0, int(has_const), int(has_noise),
+                                         float(jitter), ptr(K)))
+    return K
+
+
+def cholesky(A, device=0):
+    """Lower Cholesky factor on the device (scipy.linalg.cholesky(A, lower=True))."""
+    A = np.array(A, dtype=np.float64, order="C")
+    rc = _lib.lib().gpemu_cholesky(int(device), A.shape[0], ptr(A))
+    if rc > 0:
+        raise LinAlgError(_lib.lib().gpemu_last_error().decode())
+    check(rc)
+    return A

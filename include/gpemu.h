@@ -47,6 +47,7 @@ extern "C" {
 
 typedef struct gpemu_model gpemu_model;     /* one emulation group on one device */
 typedef struct gpemu_sampler gpemu_sampler; /* stretch-move ensemble over >= 1 groups */
+typedef struct gpemu_fit gpemu_fit;         /* GP fit workspace for one design matrix */
 
 /* ---- library / device ------------------------------------------------------------------- */
 const char *gpemu_version(void);
@@ -112,6 +113,32 @@ int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_
 int gpemu_logpost(gpemu_model *m, int64_t B, const double *X, double *out, int mode);
 int gpemu_logpost_dev(gpemu_model *m, int64_t B, const double *dX, double *dout, int mode,
                       void *stream);
+
+/* ---- GP fit: kernel matrix, Cholesky, log-marginal likelihood + gradient -------------------------
+ * Replaces the arithmetic inside ref: emulation.py:169-172 (GaussianProcessRegressor(...).fit):
+ * skl _gpr.py:537-652 log_marginal_likelihood(theta, eval_gradient=True) and :346-364 (final L_,
+ * alpha_).  theta = log([l_1..l_d, (constant_value), (noise_level)]) in sklearn's order
+ * (skl kernels.py:733-760, 861-866); jitter = GaussianProcessRegressor(alpha=...).  The optimiser
+ * (L-BFGS-B + restarts, skl _gpr.py:299-337) stays on the host and calls gpemu_fit_lml.
+ * A non-positive-definite kernel matrix returns > 0 (index + 1 of the failing pivot); sklearn
+ * raises LinAlgError there (skl _gpr.py:350-358).
+ */
+int gpemu_fit_create(gpemu_fit **out, int device, int64_t N, int64_t d, const double *X,
+                     int kernel_kind, double nu, int has_const, int has_noise, double jitter);
+int gpemu_fit_destroy(gpemu_fit *f);
+/* lml and, if grad != NULL, d lml / d theta [n_theta] for target y[N] */
+int gpemu_fit_lml(gpemu_fit *f, const double *y, const double *theta, int64_t n_theta, double *lml,
+                  double *grad);
+/* L_out[N*N] (lower, zeros above), alpha_out[N], lml at theta; any output may be NULL */
+int gpemu_fit_factor(gpemu_fit *f, const double *y, const double *theta, int64_t n_theta,
+                     double *L_out, double *alpha_out, double *lml);
+/* K_out[N*N] = kernel_(X) (+ jitter on the diagonal): skl kernels.py:1553-1582, 1708-1781 */
+int gpemu_kernel_matrix(int device, int64_t N, int64_t d, const double *X, const double *theta,
+                        int64_t n_theta, int kernel_kind, double nu, int has_const, int has_noise,
+                        double jitter, double *K_out);
+/* in-place lower Cholesky of a symmetric positive definite N x N matrix (scipy.linalg.cholesky
+ * (lower=True), skl _gpr.py:349): blocked, MFMA f64 SYRK trailing updates */
+int gpemu_cholesky(int device, int64_t N, double *A_inout);
 
 /* ---- stretch-move ensemble sampler ------------------------------------------------------------
  * Replaces ref: mcmc.py:77-107, 187-204: emcee.EnsembleSampler(n_walkers, ndim, log_posterior,

@@ -1,0 +1,89 @@
+"""-m gpu parity tests of the fit side: kernel matrix, blocked Cholesky, log-marginal likelihood and
+gradient at identical theta against the goldens (reference run) and the CPU oracle."""
+import numpy as np
+import pytest
+
+import golden_util as GU
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+SYN = ["g1_rbf_noise", "g1_matern15_noise", "g1_matern25_const_noise", "g1_rbf_only", "g2_rbf_noise"]
+
+
+def relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _fit_for(g, design=None):
+    from gpemu.fit import DeviceFit
+    spec = GU.spec_of(g)
+    X = g["design"] if design is None else design
+    return DeviceFit(X, kernel_kind=spec.kind, nu=spec.nu, has_const=spec.has_const, has_noise=spec.has_noise,
+                     jitter=float(g["gpr_alpha"])), spec, X
+
+
+@pytest.mark.parametrize("name", SYN)
+def test_kernel_matrix_and_cholesky(name):
+    from gpemu.fit import cholesky, kernel_matrix
+    g = GU.load(name)
+    spec = GU.spec_of(g)
+    X = g["design"]
+    th = g["theta"][0]
+    ls, c, nz = O.split_theta(th, X.shape[1], spec)
+    Kref = O.kernel_train(X, ls, spec, c, nz)
+    K = kernel_matrix(X, th, spec.kind, spec.nu, spec.has_const, spec.has_noise, jitter=0.0)
+    assert relerr(K, Kref) < 1e-13
+    Kj = Kref + float(g["gpr_alpha"]) * np.eye(X.shape[0])
+    L = cholesky(Kj)
+    assert np.allclose(np.triu(L, 1), 0.0)
+    j = list(g["L_index"]).index(0)
+    assert relerr(L, g["L"][j]) < 1e-8          # sklearn's L_ for PC 0 (same theta)
+
+
+@pytest.mark.parametrize("name", SYN + ["g3_realdata_matern15"])
+def test_lml_grad_factor_at_golden_theta(name):
+    g = GU.load(name)
+    design = GU.load("observables_fixture")["design"] if name.startswith("g3") else None
+    fit, spec, X = _fit_for(g, design)
+    ytr = g["Y_pca_truncated"]
+    cond_loose = not spec.has_noise          # cond(K) ~ 1e9 without a noise term
+    for i in range(int(g["n_pc"])):
+        for th, lk, gk in ((g["theta"][i], "lml_at_theta", "grad_at_theta"),
+                           (g["theta2"][i], "lml_at_theta2", "grad_at_theta2")):
+            lml, grad = fit.lml(ytr[:, i], th)
+            assert abs(lml - g[lk][i]) <= (1e-6 if cond_loose else 1e-8) * max(1.0, abs(g[lk][i]))
+            scale = max(1.0, np.max(np.abs(g[gk][i])))
+            assert np.max(np.abs(grad - g[gk][i])) <= (1e-4 if cond_loose else 1e-6) * scale
+    for j, i in enumerate(g["L_index"]):
+        L, alpha, lml = fit.factor(ytr[:, i], g["theta"][i])
+        assert relerr(L, g["L"][j]) < 1e-8
+        assert relerr(alpha, g["alpha"][i]) < (1e-4 if cond_loose else 1e-7)
+        assert abs(lml - g["lml_value"][i]) <= 1e-6 * max(1.0, abs(g["lml_value"][i]))
+    fit.close()
+
+
+def test_not_positive_definite_raises():
+    from gpemu.fit import LinAlgError, cholesky
+    A = np.eye(70)
+    A[5, 5] = -1.0
+    with pytest.raises(LinAlgError):
+        cholesky(A)
+
+
+def test_c3_size_fit_matches_oracle():
+    """N = 1000 (BASELINE config 3): device lml/grad/factor vs the oracle at the fixed theta."""
+    from gpemu.fit import DeviceFit
+    model, prob, pca = GU.fixed_theta_model(1000, 500, 2, seed=0)
+    X = prob["design"]
+    theta = np.log(np.r_[model.gps[0].ls, model.gps[0].noise])
+    fit = DeviceFit(X, kernel_kind=0, has_noise=True, jitter=1e-10)
+    y = pca["Y_pca"][:, 0]
+    lml, grad = fit.lml(y, theta)
+    lo, go = O.lml_and_grad(X, y, theta, model.spec)
+    assert abs(lml - lo) <= 1e-8 * abs(lo)
+    assert np.max(np.abs(grad - go)) <= 1e-6 * max(1.0, np.max(np.abs(go)))
+    L, alpha, _ = fit.factor(y, theta)
+    assert relerr(L, model.gps[0].L) < 1e-9
+    assert relerr(alpha, model.gps[0].alpha) < 1e-7
+    fit.close()
