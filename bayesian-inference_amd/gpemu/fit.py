@@ -86,3 +86,22 @@ def cholesky(A, device=0):
         raise LinAlgError(_lib.lib().gpemu_last_error().decode())
     check(rc)
     return A
+
+
+def pca_fit(Y, n_components=None, device=0):
+    """StandardScaler + full PCA on the device.  Returns a dict with scaler_mean/scale/var, pca_mean,
+    components (nc,F), explained_variance(_ratio) (nc,), Y_pca (N,nc), flip_argmax (nc,), n_sweeps."""
+    _lib.require_device()
+    Y = as_f64(Y)
+    N, F = Y.shape
+    nc = min(N, F) if n_components is None else int(n_components)
+    out = dict(scaler_mean=np.empty(F), scaler_scale=np.empty(F), scaler_var=np.empty(F), pca_mean=np.empty(F),
+               components=np.empty((nc, F)), explained_variance=np.empty(nc), explained_variance_ratio=np.empty(nc),
+               Y_pca=np.empty((N, nc)), flip_argmax=np.empty(nc, dtype=np.int64))
+    ns = np.zeros(1, dtype=np.int64)
+    check(_lib.lib().gpemu_pca_fit(int(device), N, F, ptr(Y), nc, ptr(out["scaler_mean"]), ptr(out["scaler_scale"]),
+                                   ptr(out["scaler_var"]), ptr(out["pca_mean"]), ptr(out["components"]),
+                                   ptr(out["explained_variance"]), ptr(out["explained_variance_ratio"]),
+                                   ptr(out["Y_pca"]), ptr(out["flip_argmax"]), ptr(ns)))
+    out["n_sweeps"] = int(ns[0])
+    return out

@@ -140,6 +140,18 @@ int gpemu_kernel_matrix(int device, int64_t N, int64_t d, const double *X, const
  * (lower=True), skl _gpr.py:349): blocked, MFMA f64 SYRK trailing updates */
 int gpemu_cholesky(int device, int64_t N, double *A_inout);
 
+/* ---- StandardScaler + PCA ---------------------------------------------------------------------
+ * Replaces ref: emulation.py:109-118: scaler.fit_transform(Y) followed by
+ * PCA(n_components, svd_solver='full').fit_transform (skl preprocessing/_data.py:1015-1051,
+ * decomposition/_pca.py:544-702, svd_flip utils/extmath.py:944-952).  Y[N*F] row-major.
+ * n_components <= 0 means min(N, F).  Outputs: scaler mean_/scale_/var_ [F], pca mean_ [F],
+ * components_ [nc*F], explained_variance_ / _ratio_ [nc], Y_pca [N*nc] (= U S), flip_argmax [nc]
+ * (index of the max-|.| entry of each component row: the svd_flip sign decision), n_sweeps. */
+int gpemu_pca_fit(int device, int64_t N, int64_t F, const double *Y, int64_t n_components,
+                  double *scaler_mean, double *scaler_scale, double *scaler_var, double *pca_mean,
+                  double *components, double *explained_variance, double *explained_variance_ratio,
+                  double *Y_pca, int64_t *flip_argmax, int64_t *n_sweeps);
+
 /* ---- stretch-move ensemble sampler ------------------------------------------------------------
  * Replaces ref: mcmc.py:77-107, 187-204: emcee.EnsembleSampler(n_walkers, ndim, log_posterior,
  * pool=Pool()) with its default StretchMove(a=2) and the pool.map over walkers.  The ensemble,

@@ -87,3 +87,32 @@ def test_c3_size_fit_matches_oracle():
     assert relerr(L, model.gps[0].L) < 1e-9
     assert relerr(alpha, model.gps[0].alpha) < 1e-7
     fit.close()
+
+
+@pytest.mark.parametrize("name", SYN + ["g3_realdata_matern15"])
+def test_scaler_pca_vs_reference(name):
+    """StandardScaler + PCA (device Jacobi SVD) against the reference's sklearn objects: the sign-decision
+    indices bit-exact, scaler statistics to the last bits, leading components / scores / variances to 1e-9,
+    and the full-rank physical-space quantity (covariance of the truncated components) to 1e-9."""
+    from gpemu.fit import pca_fit
+    g = GU.load(name)
+    Y = GU.load("observables_fixture")["Y"] if name.startswith("g3") else g["Y"]
+    k = int(g["n_pc"])
+    out = pca_fit(Y)
+    np.testing.assert_allclose(out["scaler_mean"], g["scaler_mean"], rtol=1e-15, atol=0)
+    np.testing.assert_allclose(out["scaler_var"], g["scaler_var"], rtol=1e-13, atol=0)
+    np.testing.assert_allclose(out["scaler_scale"], g["scaler_scale"], rtol=1e-14, atol=0)
+    assert np.array_equal(out["flip_argmax"][:k], g["flip_argmax"][:k])          # integer decisions: exact
+    nall = g["pca_explained_variance"].shape[0]
+    ev_scale = g["pca_explained_variance"][0]
+    assert np.max(np.abs(out["explained_variance"][:nall] - g["pca_explained_variance"])) < 1e-12 * ev_scale
+    assert relerr(out["explained_variance_ratio"][:k], g["pca_explained_variance_ratio"][:k]) < 1e-11
+    assert relerr(out["components"][:k], g["pca_components"][:k]) < 1e-9
+    assert relerr(out["Y_pca"][:, :k], g["Y_pca_truncated"]) < 1e-9
+    # truncation covariance S_{>k} diag(ev_{>k}) S_{>k}^T (ref: emulation.py:246-249)
+    cu = (out["components"][k:].T * out["explained_variance"][k:]) @ out["components"][k:]
+    assert relerr(cu, g["cov_unexplained"]) < 1e-9
+    # n_components truncation returns the leading block
+    out5 = pca_fit(Y, n_components=k)
+    np.testing.assert_array_equal(out5["components"], out["components"][:k])
+    assert 2 <= out["n_sweeps"] <= 30
