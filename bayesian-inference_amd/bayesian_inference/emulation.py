@@ -1,0 +1,428 @@
+"""Drop-in replacement of ``bayesian_inference.emulation`` with the arithmetic on an MI355X.
+
+Same public names, arguments and return shapes as the reference module
+(ref: src/bayesian_inference/emulation.py): ``fit_emulators``, ``fit_emulator_group``,
+``read_emulators``, ``write_emulators``, ``compute_emulator_cov_unexplained``,
+``compute_emulator_group_cov_unexplained``, ``nd_block_diag``, ``SortEmulationGroupObservables``,
+``predict``, ``predict_emulation_group``, ``EmulationGroupConfig``, ``EmulationConfig``.
+
+What runs where
+  * standardise + PCA, GP fit (kernel matrix, Cholesky, LML + gradient), GP predict, the
+    back-projection and the covariance assembly run in libgpemu (HIP, gfx950) via ``gpemu``;
+  * configuration parsing, HDF5 / pickle I/O and the observable bookkeeping are host Python, as in
+    the reference.  ``data_IO`` is imported lazily from the reference package (it is untouched).
+The results dict has the reference's keys; the objects in it are ``gpemu.estimators`` classes
+(same attribute names as the sklearn objects, picklable without scikit-learn).
+
+Deliberate differences (results identical): ``compute_emulator_cov_unexplained`` returns the dict it
+builds (the reference forgets the ``return``, ref: emulation.py:214-224, so callers got ``None`` and
+recomputed the matrix on every predict call).
+"""
+from __future__ import annotations
+
+import logging
+import os
+import pickle
+from pathlib import Path
+from typing import Any
+
+import numpy as np
+import yaml
+
+from gpemu import estimators
+from gpemu.model import DeviceModel
+
+logger = logging.getLogger(__name__)
+
+
+def _data_IO():
+    """The reference's data_IO module (HDF5 readers; out of scope here and left untouched)."""
+    from bayesian_inference import data_IO
+    return data_IO
+
+
+####################################################################################################
+def fit_emulators(emulation_config: "EmulationConfig") -> None:
+    """PCA + GP fit for every emulation group; writes one pickle per group (ref: emulation.py:38-50)."""
+    for name, group_config in emulation_config.emulation_groups_config.items():
+        result = fit_emulator_group(group_config)
+        if result:   # an existing emulator is not overwritten (ref: emulation.py:46-48)
+            write_emulators(config=group_config, output_dict=result)
+
+
+def build_kernel(config) -> estimators.ARDKernel:
+    """Kernel prototype in the order of ``kernels.active`` (ref: emulation.py:129-162)."""
+    par = config.analysis_config['parameterization'][config.parameterization]
+    lo, hi = np.array(par['min'], dtype=np.float64), np.array(par['max'], dtype=np.float64)
+    kw: dict[str, Any] = {}
+    kind = None
+    for kernel_type, kernel_args in config.active_kernels.items():
+        if kernel_type in ("matern", "rbf"):
+            length_scale = hi - lo
+            bounds = np.outer(length_scale, tuple(kernel_args['length_scale_bounds_factor']))
+            kind = estimators.MATERN_KIND if kernel_type == "matern" else estimators.RBF_KIND
+            kw.update(length_scale=length_scale, length_scale_bounds=bounds)
+            if kernel_type == "matern":
+                kw["nu"] = kernel_args['nu']
+        elif kernel_type == "constant":
+            kw.update(constant_value=kernel_args["constant_value"],
+                      constant_value_bounds=kernel_args["constant_value_bounds"])
+        elif kernel_type == "noise":
+            kw.update(noise_level=kernel_args["args"]["noise_level"],
+                      noise_level_bounds=kernel_args["args"]["noise_level_bounds"])
+    if kind is None:
+        raise ValueError("Must provide exactly one of 'matern', 'rbf' kernel")
+    return estimators.ARDKernel(kind, **kw)
+
+
+def fit_emulator_group(config: "EmulationGroupConfig") -> dict[str, Any]:
+    """Standardise, PCA, fit one GP per retained PC (ref: emulation.py:53-192)."""
+    if os.path.exists(config.emulation_outputfile):
+        if config.force_retrain:
+            os.remove(config.emulation_outputfile)
+            logger.info(f'Removed {config.emulation_outputfile}')
+        else:
+            logger.info(f'Emulators already exist: {config.emulation_outputfile} (to force retrain, set force_retrain: True)')
+            return {}
+
+    logger.info('Doing PCA...')
+    data_IO = _data_IO()
+    Y = data_IO.predictions_matrix_from_h5(config.output_dir, filename=config.observables_filename,
+                                           observable_filter=config.observable_filter)
+    max_n_components = config.max_n_components_to_calculate
+    if max_n_components is not None:
+        logger.info(f"Running with max n_pc={max_n_components}")
+    scaler, pca, Y_pca = estimators.scale_and_pca(Y, n_components=max_n_components)
+    Y_pca_truncated = Y_pca[:, :config.n_pc]
+    Y_reconstructed_truncated = Y_pca_truncated.dot(pca.components_[:config.n_pc, :])
+    Y_reconstructed_truncated_unscaled = scaler.inverse_transform(Y_reconstructed_truncated)
+    logger.info(f'  Variance explained by first {config.n_pc} components: '
+                f'{np.sum(pca.explained_variance_ratio_[:config.n_pc])}')
+
+    design = data_IO.design_array_from_h5(config.output_dir, filename=config.observables_filename)
+    kernel = build_kernel(config)
+
+    logger.info("")
+    logger.info('Fitting GPs...')
+    logger.info(f'  The design has {design.shape[1]} parameters')
+    from gpemu.fit import DeviceFit
+    dfit = DeviceFit(design, kernel.kind, kernel.nu, kernel.has_const, kernel.has_noise, config.alpha)
+    try:
+        emulators = [estimators.GaussianProcessRegressor(kernel=kernel, alpha=config.alpha,
+                                                         n_restarts_optimizer=config.n_restarts,
+                                                         copy_X_train=False).fit(design, y, _device_fit=dfit)
+                     for y in Y_pca_truncated.T]
+    finally:
+        dfit.close()
+
+    logger.info("")
+    logger.info('Kernel hyperparameters:')
+    for emulator in emulators:
+        logger.info(f'  {emulator.kernel_}')
+    logger.info("")
+
+    output_dict: dict[str, Any] = {'PCA': {}}
+    output_dict['PCA']['Y'] = Y
+    output_dict['PCA']['Y_pca'] = Y_pca
+    output_dict['PCA']['Y_pca_truncated'] = Y_pca_truncated
+    output_dict['PCA']['Y_reconstructed_truncated'] = Y_reconstructed_truncated
+    output_dict['PCA']['Y_reconstructed_truncated_unscaled'] = Y_reconstructed_truncated_unscaled
+    output_dict['PCA']['pca'] = pca
+    output_dict['PCA']['scaler'] = scaler
+    output_dict['emulators'] = emulators
+    return output_dict
+
+
+####################################################################################################
+def read_emulators(config: "EmulationGroupConfig") -> dict[str, Any]:
+    with Path(config.emulation_outputfile).open("rb") as f:
+        return pickle.load(f)
+
+
+def write_emulators(config: "EmulationGroupConfig", output_dict: dict[str, Any]) -> None:
+    filename = Path(config.emulation_outputfile)
+    filename.parent.mkdir(parents=True, exist_ok=True)
+    with filename.open('wb') as f:
+        pickle.dump(output_dict, f)
+
+
+####################################################################################################
+def compute_emulator_cov_unexplained(emulation_config, emulation_results) -> dict[str, np.ndarray]:
+    """Truncation covariance of every group (ref: emulation.py:214-224; returned here, see module doc)."""
+    if not emulation_results:
+        emulation_results = emulation_config.read_all_emulator_groups()
+    return {name: compute_emulator_group_cov_unexplained(cfg, emulation_results.get(name))
+            for name, cfg in emulation_config.emulation_groups_config.items()}
+
+
+def compute_emulator_group_cov_unexplained(emulation_group_config, emulation_group_result) -> np.ndarray:
+    """S_{>k} diag(explained_variance_{>k}) S_{>k}^T (ref: emulation.py:227-251).  A one-off F x F
+    product at setup time, kept on the host exactly as the reference writes it."""
+    pca = emulation_group_result['PCA']['pca']
+    S_unexplained = pca.components_.T[:, emulation_group_config.n_pc:]
+    D_unexplained = np.diag(pca.explained_variance_[emulation_group_config.n_pc:])
+    return S_unexplained.dot(D_unexplained.dot(S_unexplained.T))
+
+
+####################################################################################################
+def nd_block_diag(arrays):
+    """Stack (..., r_i, c_i) blocks on the diagonal of a (..., sum r, sum c) array (ref: emulation.py:254-270)."""
+    lead = np.amax(np.array([a.shape[:-2] for a in arrays]), axis=0) if arrays[0].ndim > 2 else ()
+    rows = sum(a.shape[-2] for a in arrays)
+    cols = sum(a.shape[-1] for a in arrays)
+    out = np.zeros(tuple(lead) + (rows, cols))
+    r = c = 0
+    for a in arrays:
+        out[..., r:r + a.shape[-2], c:c + a.shape[-1]] = a
+        r += a.shape[-2]
+        c += a.shape[-1]
+    return out
+
+
+class SortEmulationGroupObservables:
+    """Mapping between the per-group matrices and the globally sorted observable order
+    (ref: emulation.py:274-406).  ``emulation_group_to_observable_matrix`` is
+    {observable: (group, slice in the merged matrix, slice in the group matrix)} in sorted order."""
+
+    def __init__(self, emulation_group_to_observable_matrix, shape):
+        self.emulation_group_to_observable_matrix = emulation_group_to_observable_matrix
+        self.shape = tuple(shape)
+        self._available_value_types = None
+
+    @classmethod
+    def learn_mapping(cls, emulation_config: "EmulationConfig") -> "SortEmulationGroupObservables":
+        data_IO = _data_IO()
+        prediction_key = "Prediction"
+        all_observables = data_IO.read_dict_from_h5(emulation_config.output_dir, 'observables.h5')
+        position = 0
+        observable_slices = {}
+        for key in data_IO.sorted_observable_list_from_dict(all_observables[prediction_key]):
+            n_bins = all_observables[prediction_key][key]['y'].shape[0]
+            observable_slices[key] = slice(position, position + n_bins)
+            position += n_bins
+        mapping = {}
+        for group_name, group_config in emulation_config.emulation_groups_config.items():
+            keys = data_IO.sorted_observable_list_from_dict(all_observables[prediction_key],
+                                                            observable_filter=group_config.observable_filter)
+            group_bin = 0
+            for key in keys:
+                sl = observable_slices[key]
+                width = sl.stop - sl.start
+                mapping[key] = (group_name, sl, slice(group_bin, group_bin + width))
+                group_bin += width
+        mapping = {k: mapping[k] for k in observable_slices}
+        last = list(observable_slices)[-1]
+        n_design = all_observables[prediction_key][last]['y'].shape[1]
+        return cls(mapping, (n_design, observable_slices[last].stop))
+
+    def group_layout(self, group_name):
+        """(columns of this group in the merged matrix, observable block starts inside the group)."""
+        entries = sorted(((sg.start, so, sg) for (g, so, sg) in self.emulation_group_to_observable_matrix.values()
+                          if g == group_name), key=lambda e: e[0])
+        cols = np.concatenate([np.arange(so.start, so.stop) for _, so, _ in entries])
+        starts = [sg.start for _, _, sg in entries] + [entries[-1][2].stop]
+        return cols, np.array(starts, dtype=np.int64)
+
+    def convert(self, group_matrices):
+        if self._available_value_types is None:
+            self._available_value_types = set(vt for group in group_matrices.values() for vt in group)
+        output = {}
+        if "cov" in self._available_value_types:
+            blocks = {}
+            for _, (group_name, slice_out, slice_group) in self.emulation_group_to_observable_matrix.items():
+                blocks[slice_out.start] = group_matrices[group_name]["cov"][:, slice_group, slice_group]
+            output["cov"] = nd_block_diag([blocks[s] for s in sorted(blocks)])
+        for value_type in self._available_value_types:
+            if value_type == "cov":
+                continue
+            out = None
+            for _, (group_name, slice_out, slice_group) in self.emulation_group_to_observable_matrix.items():
+                m = group_matrices[group_name][value_type]
+                if out is None:
+                    out = np.zeros((m.shape[0], *self.shape[1:]))
+                out[:, slice_out] = m[:, slice_group]
+            output[value_type] = out
+        return output
+
+
+####################################################################################################
+# device models are built once per results dict and reused (the reference rebuilds nothing either:
+# its sklearn objects live in the dict)
+_DEVICE_MODELS: dict[int, tuple[Any, DeviceModel, int]] = {}
+
+
+def device_model_for(results: dict[str, Any], n_pc: int, cov_unexplained: np.ndarray | None = None) -> DeviceModel:
+    """The DeviceModel (GP factors, PCA, scaler resident in HBM) of one emulation group's results dict."""
+    key = id(results)
+    hit = _DEVICE_MODELS.get(key)
+    if hit is not None and hit[0] is results and hit[2] == n_pc:
+        return hit[1]
+    emulators = results['emulators'][:n_pc]
+    pca, scaler = results['PCA']['pca'], results['PCA']['scaler']
+    k0 = emulators[0].kernel_
+    if cov_unexplained is None:
+        S_un = pca.components_.T[:, n_pc:]
+        cov_unexplained = S_un.dot(np.diag(pca.explained_variance_[n_pc:]).dot(S_un.T))
+    dm = DeviceModel(
+        X_train=emulators[0].X_train_,
+        ls=np.stack([e.kernel_.length_scale for e in emulators]),
+        alpha=np.stack([e.alpha_ for e in emulators]),
+        L=np.stack([e.L_ for e in emulators]),
+        components=pca.components_[:n_pc], scaler_mean=scaler.mean_, scaler_scale=scaler.scale_,
+        kernel_kind=k0.kind, nu=k0.nu,
+        const=np.array([e.kernel_.constant_value for e in emulators]) if k0.has_const else None,
+        noise=np.array([e.kernel_.noise_level for e in emulators]) if k0.has_noise else None,
+        cov_unexplained=cov_unexplained)
+    _DEVICE_MODELS[key] = (results, dm, n_pc)
+    return dm
+
+
+def predict(parameters, emulation_config: "EmulationConfig", merge_predictions_over_groups: bool = True,
+            emulation_group_results: dict[str, dict[str, Any]] | None = None,
+            emulator_cov_unexplained: dict | None = None) -> dict[str, np.ndarray]:
+    """{'central_value': (B,F), 'cov': (B,F,F)} over all groups (ref: emulation.py:410-462)."""
+    emulation_group_results = emulation_group_results or {}
+    emulator_cov_unexplained = emulator_cov_unexplained or {}
+    predict_output = {}
+    for group_name, group_config in emulation_config.emulation_groups_config.items():
+        group_result = emulation_group_results.get(group_name)
+        if group_result is None:
+            group_result = read_emulators(group_config)
+        cov_un = emulator_cov_unexplained[group_name] if emulator_cov_unexplained else None
+        predict_output[group_name] = predict_emulation_group(parameters, group_result, group_config,
+                                                             emulator_group_cov_unexplained=cov_un)
+    if not merge_predictions_over_groups:
+        return predict_output
+    return emulation_config.sort_observables_in_matrix.convert(group_matrices=predict_output)
+
+
+def predict_emulation_group(parameters, results, emulation_group_config, emulator_group_cov_unexplained=None):
+    """Central values (B,F) and covariances (B,F,F) of one group (ref: emulation.py:466-548).
+    The truncation covariance is divided by the number of rows passed, like the reference
+    (ref: emulation.py:531-532)."""
+    parameters = np.array(parameters, ndmin=2, dtype=np.float64)
+    dm = device_model_for(results, emulation_group_config.n_pc, emulator_group_cov_unexplained)
+    cv, cov = dm.predict_full(parameters, n_div=parameters.shape[0])
+    return {'central_value': cv, 'cov': cov}
+
+
+####################################################################################################
+class _Base:
+    """Attribute bag (the reference derives its config classes from common_base.CommonBase)."""
+
+    def __init__(self, **kwargs):
+        for key, value in kwargs.items():
+            setattr(self, key, value)
+
+    def set_attribute(self, **kwargs):
+        for key, value in kwargs.items():
+            setattr(self, key, value)
+
+    def __str__(self):
+        body = '\n .  '.join(f'{k} = {v}' for k, v in self.__dict__.items())
+        return f"[i] {self.__class__.__name__} with \n .  {body}"
+
+
+class EmulationGroupConfig(_Base):
+    """Per-group settings read from the YAML (ref: emulation.py:551-622); same attribute names."""
+
+    def __init__(self, analysis_name='', parameterization='', analysis_config='', config_file='',
+                 emulation_group_name: str | None = None):
+        self.analysis_name = analysis_name
+        self.parameterization = parameterization
+        self.analysis_config = analysis_config
+        self.config_file = config_file
+        with open(self.config_file, 'r') as stream:
+            config = yaml.safe_load(stream)
+        self.observable_table_dir = config['observable_table_dir']
+        self.observable_config_dir = config['observable_config_dir']
+        self.observables_filename = config["observables_filename"]
+
+        emulators = self.analysis_config["parameters"]["emulators"]
+        emulator_configuration = emulators if emulation_group_name is None else emulators[emulation_group_name]
+        self.force_retrain = emulator_configuration['force_retrain']
+        self.n_pc = emulator_configuration['n_pc']
+        self.max_n_components_to_calculate = emulator_configuration.get("max_n_components_to_calculate", None)
+
+        self.active_kernels = {kt: emulator_configuration['kernels'][kt]
+                               for kt in emulator_configuration['kernels']['active']}
+        assert sum(s in self.active_kernels for s in ("matern", "rbf")) == 1, \
+            "Must provide exactly one of 'matern', 'rbf' kernel"
+        if 'noise' in self.active_kernels:
+            noise = self.active_kernels['noise']
+            assert all(k in noise for k in ("type", "args")), "Noise configuration must have keys 'type' and 'args'"
+            if noise["type"] == "white":
+                assert set(noise["args"]) == {"noise_level", "noise_level_bounds"}, \
+                    "Must provide arguments 'noise_level' and 'noise_level_bounds' for white noise kernel"
+            else:
+                raise ValueError("Unsupported noise kernel")
+
+        self.n_restarts = emulator_configuration["GPR"]['n_restarts']
+        self.alpha = emulator_configuration["GPR"]["alpha"]
+
+        self.observable_filter = None
+        observable_list = emulator_configuration.get("observable_list", [])
+        observable_exclude_list = emulator_configuration.get("observable_exclude_list", [])
+        if observable_list or observable_exclude_list:
+            self.observable_filter = _data_IO().ObservableFilter(include_list=observable_list,
+                                                                 exclude_list=observable_exclude_list)
+
+        self.output_dir = os.path.join(config['output_dir'], f'{analysis_name}_{parameterization}')
+        name = 'emulation.pkl' if emulation_group_name is None else f'emulation_group_{emulation_group_name}.pkl'
+        self.emulation_outputfile = os.path.join(self.output_dir, name)
+
+
+class EmulationConfig(_Base):
+    """All groups of one analysis (ref: emulation.py:624-709); same attribute and method names."""
+
+    def __init__(self, analysis_name: str, parameterization: str, config_file, analysis_config=None,
+                 emulation_groups_config=None):
+        self.analysis_name = analysis_name
+        self.parameterization = parameterization
+        self.config_file = Path(config_file)
+        self.analysis_config = analysis_config if analysis_config is not None else {}
+        self.emulation_groups_config = emulation_groups_config if emulation_groups_config is not None else {}
+        with self.config_file.open() as stream:
+            self.config = yaml.safe_load(stream)
+        self.observable_table_dir = self.config['observable_table_dir']
+        self.observable_config_dir = self.config['observable_config_dir']
+        self.observables_filename = self.config["observables_filename"]
+        self.output_dir = os.path.join(self.config['output_dir'], f'{self.analysis_name}_{self.parameterization}')
+        self._observable_filter = None
+        self._sort_observables_in_matrix = None
+
+    @classmethod
+    def from_config_file(cls, analysis_name: str, parameterization: str, config_file, analysis_config):
+        c = cls(analysis_name=analysis_name, parameterization=parameterization, config_file=config_file,
+                analysis_config=analysis_config)
+        c.emulation_groups_config = {
+            k: EmulationGroupConfig(analysis_name=c.analysis_name, parameterization=c.parameterization,
+                                    analysis_config=c.analysis_config, config_file=c.config_file,
+                                    emulation_group_name=k)
+            for k in c.analysis_config["parameters"]["emulators"]
+        }
+        return c
+
+    def read_all_emulator_groups(self):
+        return {name: read_emulators(cfg) for name, cfg in self.emulation_groups_config.items()}
+
+    @property
+    def observable_filter(self):
+        if self._observable_filter is None:
+            if not self.emulation_groups_config:
+                raise ValueError("Need to specify emulation groups to provide an observable filter")
+            include_list: list[str] = []
+            exclude_list: list[str] = self.config.get("global_observable_exclude_list", [])
+            for group_config in self.emulation_groups_config.values():
+                include_list.extend(group_config.observable_filter.include_list)
+                exclude_list.extend(group_config.observable_filter.exclude_list)
+            self._observable_filter = _data_IO().ObservableFilter(include_list=include_list, exclude_list=exclude_list)
+        return self._observable_filter
+
+    @property
+    def sort_observables_in_matrix(self) -> SortEmulationGroupObservables:
+        if self._sort_observables_in_matrix is None:
+            if not self.emulation_groups_config:
+                raise ValueError("Need to specify emulation groups to provide an sorting for observable group observables")
+            self._sort_observables_in_matrix = SortEmulationGroupObservables.learn_mapping(self)
+        return self._sort_observables_in_matrix

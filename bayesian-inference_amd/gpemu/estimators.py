@@ -1,0 +1,260 @@
+"""Light, picklable stand-ins for the sklearn objects the reference stores in its results dict
+(ref: emulation.py:181-192): ``StandardScaler``, ``PCA``, ARD kernels and ``GaussianProcessRegressor``.
+
+They carry the same attribute names downstream code touches (``pca.components_``,
+``.explained_variance_``, ``.explained_variance_ratio_``, ``scaler.inverse_transform``, ``.scale_``,
+``emulator.predict(X, return_std=True)``, ``.kernel_``) but hold only numpy arrays, so the pickles load
+without scikit-learn.  All arithmetic runs on the device through libgpemu; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from operator import itemgetter
+
+import numpy as np
+
+from . import fit as _fit
+from .model import DeviceModel
+
+RBF_KIND, MATERN_KIND = 0, 1
+
+
+# ------------------------------------------------------------------------------------------------
+class StandardScaler:
+    """mean_/var_/scale_ as sklearn.preprocessing.StandardScaler (skl _data.py:1015-1051)."""
+
+    def __init__(self):
+        self.mean_ = self.var_ = self.scale_ = None
+        self.n_samples_seen_ = 0
+
+    def transform(self, X):
+        return (np.asarray(X, dtype=np.float64) - self.mean_) / self.scale_
+
+    def inverse_transform(self, X):
+        return np.asarray(X, dtype=np.float64) * self.scale_ + self.mean_
+
+
+class PCA:
+    """components_/explained_variance_(_ratio_)/mean_ as sklearn.decomposition.PCA(svd_solver='full')."""
+
+    def __init__(self, n_components=None, svd_solver="full", whiten=False):
+        if whiten:
+            raise ValueError("whiten=True is not supported (the reference uses whiten=False)")
+        self.n_components = n_components
+        self.svd_solver = svd_solver
+        self.whiten = whiten
+        self.components_ = self.explained_variance_ = self.explained_variance_ratio_ = self.mean_ = None
+
+    def transform(self, X):
+        return (np.asarray(X, dtype=np.float64) - self.mean_) @ self.components_.T
+
+    def inverse_transform(self, X):
+        return np.asarray(X, dtype=np.float64) @ self.components_ + self.mean_
+
+
+def scale_and_pca(Y, n_components=None, device=0):
+    """``pca.fit_transform(scaler.fit_transform(Y))`` on the device (ref: emulation.py:109-117).
+    Returns (scaler, pca, Y_pca (N, n_components))."""
+    out = _fit.pca_fit(Y, n_components=n_components, device=device)
+    scaler = StandardScaler()
+    scaler.mean_, scaler.var_, scaler.scale_ = out["scaler_mean"], out["scaler_var"], out["scaler_scale"]
+    scaler.n_samples_seen_ = int(np.asarray(Y).shape[0])
+    pca = PCA(n_components=n_components)
+    pca.components_ = out["components"]
+    pca.explained_variance_ = out["explained_variance"]
+    pca.explained_variance_ratio_ = out["explained_variance_ratio"]
+    pca.mean_ = out["pca_mean"]
+    pca.singular_values_ = np.sqrt(out["explained_variance"] * (np.asarray(Y).shape[0] - 1))
+    pca.n_components_ = out["components"].shape[0]
+    pca.flip_argmax_ = out["flip_argmax"]
+    return scaler, pca, out["Y_pca"]
+
+
+# ------------------------------------------------------------------------------------------------
+class ARDKernel:
+    """base (+ ConstantKernel) (+ WhiteKernel) in the order the reference builds it
+    (ref: emulation.py:132-162).  theta = log([l_1..l_d, (constant), (noise)]) and bounds follow
+    sklearn's Sum/hyperparameter ordering (skl kernels.py:733-760, 861-866)."""
+
+    def __init__(self, kind, length_scale, length_scale_bounds, nu=math.inf, constant_value=None,
+                 constant_value_bounds=None, noise_level=None, noise_level_bounds=None):
+        self.kind = int(kind)
+        self.nu = float(nu)
+        self.length_scale = np.atleast_1d(np.asarray(length_scale, dtype=np.float64)).copy()
+        self.length_scale_bounds = np.atleast_2d(np.asarray(length_scale_bounds, dtype=np.float64)).copy()
+        self.constant_value = None if constant_value is None else float(constant_value)
+        self.constant_value_bounds = None if constant_value is None else tuple(constant_value_bounds)
+        self.noise_level = None if noise_level is None else float(noise_level)
+        self.noise_level_bounds = None if noise_level is None else tuple(noise_level_bounds)
+
+    @property
+    def has_const(self):
+        return self.constant_value is not None
+
+    @property
+    def has_noise(self):
+        return self.noise_level is not None
+
+    @property
+    def n_dims(self):
+        return self.length_scale.size + int(self.has_const) + int(self.has_noise)
+
+    @property
+    def theta(self):
+        t = list(np.log(self.length_scale))
+        if self.has_const:
+            t.append(math.log(self.constant_value))
+        if self.has_noise:
+            t.append(math.log(self.noise_level))
+        return np.array(t)
+
+    @theta.setter
+    def theta(self, value):
+        value = np.asarray(value, dtype=np.float64)
+        d = self.length_scale.size
+        self.length_scale = np.exp(value[:d])
+        i = d
+        if self.has_const:
+            self.constant_value = float(np.exp(value[i]))
+            i += 1
+        if self.has_noise:
+            self.noise_level = float(np.exp(value[i]))
+
+    @property
+    def bounds(self):
+        b = [np.log(self.length_scale_bounds)]
+        if self.has_const:
+            b.append(np.log(np.atleast_2d(self.constant_value_bounds)))
+        if self.has_noise:
+            b.append(np.log(np.atleast_2d(self.noise_level_bounds)))
+        return np.vstack(b)
+
+    def clone(self):
+        return ARDKernel(self.kind, self.length_scale, self.length_scale_bounds, self.nu, self.constant_value,
+                         self.constant_value_bounds, self.noise_level, self.noise_level_bounds)
+
+    def diag_value(self):
+        """kernel_.diag: 1 (+ constant) (+ noise) (skl kernels.py:868-885, 1433-1435)."""
+        return 1.0 + (self.constant_value or 0.0) + (self.noise_level or 0.0)
+
+    def __repr__(self):
+        ls = ", ".join(f"{v:.3g}" for v in self.length_scale)
+        if self.kind == RBF_KIND:
+            s = f"RBF(length_scale=[{ls}])"
+        else:
+            s = f"Matern(length_scale=[{ls}], nu={self.nu:.3g})"
+        if self.has_const:
+            s += f" + {math.sqrt(self.constant_value):.3g}**2"
+        if self.has_noise:
+            s += f" + WhiteKernel(noise_level={self.noise_level:.3g})"
+        return s
+
+
+class ConvergenceWarning(UserWarning):
+    pass
+
+
+class GaussianProcessRegressor:
+    """The subset of sklearn.gaussian_process.GaussianProcessRegressor the reference uses
+    (ref: emulation.py:169-172, 497), fitted and evaluated on the device.
+
+    fit: maximise the log-marginal likelihood with L-BFGS-B from the initial theta and
+    ``n_restarts_optimizer`` restarts drawn uniformly in the log-bounds from numpy's global RandomState
+    (skl _gpr.py:299-337; restarts use ``check_random_state(None)`` = ``np.random.mtrand._rand``).
+    """
+
+    def __init__(self, kernel, alpha=1e-10, n_restarts_optimizer=0, copy_X_train=True, optimizer="fmin_l_bfgs_b",
+                 device=0):
+        self.kernel = kernel
+        self.alpha = alpha
+        self.n_restarts_optimizer = n_restarts_optimizer
+        self.copy_X_train = copy_X_train
+        self.optimizer = optimizer
+        self.device = device
+        self._dev = None
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_dev"] = None
+        return st
+
+    def _optimise(self, dfit, y, theta0, bounds):
+        import scipy.optimize
+
+        def obj(theta):
+            lml, grad = dfit.lml(y, theta, eval_gradient=True)
+            return -lml, -grad
+        res = scipy.optimize.minimize(obj, theta0, method="L-BFGS-B", jac=True, bounds=bounds)
+        if res.status != 0:
+            warnings.warn(f"lbfgs failed to converge (status={res.status}): {res.message}", ConvergenceWarning)
+        return res.x, res.fun
+
+    def fit(self, X, y, _device_fit=None):
+        X = np.array(X, dtype=np.float64) if self.copy_X_train else np.asarray(X, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64).reshape(-1)
+        self.X_train_, self.y_train_ = X, y
+        self.kernel_ = self.kernel.clone()
+        k = self.kernel_
+        own = _device_fit is None
+        dfit = _device_fit or _fit.DeviceFit(X, k.kind, k.nu, k.has_const, k.has_noise, self.alpha, self.device)
+        try:
+            if self.optimizer is not None and k.n_dims > 0:
+                bounds = k.bounds
+                optima = [self._optimise(dfit, y, k.theta, bounds)]
+                if self.n_restarts_optimizer > 0:
+                    if not np.isfinite(bounds).all():
+                        raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) requires that all "
+                                         "bounds are finite.")
+                    rng = np.random.mtrand._rand
+                    for _ in range(self.n_restarts_optimizer):
+                        theta_initial = rng.uniform(bounds[:, 0], bounds[:, 1])
+                        optima.append(self._optimise(dfit, y, theta_initial, bounds))
+                lml_values = list(map(itemgetter(1), optima))
+                k.theta = optima[int(np.argmin(lml_values))][0]
+                self._check_bounds(k)
+            self.L_, self.alpha_, self.log_marginal_likelihood_value_ = dfit.factor(y, k.theta)
+        finally:
+            if own:
+                dfit.close()
+        self._y_train_mean, self._y_train_std = 0.0, 1.0
+        return self
+
+    @staticmethod
+    def _check_bounds(k):
+        th, b = k.theta, k.bounds
+        close_lo = np.isclose(b[:, 0], th)
+        close_hi = np.isclose(b[:, 1], th)
+        if np.any(close_lo) or np.any(close_hi):
+            warnings.warn("The optimal value found for some hyper-parameters is close to the specified bound; "
+                          "changing the bound and repeating the fit may find a better value.", ConvergenceWarning)
+
+    def log_marginal_likelihood(self, theta=None, eval_gradient=False):
+        if theta is None:
+            return self.log_marginal_likelihood_value_
+        k = self.kernel_
+        dfit = _fit.DeviceFit(self.X_train_, k.kind, k.nu, k.has_const, k.has_noise, self.alpha, self.device)
+        try:
+            return dfit.lml(self.y_train_, theta, eval_gradient=eval_gradient)
+        finally:
+            dfit.close()
+
+    def _device(self):
+        if self._dev is None:
+            k = self.kernel_
+            self._dev = DeviceModel(
+                X_train=self.X_train_, ls=k.length_scale[None, :], alpha=self.alpha_[None, :], L=self.L_[None],
+                components=np.ones((1, 1)), scaler_mean=np.zeros(1), scaler_scale=np.ones(1),
+                kernel_kind=k.kind, nu=k.nu,
+                const=np.array([k.constant_value]) if k.has_const else None,
+                noise=np.array([k.noise_level]) if k.has_noise else None, device=self.device)
+        return self._dev
+
+    def predict(self, X, return_std=False, return_cov=False):
+        if return_cov:
+            raise NotImplementedError("return_cov is not on the reference's path")
+        X = np.array(X, ndmin=2, dtype=np.float64)
+        mean, var = self._device().gp_predict(X)
+        if return_std:
+            return mean[:, 0], np.sqrt(var[:, 0])
+        return mean[:, 0]

@@ -266,3 +266,205 @@ class HostEnsemble:
     def run(self, steps, store=True):
         for _ in range(int(steps)):
             self.step(store)
+
+
+# ------------------------------------------------------------------------------------------------
+def walkers_independent(coords):
+    """emcee's initial-state check: the walker cloud must span the space (condition number <= 1e8)."""
+    if not np.all(np.isfinite(coords)):
+        return False
+    C = coords - np.mean(coords, axis=0)[None, :]
+    C_colmax = np.amax(np.abs(C), axis=0)
+    if np.any(C_colmax == 0):
+        return False
+    C = C / C_colmax
+    C = C / np.sqrt(np.sum(C ** 2, axis=0))
+    return np.linalg.cond(C.astype(float)) <= 1e8
+
+
+class State:
+    """Minimal emcee.State: ``coords``, ``log_prob``; unpacks / indexes like emcee's
+    (``sampler.run_mcmc(...)[0]`` is the coordinate array, ref: mcmc.py:101)."""
+
+    def __init__(self, coords, log_prob=None, blobs=None, random_state=None):
+        self.coords = np.atleast_2d(np.asarray(coords, dtype=np.float64))
+        self.log_prob = log_prob
+        self.blobs = blobs
+        self.random_state = random_state
+
+    def __iter__(self):
+        return iter((self.coords, self.log_prob, self.random_state))
+
+    def __getitem__(self, i):
+        return (self.coords, self.log_prob, self.random_state)[i]
+
+    def __len__(self):
+        return 3
+
+
+class EnsembleSampler:
+    """emcee.EnsembleSampler look-alike (the subset the reference uses: ref: mcmc.py:83-116, 187-204 and
+    plot_mcmc.py): stretch move a = 2, red/blue split re-drawn every step.
+
+    * ``log_prob_fn`` bound to device models (``bayesian_inference.log_posterior.log_posterior`` carries a
+      ``_gpemu_device_models`` hook): the ensemble lives on the GPU (``DeviceSampler``); with
+      torch.distributed initialised the proposals are sharded over the ranks.
+    * any other callable: host stretch move (``HostEnsemble``), one call per walker like emcee
+      (``vectorize=True`` passes the whole half-ensemble), ``pool.map`` if a pool is given.
+    """
+
+    def __init__(self, nwalkers, ndim, log_prob_fn, pool=None, a=2.0, seed=None, vectorize=False,
+                 args=None, kwargs=None, **_ignored):
+        self.nwalkers, self.ndim = int(nwalkers), int(ndim)
+        self.log_prob_fn = log_prob_fn
+        self.pool = pool
+        self.a = float(a)
+        self.vectorize = vectorize
+        self._args, self._kwargs = tuple(args or ()), dict(kwargs or {})
+        self._seed = int(np.random.randint(0, 2 ** 31 - 1)) if seed is None else int(seed)
+        self._impl = None
+        self._cache = None
+
+    # -- backends -------------------------------------------------------------------------------
+    @property
+    def world_size(self):
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                return dist.get_world_size()
+        except ImportError:
+            pass
+        return 1
+
+    def _call_rows(self, q):
+        f = self.log_prob_fn
+        if self.vectorize:
+            return np.asarray(f(q, *self._args, **self._kwargs), dtype=np.float64).reshape(-1)
+        mapper = self.pool.map if self.pool is not None else map
+        vals = list(mapper(_RowCall(f, self._args, self._kwargs), list(q)))
+        return np.array([float(np.asarray(v).reshape(-1)[0]) for v in vals])
+
+    def _ensure(self):
+        if self._impl is not None:
+            return
+        hook = getattr(self.log_prob_fn, "_gpemu_device_models", None)
+        if hook is not None:
+            self._impl = DeviceSampler(hook(), self.nwalkers, a=self.a, seed=self._seed)
+            self._device = True
+        else:
+            self._impl = HostEnsemble(self.nwalkers, self.ndim, self._call_rows, a=self.a, seed=self._seed,
+                                      sharded=self.world_size > 1)
+            self._device = False
+
+    # -- running ----------------------------------------------------------------------------------
+    def advance(self, initial_state, nsteps, store=True):
+        """Run ``nsteps`` steps (from ``initial_state`` if given, else from the current state)."""
+        self._ensure()
+        self._cache = None
+        if initial_state is not None:
+            X0 = initial_state.coords if isinstance(initial_state, State) else np.asarray(initial_state, dtype=np.float64)
+            if X0.shape != (self.nwalkers, self.ndim):
+                raise ValueError("incompatible input dimensions")
+            if self.nwalkers < 2 * self.ndim:
+                raise RuntimeError("It is unadvisable to use a red-blue move with fewer walkers than twice the "
+                                   "number of dimensions.")
+            if not walkers_independent(X0):
+                raise ValueError("Initial state has a large condition number. Make sure that your walkers are "
+                                 "linearly independent for the best performance")
+            self._impl.set_state(X0)
+            lp0 = self._impl.get_state()[1] if self._device else self._impl.lp
+            if np.any(np.isnan(lp0)):
+                raise ValueError("The initial log_prob was NaN")
+        if self._device and self.world_size > 1:
+            self._impl.run_sharded(nsteps, store)
+        else:
+            self._impl.run(nsteps, store)
+        if self._device:
+            X, lp = self._impl.get_state()
+        else:
+            X, lp = self._impl.X.copy(), self._impl.lp.copy()
+        return State(X, log_prob=lp)
+
+    def run_mcmc(self, initial_state, nsteps, **kwargs):
+        return self.advance(initial_state, nsteps, **kwargs)
+
+    def sample(self, initial_state, iterations=1, store=True, **_ignored):
+        """Generator over single steps (emcee's ``sample``)."""
+        state = None
+        for i in range(int(iterations)):
+            state = self.advance(initial_state if i == 0 else None, 1, store=store)
+            yield state
+
+    def reset(self):
+        self._cache = None
+        if self._impl is not None:
+            self._impl.reset()
+
+    # -- results ----------------------------------------------------------------------------------
+    def _results(self):
+        if self._cache is None:
+            if self.__dict__.get("_frozen") or self._impl is None:
+                chain = np.empty((0, self.nwalkers, self.ndim)); lp = np.empty((0, self.nwalkers))
+                nacc = np.zeros(self.nwalkers, dtype=np.int64); it = 0
+            elif self._device:
+                chain, lp = self._impl.get_chain()
+                nacc, it, _ = self._impl.counts()
+            else:
+                h = self._impl
+                chain = np.stack(h.chain) if h.chain else np.empty((0, self.nwalkers, self.ndim))
+                lp = np.stack(h.lps) if h.lps else np.empty((0, self.nwalkers))
+                nacc, it = h.naccepted.copy(), h.iterations
+            self._cache = (chain, lp, nacc, it)
+        return self._cache
+
+    @property
+    def iteration(self):
+        return self._results()[3]
+
+    @staticmethod
+    def _thin(v, discard, thin, flat):
+        v = v[discard + thin - 1::thin]
+        if flat:
+            v = v.reshape((-1,) + v.shape[2:])
+        return v
+
+    def get_chain(self, discard=0, thin=1, flat=False):
+        return self._thin(self._results()[0], discard, thin, flat)
+
+    def get_log_prob(self, discard=0, thin=1, flat=False):
+        return self._thin(self._results()[1], discard, thin, flat)
+
+    @property
+    def flatchain(self):
+        return self.get_chain(flat=True)
+
+    @property
+    def flatlnprobability(self):
+        return self.get_log_prob(flat=True)
+
+    @property
+    def acceptance_fraction(self):
+        _, _, nacc, it = self._results()
+        return nacc / float(max(it, 1))
+
+    def get_autocorr_time(self, discard=0, thin=1, **kwargs):
+        return thin * integrated_time(self.get_chain(discard=discard, thin=thin), **kwargs)
+
+    # -- pickling (ref: mcmc.py:131-132 pickles the sampler) --------------------------------------
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_cache"] = self._results()
+        st["_impl"] = None
+        st["pool"] = None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._frozen = True
+
+class _RowCall:
+    def __init__(self, f, args, kwargs):
+        self.f, self.args, self.kwargs = f, args, kwargs
+
+    def __call__(self, x):
+        return self.f(x, *self.args, **self.kwargs)

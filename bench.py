@@ -36,34 +36,29 @@ N_DESIGN, N_OBS, N_PC, N_WALKERS = 1000, 500, 10, 1024
 FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix rate (the local guide lists none)
 
 
-def build_workload():
-    """Synthetic C3 model (numpy/scipy, setup only -- not timed): standardise, PCA, fixed-theta GP
-    factors.  Same generator and hyper-parameters as the goldens (gpemu/synthetic.py)."""
-    from scipy.linalg import cho_solve, cholesky, svd
-    from scipy.spatial.distance import pdist, squareform
-    from gpemu import synthetic
+def build_workload(device=0):
+    """Synthetic C3 model, built with the product's own device fit path (setup, not timed):
+    standardise + PCA (gpemu_pca_fit), then kernel matrix / Cholesky / alpha at the fixed
+    hyper-parameters of SURVEY.md 8d (gpemu_fit_factor).  Same generator as the goldens."""
+    from gpemu import estimators, synthetic
+    from gpemu.fit import DeviceFit
     prob = synthetic.make_problem(N_DESIGN, N_OBS, seed=0)
-    Y, X = prob["Y"], prob["design"]
-    mean = Y.mean(0)
-    scale = Y.std(0)
-    Ys = (Y - mean) / scale
-    U, S, Vt = svd(Ys - Ys.mean(0), full_matrices=False)
-    sg = np.sign(Vt[np.arange(Vt.shape[0]), np.argmax(np.abs(Vt), axis=1)])
-    U, Vt = U * sg, Vt * sg[:, None]
-    ev = S ** 2 / (N_DESIGN - 1)
-    Ypca = (U * S)[:, :N_PC]
+    scaler, pca, Y_pca = estimators.scale_and_pca(prob["Y"], device=device)
     ls = (prob["hi"] - prob["lo"]) * 0.5
     noise = 0.05
-    K = squareform(np.exp(-0.5 * pdist(X / ls, "sqeuclidean")))
-    np.fill_diagonal(K, 1.0)
-    K[np.diag_indices_from(K)] += noise + 1e-10
-    L = cholesky(K, lower=True)
-    alpha = np.stack([cho_solve((L, True), Ypca[:, i]) for i in range(N_PC)])
-    Sun = Vt.T[:, N_PC:]
-    cun = Sun @ (ev[N_PC:, None] * Sun.T)
-    return dict(prob=prob, ls=np.tile(ls, (N_PC, 1)), noise=np.full(N_PC, noise), alpha=alpha,
-                L=np.broadcast_to(L, (N_PC,) + L.shape).copy(), components=Vt[:N_PC], mean=mean,
-                scale=scale, cun=cun)
+    theta = np.log(np.r_[ls, noise])
+    fit = DeviceFit(prob["design"], kernel_kind=0, has_noise=True, jitter=1e-10, device=device)
+    Ls, alphas = [], []
+    for i in range(N_PC):
+        L, alpha, _ = fit.factor(Y_pca[:, i], theta)
+        Ls.append(L)
+        alphas.append(alpha)
+    fit.close()
+    S_un = pca.components_.T[:, N_PC:]
+    cun = S_un.dot(np.diag(pca.explained_variance_[N_PC:]).dot(S_un.T))
+    return dict(prob=prob, ls=np.tile(ls, (N_PC, 1)), noise=np.full(N_PC, noise), alpha=np.stack(alphas),
+                L=np.stack(Ls), components=pca.components_[:N_PC], mean=scaler.mean_, scale=scaler.scale_,
+                cun=cun)
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -142,7 +137,7 @@ def main():
     from gpemu.model import DeviceModel
     from gpemu.sampler import DeviceSampler
 
-    wl = build_workload()
+    wl = build_workload(dev_index)
     prob = wl["prob"]
     dm = DeviceModel(X_train=prob["design"], ls=wl["ls"], alpha=wl["alpha"], L=wl["L"],
                      components=wl["components"], scaler_mean=wl["mean"], scaler_scale=wl["scale"],

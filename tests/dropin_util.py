@@ -1,0 +1,60 @@
+"""Test helpers for the drop-in modules: a fake ``data_IO`` (the reference's HDF5 layer is out of
+scope and needs silx, which is not installed) and a config written to a temp dir."""
+import os
+import sys
+import types
+
+import numpy as np
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class FakeObservableFilter:
+    def __init__(self, include_list, exclude_list=None):
+        self.include_list = list(include_list)
+        self.exclude_list = list(exclude_list or [])
+
+    def accept_observable(self, observable_name):
+        return True
+
+
+def install_fake_data_IO(Y, design, y_exp, y_err, written):
+    """Register a stand-in ``bayesian_inference.data_IO`` serving in-memory matrices; ``written``
+    collects what ``write_dict_to_h5`` receives."""
+    import bayesian_inference
+    m = types.ModuleType("bayesian_inference.data_IO")
+    m.predictions_matrix_from_h5 = lambda *a, **k: Y
+    m.design_array_from_h5 = lambda *a, **k: design
+    m.data_array_from_h5 = lambda *a, **k: {"y": y_exp, "y_err": y_err}
+    m.ObservableFilter = FakeObservableFilter
+
+    def write_dict_to_h5(results, output_dir, filename, verbose=True):
+        written[os.path.join(output_dir, filename)] = results
+    m.write_dict_to_h5 = write_dict_to_h5
+    sys.modules["bayesian_inference.data_IO"] = m
+    bayesian_inference.data_IO = m
+    return m
+
+
+def write_config(tmp_path, kernels_active=("rbf", "noise"), n_pc=5, n_restarts=1):
+    cfg = yaml.safe_load(open(os.path.join(HERE, "fixtures", "analysis.yaml")))
+    cfg["output_dir"] = str(tmp_path / "out")
+    em = cfg["test_analysis"]["parameters"]["emulators"]["main"]
+    em["kernels"]["active"] = list(kernels_active)
+    em["n_pc"] = n_pc
+    em["GPR"]["n_restarts"] = n_restarts
+    path = tmp_path / "analysis.yaml"
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    return str(path), cfg["test_analysis"]
+
+
+class TrivialSort:
+    """Single group whose matrix is the merged matrix."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def convert(self, group_matrices):
+        return group_matrices[self.name]

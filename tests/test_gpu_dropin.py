@@ -1,0 +1,167 @@
+"""-m gpu tests of the drop-in modules through the reference's call signatures
+(emulation.fit_emulator_group / predict / predict_emulation_group, log_posterior.log_posterior,
+mcmc.run_mcmc) against the goldens produced by running the reference."""
+import pickle
+
+import numpy as np
+import pytest
+
+import dropin_util as DU
+import golden_util as GU
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+
+def relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def _results_at_golden_theta(g, kernels_active, design=None):
+    """Results dict in the reference's schema with our estimator objects at the golden's fitted theta."""
+    from gpemu import estimators as E
+    design = g["design"] if design is None else design
+    spec = GU.spec_of(g)
+    k = int(g["n_pc"])
+    d = design.shape[1]
+    scaler = E.StandardScaler()
+    scaler.mean_, scaler.scale_, scaler.var_ = g["scaler_mean"], g["scaler_scale"], g["scaler_var"]
+    pca = E.PCA()
+    pca.components_, pca.explained_variance_ = g["pca_components"], g["pca_explained_variance"]
+    pca.explained_variance_ratio_, pca.mean_ = g["pca_explained_variance_ratio"], g["pca_mean"]
+    emus = []
+    for i in range(k):
+        th = np.exp(g["theta"][i])
+        kern = E.ARDKernel(spec.kind, th[:d], np.outer(th[:d], [0.01, 100]), nu=spec.nu,
+                           constant_value=th[d] if spec.has_const else None, constant_value_bounds=(1e-3, 1e3),
+                           noise_level=th[d + int(spec.has_const)] if spec.has_noise else None,
+                           noise_level_bounds=(1e-3, 10))
+        gp = E.GaussianProcessRegressor(kern, alpha=float(g["gpr_alpha"]), optimizer=None, copy_X_train=False)
+        gp.fit(design, g["Y_pca_truncated"][:, i])
+        emus.append(gp)
+    return {"PCA": {"pca": pca, "scaler": scaler, "Y_pca_truncated": g["Y_pca_truncated"]}, "emulators": emus}
+
+
+class _GroupCfg:
+    def __init__(self, n_pc):
+        self.n_pc = n_pc
+
+
+class _EmuCfg:
+    def __init__(self, groups, sorter):
+        self.emulation_groups_config = groups
+        self.sort_observables_in_matrix = sorter
+
+
+@pytest.mark.parametrize("name", ["g1_rbf_noise", "g1_matern25_const_noise", "g2_rbf_noise"])
+def test_predict_and_log_posterior_module_api(name):
+    from bayesian_inference import emulation, log_posterior
+    g = GU.load(name)
+    res = _results_at_golden_theta(g, None)
+    cfg = _GroupCfg(int(g["n_pc"]))
+    Xq = g["Xq"]
+    # single estimator API (ref: emulation.py:497)
+    m0, s0 = res["emulators"][0].predict(Xq, return_std=True)
+    assert relerr(m0, g["gp_mean"][:, 0]) < TOL and np.max(np.abs(s0 ** 2 - g["gp_var"][:, 0])) < TOL
+    # predict_emulation_group: batch and single-row semantics (cov_unexplained / n_samples)
+    cu = emulation.compute_emulator_group_cov_unexplained(cfg, res)
+    assert relerr(cu, g["cov_unexplained"]) < 1e-12
+    pb = emulation.predict_emulation_group(Xq, res, cfg, emulator_group_cov_unexplained=cu)
+    assert relerr(pb["central_value"], g["batch_central_value"]) < TOL
+    assert relerr(pb["cov"][:g["batch_cov_head"].shape[0]], g["batch_cov_head"]) < TOL
+    p1 = emulation.predict_emulation_group(Xq[0], res, cfg)
+    assert relerr(p1["cov"][0], g["single_cov_head"][0]) < TOL
+    # predict() over groups + log_posterior through the module globals
+    emu_cfg = _EmuCfg({"g": cfg}, DU.TrivialSort("g"))
+    merged = emulation.predict(Xq[:4], emu_cfg, emulation_group_results={"g": res})
+    assert merged["cov"].shape == (4, g["Y"].shape[1], g["Y"].shape[1])
+    log_posterior.initialize_pool_variables(g["lo"], g["hi"], emu_cfg, {"g": res},
+                                            {"y": g["y_exp"], "y_err": g["y_err"]}, None)
+    nper = g["logpost_per_walker"].shape[0]
+    per = np.array([log_posterior.log_posterior(Xq[i])[0] for i in range(min(nper, 12))])
+    np.testing.assert_allclose(per, g["logpost_per_walker"][:per.size], rtol=TOL)
+    np.testing.assert_allclose(log_posterior.log_posterior(Xq), g["logpost_batched"], rtol=TOL)
+    mixed = log_posterior.log_posterior(g["X_mixed"])
+    assert np.array_equal(np.isneginf(mixed), np.isneginf(g["logpost_mixed"]))
+    fin = np.isfinite(mixed)
+    np.testing.assert_allclose(mixed[fin], g["logpost_mixed"][fin], rtol=TOL)
+    assert log_posterior.log_posterior(Xq[3]).shape == (1,)
+
+
+def test_multigroup_log_posterior_module_api():
+    from bayesian_inference import emulation, log_posterior
+    g = GU.load("g5_multigroup")
+    mapping = {"A": ("g1", slice(0, 10), slice(0, 10)), "B": ("g2", slice(10, 18), slice(0, 8)),
+               "C": ("g1", slice(18, 30), slice(10, 22))}
+    sorter = emulation.SortEmulationGroupObservables(mapping, (60, 30))
+    res, cfgs = {}, {}
+    for grp in ("g1", "g2"):
+        sub = {k[len(grp) + 1:]: v for k, v in g.items() if k.startswith(grp + "_")}
+        sub.update(design=g["design"], gpr_alpha=g["gpr_alpha"])
+        res[grp] = _results_at_golden_theta(sub, None)
+        cfgs[grp] = _GroupCfg(int(sub["n_pc"]))
+    emu_cfg = _EmuCfg(cfgs, sorter)
+    Xq = g["Xq"]
+    merged = emulation.predict(Xq, emu_cfg, emulation_group_results=res)
+    assert relerr(merged["central_value"], g["merged_central_value"]) < TOL
+    assert relerr(merged["cov"][:2], g["merged_cov_head"]) < TOL
+    log_posterior.initialize_pool_variables(g["lo"], g["hi"], emu_cfg, res, {"y": g["y_exp"], "y_err": g["y_err"]}, None)
+    np.testing.assert_allclose(log_posterior.log_posterior(Xq), g["logpost_batched"], rtol=TOL)
+    per = np.array([log_posterior.log_posterior(Xq[i])[0] for i in range(6)])
+    np.testing.assert_allclose(per, g["logpost_per_walker"][:6], rtol=TOL)
+
+
+def test_fit_emulator_group_end_to_end(tmp_path):
+    """The whole fit (device PCA + device LML/gradient under host L-BFGS-B with restarts) lands on the
+    reference's optimum: same seeds for the restarts, so the same basins."""
+    from bayesian_inference import emulation
+    g = GU.load("g1_rbf_noise")
+    DU.install_fake_data_IO(g["Y"], g["design"], g["y_exp"], g["y_err"], {})
+    path, analysis = DU.write_config(tmp_path, kernels_active=("rbf", "noise"), n_pc=5, n_restarts=2)
+    ec = emulation.EmulationConfig.from_config_file("test_analysis", "exponential", path, analysis)
+    np.random.seed(12345)
+    emulation.fit_emulators(ec)
+    res = emulation.read_emulators(ec.emulation_groups_config["main"])
+    assert set(res["PCA"]) == {"Y", "Y_pca", "Y_pca_truncated", "Y_reconstructed_truncated",
+                               "Y_reconstructed_truncated_unscaled", "pca", "scaler"}
+    assert relerr(res["PCA"]["Y_pca_truncated"], g["Y_pca_truncated"]) < 1e-9
+    assert relerr(res["PCA"]["Y_reconstructed_truncated_unscaled"], g["Y_reconstructed_truncated_unscaled"]) < 1e-9
+    for i, e in enumerate(res["emulators"]):
+        # the optimiser is path dependent; the optimum itself is well defined
+        assert e.log_marginal_likelihood_value_ >= g["lml_value"][i] - 1e-5 * abs(g["lml_value"][i])
+        assert abs(e.log_marginal_likelihood_value_ - g["lml_value"][i]) < 1e-4 * abs(g["lml_value"][i])
+    cfg = ec.emulation_groups_config["main"]
+    p = emulation.predict_emulation_group(g["Xq"], res, cfg)
+    assert relerr(p["central_value"], g["batch_central_value"]) < 2e-3
+    # a second call returns {} and does not overwrite (checkpoint behaviour, ref: emulation.py:64-70)
+    assert emulation.fit_emulator_group(cfg) == {}
+
+
+def test_run_mcmc_end_to_end(tmp_path):
+    from bayesian_inference import emulation, mcmc
+    g = GU.load("g1_rbf_noise")
+    written = {}
+    DU.install_fake_data_IO(g["Y"], g["design"], g["y_exp"], g["y_err"], written)
+    path, analysis = DU.write_config(tmp_path, n_pc=5, n_restarts=0)
+    ec = emulation.EmulationConfig.from_config_file("test_analysis", "exponential", path, analysis)
+    ec._sort_observables_in_matrix = None
+    np.random.seed(1)
+    emulation.fit_emulators(ec)
+    # single group: the merged matrix is the group matrix
+    emulation.EmulationConfig.sort_observables_in_matrix = property(lambda self: DU.TrivialSort("main"))
+    emulation.EmulationConfig.observable_filter = property(lambda self: None)
+    cfg = mcmc.MCMCConfig("test_analysis", "exponential", analysis, path)
+    mcmc.run_mcmc(cfg)
+    out = written[cfg.mcmc_outputfile]
+    W, steps, d = cfg.n_walkers, cfg.n_sampling_steps, 6
+    assert out["chain"].shape == (steps, W, d) and out["log_prob"].shape == (steps, W)
+    assert out["acceptance_fraction"].shape == (W,) and out["autocorrelation_time"] is None
+    lo, hi = np.array(g["lo"]), np.array(g["hi"])
+    assert np.all(out["chain"] > lo) and np.all(out["chain"] < hi) and np.all(np.isfinite(out["log_prob"]))
+    # stored log-probs are the (single-walker semantics) log-posterior of the stored positions
+    from bayesian_inference import log_posterior
+    lp = np.array([log_posterior.log_posterior(x)[0] for x in out["chain"][-1][:5]])
+    np.testing.assert_allclose(lp, out["log_prob"][-1][:5], rtol=1e-10)
+    sampler = pickle.load(open(cfg.sampler_outputfile, "rb"))
+    np.testing.assert_array_equal(sampler.get_chain(), out["chain"])
