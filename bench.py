@@ -61,6 +61,20 @@ def build_workload(device=0):
                 cun=cun)
 
 
+def committed_traffic(world):
+    """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied).
+    The counters cannot be collected from inside this process; null when the file or shape differs."""
+    if world != 1:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            k = json.load(f)["kernels"]["gpemu::trmm_vsq_persistent_kernel"]
+        return {"bytes_per_launch": k["bytes_per_launch_corrected"], "source": "profiles/r01_traffic.json"}
+    except Exception:
+        return None
+
+
 def cpu_baseline(seconds_budget=20.0):
     """Reference-form per-walker log_posterior (oracle port, incl. the per-call recomputation of the
     truncation covariance) over a spawn Pool, one walker per task (ref: mcmc.py:77-85)."""
@@ -183,9 +197,9 @@ def main():
         flop_per_launch = N_PC * N_DESIGN ** 2 * evals_per_launch
         avg_s = ms_tot / n_launch * 1e-3
         achieved = flop_per_launch / avg_s / 1e12
-        roofline = {"bound": "mfma", "kernel": "trmm_vsq_kernel", "achieved": achieved,
+        roofline = {"bound": "mfma", "kernel": "trmm_vsq_persistent_kernel", "achieved": achieved,
                     "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                    "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": committed_traffic(world),
                     "avg_launch_us": avg_s * 1e6, "launches": n_launch,
                     "kstar_avg_launch_us": prof["kstar"][0] / max(prof["kstar"][1], 1) * 1e3}
 
