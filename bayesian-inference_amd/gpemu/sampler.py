@@ -156,28 +156,47 @@ class DeviceSampler:
         return chain, lp
 
     # -- multi-GPU: one process per GPU, the ensemble replicated, proposals sharded -------------
-    def run_sharded(self, steps, store=True, group=None):
+    def run_sharded(self, steps, store=True, group=None, force=False):
         """Same chain as ``run`` (every rank draws identical randomness); rank r evaluates its
-        block of each half's proposals and the log-probabilities are all-gathered."""
+        block of each half's proposals and the log-probabilities are all-gathered.
+
+        Backend "nccl" (RCCL over xGMI): the gather runs on device buffers on the sampler's stream.
+        Any other backend (gloo, for tests): the 8-byte-per-walker payload is staged through the host.
+        """
         import torch
         import torch.distributed as dist
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        if world == 1:
+        if world == 1 and not force:
             return self.run(steps, store)
         L = _lib.lib()
         dev = torch.device("cuda", self.device)
-        stream = torch.cuda.current_stream(dev)
+        on_device = dist.get_backend(group) == "nccl"
+        # a dedicated (non-null) torch stream carries the library's launches AND the collectives, so
+        # they are ordered by the stream; torch's default stream has handle 0, which the C ABI reads
+        # as "use the handle's own stream"
+        if getattr(self, "_tstream", None) is None:
+            self._tstream = torch.cuda.Stream(device=dev)
+        stream = self._tstream
+        stream.wait_stream(torch.cuda.current_stream(dev))
         check(L.gpemu_sampler_set_stream(self._h, C.c_void_p(stream.cuda_stream)))
         bounds = [shard_bounds(self.ns[h], world, rank) for h in (0, 1)]
-        mine = [torch.zeros(b[2], dtype=torch.float64, device=dev) for b in bounds]
-        full = [torch.zeros(b[2] * world, dtype=torch.float64, device=dev) for b in bounds]
+        with torch.cuda.stream(stream):
+            mine = [torch.zeros(b[2], dtype=torch.float64, device=dev) for b in bounds]
+            full = [torch.zeros(b[2] * world, dtype=torch.float64, device=dev) for b in bounds]
         try:
+          with torch.cuda.stream(stream):
             for _ in range(int(steps)):
                 check(L.gpemu_sampler_begin_step(self._h))
                 for h in (0, 1):
                     lo, hi, _per = bounds[h]
                     check(L.gpemu_sampler_half_propose_eval(self._h, h, lo, hi, C.c_void_p(mine[h].data_ptr())))
-                    dist.all_gather_into_tensor(full[h], mine[h], group=group)
+                    if on_device:
+                        dist.all_gather_into_tensor(full[h], mine[h], group=group)
+                    else:
+                        host_mine = mine[h].cpu()
+                        host_full = torch.empty(full[h].shape, dtype=torch.float64)
+                        dist.all_gather_into_tensor(host_full, host_mine, group=group)
+                        full[h].copy_(host_full)
                     check(L.gpemu_sampler_half_accept(self._h, h, C.c_void_p(full[h].data_ptr())))
                 check(L.gpemu_sampler_end_step(self._h, int(bool(store))))
             rc = L.gpemu_sampler_check(self._h)
@@ -185,6 +204,7 @@ class DeviceSampler:
                 raise ValueError("Probability function returned NaN")
             check(rc)
         finally:
+            stream.synchronize()
             L.gpemu_sampler_set_stream(self._h, None)
 
 
