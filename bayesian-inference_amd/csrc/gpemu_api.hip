@@ -329,6 +329,8 @@ int gpemu_model_sync(gpemu_model *m) {
 }
 
 // ---- GP predict --------------------------------------------------------------------------------
+constexpr int64_t MAX_CHUNK = 2048;   // rows per pass of the predict pipeline (bounds the K_* workspace)
+
 static int gp_predict_core(gpemu_model *m, int64_t B, const double *dX, hipStream_t st) {
   GP_TRY(ensure_workspace(m, B));
   GP_TRY(launch_pad_queries(m, B, dX, st));
@@ -344,8 +346,11 @@ int gpemu_gp_predict_dev(gpemu_model *m, int64_t B, const double *dX, double *dm
   GP_ARG(B > 0, "B must be positive");
   GP_HIP(hipSetDevice(m->device));
   hipStream_t st = stream ? (hipStream_t)stream : m->stream;
-  GP_TRY(gp_predict_core(m, B, dX, st));
-  GP_TRY(launch_reduce_mean_var(m, B, dmean, dvar, st));
+  for (int64_t off = 0; off < B; off += MAX_CHUNK) {   // large batches go through in chunks
+    const int64_t nb = (B - off < MAX_CHUNK) ? (B - off) : MAX_CHUNK;
+    GP_TRY(gp_predict_core(m, nb, dX + off * m->d, st));
+    GP_TRY(launch_reduce_mean_var(m, nb, dmean + off * m->k, dvar + off * m->k, st));
+  }
   return GPEMU_OK;
 }
 
@@ -354,19 +359,19 @@ int gpemu_gp_predict(gpemu_model *m, int64_t B, const double *X, double *mean_ou
   GP_ARG(B > 0, "B must be positive");
   GP_HIP(hipSetDevice(m->device));
   hipStream_t st = m->stream;
-  double *dX = nullptr;
-  GP_TRY(ensure_workspace(m, B));
-  GP_TRY(dev_alloc(&dX, B * m->d));
-  int rc = upload(dX, X, B * m->d, st);
-  if (rc == GPEMU_OK) rc = gpemu_gp_predict_dev(m, B, dX, m->ws.mean, m->ws.var, st);
+  double *dX = nullptr, *dm = nullptr, *dv = nullptr;
+  int rc = dev_alloc(&dX, B * m->d);
+  if (rc == GPEMU_OK) rc = dev_alloc(&dm, B * m->k);
+  if (rc == GPEMU_OK) rc = dev_alloc(&dv, B * m->k);
+  if (rc == GPEMU_OK) rc = upload(dX, X, B * m->d, st);
+  if (rc == GPEMU_OK) rc = gpemu_gp_predict_dev(m, B, dX, dm, dv, st);
   if (rc == GPEMU_OK) {
-    hipError_t e = hipMemcpyAsync(mean_out, m->ws.mean, sizeof(double) * B * m->k, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(var_out, m->ws.var, sizeof(double) * B * m->k, hipMemcpyDeviceToHost, st);
+    hipError_t e = hipMemcpyAsync(mean_out, dm, sizeof(double) * B * m->k, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(var_out, dv, sizeof(double) * B * m->k, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { set_error("gp_predict: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
   }
-  hipFree(dX);
+  hipFree(dX); hipFree(dm); hipFree(dv);
   return rc;
 }
 
@@ -446,9 +451,13 @@ int gpemu_logpost_dev(gpemu_model *m, int64_t B, const double *dX, double *dout,
   if (!m->lik_ready) { set_error("gpemu_likelihood_setup has not been called"); return GPEMU_ERR_STATE; }
   GP_HIP(hipSetDevice(m->device));
   hipStream_t st = stream ? (hipStream_t)stream : m->stream;
-  GP_TRY(gp_predict_core(m, B, dX, st));
-  if (mode == GPEMU_LOGPOST_LOWRANK) return launch_loglik_lowrank(m, B, m->ws.Xq, dout, 0, st);
-  return launch_loglik_exact(m, B, m->ws.Xq, dout, st);
+  for (int64_t off = 0; off < B; off += MAX_CHUNK) {
+    const int64_t nb = (B - off < MAX_CHUNK) ? (B - off) : MAX_CHUNK;
+    GP_TRY(gp_predict_core(m, nb, dX + off * m->d, st));
+    if (mode == GPEMU_LOGPOST_LOWRANK) GP_TRY(launch_loglik_lowrank(m, nb, m->ws.Xq, dout + off, 0, st));
+    else GP_TRY(launch_loglik_exact(m, nb, m->ws.Xq, dout + off, st));
+  }
+  return GPEMU_OK;
 }
 
 int gpemu_logpost(gpemu_model *m, int64_t B, const double *X, double *out, int mode) {
@@ -456,17 +465,17 @@ int gpemu_logpost(gpemu_model *m, int64_t B, const double *X, double *out, int m
   GP_ARG(B > 0, "B must be positive");
   GP_HIP(hipSetDevice(m->device));
   hipStream_t st = m->stream;
-  double *dX = nullptr;
-  GP_TRY(ensure_workspace(m, B));
-  GP_TRY(dev_alloc(&dX, B * m->d));
-  int rc = upload(dX, X, B * m->d, st);
-  if (rc == GPEMU_OK) rc = gpemu_logpost_dev(m, B, dX, m->ws.logp, mode, st);
+  double *dX = nullptr, *dout = nullptr;
+  int rc = dev_alloc(&dX, B * m->d);
+  if (rc == GPEMU_OK) rc = dev_alloc(&dout, B);
+  if (rc == GPEMU_OK) rc = upload(dX, X, B * m->d, st);
+  if (rc == GPEMU_OK) rc = gpemu_logpost_dev(m, B, dX, dout, mode, st);
   if (rc == GPEMU_OK) {
-    hipError_t e = hipMemcpyAsync(out, m->ws.logp, sizeof(double) * B, hipMemcpyDeviceToHost, st);
+    hipError_t e = hipMemcpyAsync(out, dout, sizeof(double) * B, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { set_error("logpost: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
   }
-  hipFree(dX);
+  hipFree(dX); hipFree(dout);
   return rc;
 }
 
@@ -477,9 +486,14 @@ int gpemu_predict_full_dev(gpemu_model *m, int64_t B, const double *dX, double n
   GP_ARG(B > 0 && n_div >= 1.0, "B, n_div");
   GP_HIP(hipSetDevice(m->device));
   hipStream_t st = stream ? (hipStream_t)stream : m->stream;
-  GP_TRY(gp_predict_core(m, B, dX, st));
-  GP_TRY(launch_reduce_mean_var(m, B, m->ws.mean, m->ws.var, st));
-  return launch_predict_full(m, B, n_div, dcv, dcov, st);
+  const int64_t F = m->F;
+  for (int64_t off = 0; off < B; off += MAX_CHUNK) {
+    const int64_t nb = (B - off < MAX_CHUNK) ? (B - off) : MAX_CHUNK;
+    GP_TRY(gp_predict_core(m, nb, dX + off * m->d, st));
+    GP_TRY(launch_reduce_mean_var(m, nb, m->ws.mean, m->ws.var, st));
+    GP_TRY(launch_predict_full(m, nb, n_div, dcv + off * F, dcov + off * F * F, st));
+  }
+  return GPEMU_OK;
 }
 
 int gpemu_predict_full(gpemu_model *m, int64_t B, const double *X, double n_div, double *cv_out,
@@ -490,7 +504,6 @@ int gpemu_predict_full(gpemu_model *m, int64_t B, const double *X, double n_div,
   hipStream_t st = m->stream;
   const int64_t F = m->F;
   double *dX = nullptr, *dcv = nullptr, *dcov = nullptr;
-  GP_TRY(ensure_workspace(m, B));
   int rc = dev_alloc(&dX, B * m->d);
   if (rc == GPEMU_OK) rc = dev_alloc(&dcv, B * F);
   if (rc == GPEMU_OK) rc = dev_alloc(&dcov, B * F * F);

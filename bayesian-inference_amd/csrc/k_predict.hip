@@ -252,6 +252,10 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_kernel(const double *__restri
 struct TrmmItem {
   int p, rb, col0, half;  // PC, 64-row block, first column, 1 = 64-column item
 };
+constexpr int TRMM_MAX_ITEMS = 64;  // per worker; the schedule falls back to more workers' worth otherwise
+#ifdef GPEMU_TRMM_STAMPS
+__device__ unsigned long long g_trmm_stamps[512 * 8];
+#endif
 
 __global__ __launch_bounds__(512, 2) void trmm_vsq_persistent_kernel(
     const double *__restrict__ Wt, const double *__restrict__ KS, double *__restrict__ out,
@@ -270,8 +274,13 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_persistent_kernel(
   const int brow = tid >> 6, bc2 = tid & 63;   // full-width B staging: rows brow + 8 r
   const int64_t astep = (int64_t)KT * Npad, bstep = (int64_t)KT * Bcap;
 
+  // this worker's item list, copied to LDS once: reading a descriptor from global memory at an item
+  // switch would sit behind the tile loads in flight (vmcnt is in order) and stall the stream
+  __shared__ TrmmItem s_items[TRMM_MAX_ITEMS];
   const int nitems = sched_cnt[blockIdx.x];
-  const TrmmItem *my = sched + (int64_t)blockIdx.x * max_items;
+  if (tid < nitems) s_items[tid] = sched[(int64_t)blockIdx.x * max_items + tid];
+  __syncthreads();
+  const TrmmItem *my = s_items;
 
   // ---- load cursor (runs two k-tiles ahead of the compute cursor) ----
   // Every call issues exactly six 16-byte loads and every staged k-tile is stored with exactly six
@@ -315,6 +324,10 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_persistent_kernel(
     else *reinterpret_cast<d2 *>(&sB[buf][brow + 8 * (part - 2)][2 * bc2]) = sg.b[part - 2];
   };
 
+#ifdef GPEMU_TRMM_STAMPS
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+  if (tid == 0) g_trmm_stamps[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
   if (nitems == 0) return;
   l_open();
   // prologue: k-tile 0 -> LDS buffer 0, k-tile 1 -> register set st1
@@ -409,6 +422,10 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_persistent_kernel(
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+#ifdef GPEMU_TRMM_STAMPS
+      if (tid == 0 && c_item + 1 < 7) g_trmm_stamps[blockIdx.x * 8 + 1 + c_item] = __builtin_amdgcn_s_memrealtime();
+      if (tid == 0 && c_item + 1 == nitems) g_trmm_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - clk0;
+#endif
       if (++c_item == nitems) return true;
       cur = my[c_item];
       c_nt = (int)(((int64_t)cur.rb * TM + TM + KT - 1) / KT);
@@ -482,6 +499,11 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
     std::vector<int> cnt;
     int max_items = 0, nworkers = 0;
     build_trmm_schedule(m, ncb, flat, cnt, max_items, nworkers);
+    if (max_items > TRMM_MAX_ITEMS) {
+      set_error("triangular GEMM schedule needs %d items per worker (limit %d): batch too large for one launch",
+                max_items, TRMM_MAX_ITEMS);
+      return GPEMU_ERR_UNSUPPORTED;
+    }
     GP_HIP(hipStreamSynchronize(st));
     (void)hipFree(m->sched_items);
     (void)hipFree(m->sched_cnt);
@@ -498,6 +520,28 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
                      m->Npad, w.Bcap, (int)m->k, nrb);
   GP_HIP(hipGetLastError());
   prof_pair(m, 0, pe0, prof_mark(m, st));
+#ifdef GPEMU_TRMM_STAMPS
+  if (getenv("GPEMU_DUMP_STAMPS")) {
+    static int dumped = 0;
+    if (++dumped == 20) {
+      GP_HIP(hipStreamSynchronize(st));
+      std::vector<unsigned long long> h(512 * 8);
+      GP_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_trmm_stamps), sizeof(unsigned long long) * h.size()));
+      std::vector<int> cnt(m->sched_workers);
+      GP_HIP(hipMemcpy(cnt.data(), m->sched_cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost));
+      FILE *f = fopen(getenv("GPEMU_DUMP_STAMPS"), "w");
+      unsigned long long t0 = ~0ull;
+      for (int w = 0; w < m->sched_workers; ++w) t0 = h[w * 8] < t0 ? h[w * 8] : t0;
+      for (int w = 0; w < m->sched_workers; ++w) {
+        fprintf(f, "%d %d", w, cnt[w]);
+        for (int i = 0; i < 7; ++i) fprintf(f, " %.2f", i <= cnt[w] ? (double)(h[w * 8 + i] - t0) / 100.0 : -1.0);
+        fprintf(f, " %llu", h[w * 8 + 7]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
+#endif
   return GPEMU_OK;
 }
 

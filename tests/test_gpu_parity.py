@@ -161,6 +161,23 @@ def test_many_pcs_lds_likelihood_path(k):
     dm.close()
 
 
+def test_large_batch_is_chunked():
+    """B larger than one pass of the pipeline (2048 rows) gives the same rows as small calls."""
+    from gpemu import synthetic
+    g, model = _load("g1_rbf_noise")
+    dm = GU.device_model(model)
+    dm.likelihood_setup(g["y_exp"], g["y_err"], g["lo"], g["hi"], 1.0)
+    X = synthetic.make_walkers(5000, seed=11, lo=g["lo"], hi=g["hi"])
+    lp = dm.logpost(X)
+    np.testing.assert_array_equal(lp[:300], dm.logpost(X[:300]))
+    np.testing.assert_array_equal(lp[4090:4200], dm.logpost(X[4090:4200]))
+    m, v = dm.gp_predict(X)
+    m2, v2 = dm.gp_predict(X[2040:2060])
+    np.testing.assert_array_equal(m[2040:2060], m2)
+    np.testing.assert_array_equal(v[2040:2060], v2)
+    dm.close()
+
+
 def test_argument_errors():
     from gpemu._lib import GpemuError
     g, model = _load("g1_rbf_noise")
