@@ -121,11 +121,11 @@ static int check_device(int device) {
 namespace gpemu {
 // Log-posterior of B query rows already in the padded [rows >= round_up(B,128)][DPAD] layout
 // (the sampler writes its proposals in that layout).  accumulate != 0 adds to dout (multi-group).
-int logpost_padded(gpemu_model *m, int64_t B, const double *dXq, double *dout, int accumulate,
-                   hipStream_t st, const AcceptArgs *aa) {
+int logpost_padded(gpemu_model *m, int64_t B, double *dXq, double *dout, int accumulate,
+                   hipStream_t st, const AcceptArgs *aa, const ProposeArgs *pa) {
   if (!m->lik_ready) { set_error("gpemu_likelihood_setup has not been called"); return GPEMU_ERR_STATE; }
   int rc = ensure_workspace(m, B);
-  if (rc == GPEMU_OK) rc = launch_kstar(m, B, dXq, st);
+  if (rc == GPEMU_OK) rc = launch_kstar(m, B, dXq, st, pa);
   if (rc == GPEMU_OK) rc = launch_trmm_vsq(m, B, st);
   if (rc != GPEMU_OK) return rc;
   return launch_loglik_lowrank(m, B, dXq, dout, accumulate, st, aa);

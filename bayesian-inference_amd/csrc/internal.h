@@ -109,15 +109,6 @@ struct gpemu_model {
 };
 
 namespace gpemu {
-int ensure_workspace(gpemu_model *m, int64_t B);
-
-// kernels (launchers; all asynchronous on `st`)
-int launch_trtri_lower_to_Wt(const double *dL, double *dWt, int64_t k, int64_t N, int64_t Npad,
-                             hipStream_t st);
-int launch_kstar(gpemu_model *m, int64_t B, const double *dXq_padded, hipStream_t st);
-int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st);
-int launch_reduce_mean_var(gpemu_model *m, int64_t B, double *dmean, double *dvar, hipStream_t st);
-int launch_pad_queries(gpemu_model *m, int64_t B, const double *dX, hipStream_t st);
 // optional fused stretch-move finish (accept / reject + chain record) for the walker of each proposal
 struct AcceptArgs {
   int enabled = 0;
@@ -131,10 +122,34 @@ struct AcceptArgs {
   double *chain = nullptr;        // [W][d] row of this step, or null
   double *lpchain = nullptr;      // [W]
 };
+
+// optional fused stretch-move proposal: kstar_kernel builds its query rows from the ensemble
+// (q_i = c[rint_i] - (c[rint_i] - s_i) zz_i, emcee moves/stretch.py) instead of reading them
+struct ProposeArgs {
+  int enabled = 0;
+  const double *X = nullptr;      // [W][DPAD]
+  const int *idx_s = nullptr;     // [n] walker of proposal i (already offset to the evaluated slice)
+  const int *idx_c = nullptr;     // complementary set members
+  const double *zz = nullptr;     // [n]
+  const int *rint = nullptr;      // [n]
+  double *factors = nullptr;      // [n] out: (d - 1) log zz
+  int n = 0, d = 0;
+};
+
+int ensure_workspace(gpemu_model *m, int64_t B);
+
+// kernels (launchers; all asynchronous on `st`)
+int launch_trtri_lower_to_Wt(const double *dL, double *dWt, int64_t k, int64_t N, int64_t Npad,
+                             hipStream_t st);
+// dXq_padded is read, or -- with pa->enabled -- written (rows [0, round_up(B, 128))) by the kernel
+int launch_kstar(gpemu_model *m, int64_t B, double *dXq_padded, hipStream_t st, const ProposeArgs *pa = nullptr);
+int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st);
+int launch_reduce_mean_var(gpemu_model *m, int64_t B, double *dmean, double *dvar, hipStream_t st);
+int launch_pad_queries(gpemu_model *m, int64_t B, const double *dX, hipStream_t st);
 int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq_padded, double *dout,
                           int accumulate, hipStream_t st, const AcceptArgs *aa = nullptr);
-int logpost_padded(gpemu_model *m, int64_t B, const double *dXq, double *dout, int accumulate,
-                   hipStream_t st, const AcceptArgs *aa = nullptr);
+int logpost_padded(gpemu_model *m, int64_t B, double *dXq, double *dout, int accumulate,
+                   hipStream_t st, const AcceptArgs *aa = nullptr, const ProposeArgs *pa = nullptr);
 // fit-side building blocks (k_fit.hip)
 int device_invert_factor_to_Wt(const double *dL, int64_t N, double *Wt, int64_t Npad, double *A, double *Dinv,
                                double *W, double *T, hipStream_t st);

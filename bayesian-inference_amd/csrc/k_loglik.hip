@@ -174,16 +174,19 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
       double t = (lane < k) ? mu * (h + gl) : 0.0;
       for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
       const double quadA = t + scal[2 * o];
-      // right-looking Cholesky, lane = row; y = L_M^-1 (sd o h) by forward substitution alongside
+      // right-looking Cholesky, lane = row; y = L_M^-1 (sd o h) by forward substitution alongside.
+      // One reciprocal square root per pivot on the critical path; the logarithms of the pivots are
+      // taken after the loop, one per lane in parallel.
       double y = (lane < k) ? sd * h : 0.0;
-      double logdiag = 0.0;
+      double mypiv2 = 1.0;
 #pragma unroll
       for (int jx = 0; jx < KMAX; ++jx) {
         if (jx < k) {
-          const double piv = sqrt(__shfl(row[jx], jx));
-          const double lj = (lane == jx) ? piv : row[jx] / piv;      // column jx of L (lanes >= jx)
-          if (lane == jx) logdiag = log(piv);
-          const double zj = __shfl(y, jx) / piv;
+          const double piv2 = __shfl(row[jx], jx);
+          const double rinv = 1.0 / sqrt(piv2);
+          if (lane == jx) mypiv2 = piv2;
+          const double lj = row[jx] * rinv;                           // column jx of L (lanes >= jx)
+          const double zj = __shfl(y, jx) * rinv;
           if (lane == jx) y = zj;
           if (lane > jx) y = fma(-lj, zj, y);
 #pragma unroll
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
           }
         }
       }
+      const double logdiag = (lane < k) ? 0.5 * log(mypiv2) : 0.0;
       double ww = (lane < k) ? y * y : 0.0;
       double ldsum = logdiag;
       for (int off = 32; off > 0; off >>= 1) {

@@ -55,9 +55,9 @@ __device__ __forceinline__ double base_kernel(double r2) {
 // grid (Bcap/64, Npad/JCHUNK, k), block 256: lane <-> query b, wave <-> 32 training rows.
 template <int KIND>
 __global__ __launch_bounds__(256) void kstar_kernel(
-    const double *__restrict__ Xq, const double *__restrict__ Xs, const double *__restrict__ ls,
+    double *__restrict__ Xq, const double *__restrict__ Xs, const double *__restrict__ ls,
     const double *__restrict__ constv, const double *__restrict__ alpha, double *__restrict__ KS,
-    double *__restrict__ mean_part, int64_t N, int64_t Npad, int64_t Bcap, int has_const) {
+    double *__restrict__ mean_part, int64_t N, int64_t Npad, int64_t Bcap, int has_const, ProposeArgs pa) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = blockIdx.z;
@@ -66,8 +66,32 @@ __global__ __launch_bounds__(256) void kstar_kernel(
   const int64_t b = (int64_t)blockIdx.x * 64 + lane;
 
   double xq[DPAD];
+  if (pa.enabled) {
+    // stretch-move proposal for column b (every workgroup recomputes it; one of them stores it)
+    double z = 1.0;
+    int w = 0, j = 0;
+    const bool live = b < pa.n;
+    if (live) { w = pa.idx_s[b]; j = pa.idx_c[pa.rint[b]]; z = pa.zz[b]; }
 #pragma unroll
-  for (int dd = 0; dd < DPAD; ++dd) xq[dd] = Xq[b * DPAD + dd] / ls[p * DPAD + dd];
+    for (int dd = 0; dd < DPAD; ++dd) {
+      double v = 0.0;
+      if (live && dd < pa.d) {
+        const double cj = pa.X[(int64_t)j * DPAD + dd], sw = pa.X[(int64_t)w * DPAD + dd];
+        v = cj - (cj - sw) * z;
+      }
+      xq[dd] = v;
+    }
+    if (chunk == 0 && p == 0 && wave == 0) {
+#pragma unroll
+      for (int dd = 0; dd < DPAD; ++dd) Xq[b * DPAD + dd] = xq[dd];
+      if (live) pa.factors[b] = (pa.d - 1.0) * log(z);
+    }
+#pragma unroll
+    for (int dd = 0; dd < DPAD; ++dd) xq[dd] = xq[dd] / ls[p * DPAD + dd];
+  } else {
+#pragma unroll
+    for (int dd = 0; dd < DPAD; ++dd) xq[dd] = Xq[b * DPAD + dd] / ls[p * DPAD + dd];
+  }
   const double c = has_const ? constv[p] : 0.0;
 
   const int64_t jbase = (int64_t)chunk * JCHUNK + wave * (JCHUNK / 4);
@@ -97,7 +121,8 @@ __global__ __launch_bounds__(256) void kstar_kernel(
   }
 }
 
-int launch_kstar(gpemu_model *m, int64_t B, const double *dXq, hipStream_t st) {
+int launch_kstar(gpemu_model *m, int64_t B, double *dXq, hipStream_t st, const ProposeArgs *pa) {
+  const ProposeArgs pargs = pa ? *pa : ProposeArgs();
   // only the column tiles that hold real queries; the rows of dXq up to round_up(B, TILE) must be
   // finite (pad_queries_kernel / the sampler's proposal buffer zero them)
   const Workspace &w = m->ws;
@@ -107,7 +132,7 @@ int launch_kstar(gpemu_model *m, int64_t B, const double *dXq, hipStream_t st) {
   if (m->kernel_kind == GPEMU_KERNEL_MATERN) kind = (m->nu == 0.5) ? 1 : (m->nu == 1.5 ? 2 : 3);
 #define GP_LAUNCH_KSTAR(KD)                                                                      \
   hipLaunchKernelGGL(kstar_kernel<KD>, grid, block, 0, st, dXq, m->Xs, m->ls, m->constv, m->alpha, \
-                     w.KS, w.mean_part, m->N, m->Npad, w.Bcap, m->has_const)
+                     w.KS, w.mean_part, m->N, m->Npad, w.Bcap, m->has_const, pargs)
   switch (kind) {
     case 0: GP_LAUNCH_KSTAR(0); break;
     case 1: GP_LAUNCH_KSTAR(1); break;

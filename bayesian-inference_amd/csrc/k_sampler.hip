@@ -206,11 +206,14 @@ __global__ void unpad_rows_kernel(const double *__restrict__ src, double *__rest
 }
 
 // ---- host helpers ---------------------------------------------------------------------------------
-static int eval_logpost(gpemu_sampler *s, const double *dq, int64_t B, double *dout, hipStream_t st,
-                        const AcceptArgs *aa = nullptr) {
+// log-posterior of B padded query rows summed over the groups; `pa` lets the first group's kernel
+// build the rows from the ensemble (fused proposal), `aa` lets the last group's kernel finish the move
+static int eval_logpost(gpemu_sampler *s, double *dq, int64_t B, double *dout, hipStream_t st,
+                        const AcceptArgs *aa = nullptr, const ProposeArgs *pa = nullptr) {
   const size_t ng = s->groups.size();
   for (size_t g = 0; g < ng; ++g) {
-    int rc = logpost_padded(s->groups[g], B, dq, dout, g > 0 ? 1 : 0, st, g + 1 == ng ? aa : nullptr);
+    int rc = logpost_padded(s->groups[g], B, dq, dout, g > 0 ? 1 : 0, st, g + 1 == ng ? aa : nullptr,
+                            g == 0 ? pa : nullptr);
     if (rc != GPEMU_OK) return rc;
   }
   return GPEMU_OK;
@@ -274,9 +277,17 @@ static int launch_accept(gpemu_sampler *s, int h, const double *dnewlp, hipStrea
 
 // propose + log-posterior + (fused) accept / record of one half on this device
 static int half_step_fused(gpemu_sampler *s, int h, int store_chain, hipStream_t st) {
-  int rc = launch_propose(s, h, st);
-  if (rc != GPEMU_OK) return rc;
   const size_t o2 = rslot(s) * 2 * s->W;
+  ProposeArgs pa;
+  pa.enabled = 1;
+  pa.X = s->X;
+  pa.idx_s = s->idx + o2 + h * s->W;
+  pa.idx_c = s->idx + o2 + (1 - h) * s->W;
+  pa.zz = s->zz + o2 + h * s->W;
+  pa.rint = s->rint + o2 + h * s->W;
+  pa.factors = s->factors;
+  pa.n = (int)s->ns[h];
+  pa.d = (int)s->d;
   AcceptArgs aa;
   aa.enabled = 1;
   aa.X = s->X; aa.logp = s->logp;
@@ -288,7 +299,7 @@ static int half_step_fused(gpemu_sampler *s, int h, int store_chain, hipStream_t
     aa.chain = s->chain + s->chain_len * s->W * s->d;
     aa.lpchain = s->lpchain + s->chain_len * s->W;
   }
-  return eval_logpost(s, s->q, s->ns[h], s->newlp, st, &aa);
+  return eval_logpost(s, s->q, s->ns[h], s->newlp, st, &aa, &pa);
 }
 
 // bookkeeping after both halves; `recorded` = the chain row was already written by the fused kernels
