@@ -13,7 +13,13 @@ constexpr int PF_TF = 32;    // rows (f) per tile
 constexpr int PF_TG = 128;   // cols (g) per tile
 constexpr int PF_NB = 8;     // walkers per workgroup (C_unexpl tile reused across them)
 
-// grid (ceil(F/128), ceil(F/32), ceil(B/8)), block 256.  Thread: 8 rows x 2 columns (lane, lane+64).
+// grid (ceil(F/128), ceil(F/32), ceil(B/8)), block 256.  Thread: 8 rows x 2 columns.
+// PAIR = true (F even): the two columns are adjacent (2 lane, 2 lane + 1) and each row is written with
+// one 16-byte store per lane, i.e. 1 KiB contiguous per wave-instruction -- the kernel is store-issue
+// bound with 8-byte stores.  PAIR = false: columns lane and lane + 64, 8-byte stores (any F).
+typedef double d2x __attribute__((ext_vector_type(2)));
+
+template <bool PAIR>
 __global__ __launch_bounds__(256) void predict_full_kernel(
     const double *__restrict__ mean, const double *__restrict__ var, const double *__restrict__ comp,
     const double *__restrict__ smean, const double *__restrict__ sscale,
@@ -26,6 +32,7 @@ __global__ __launch_bounds__(256) void predict_full_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wr = tid >> 6;
   const int g0 = blockIdx.x * PF_TG, f0 = blockIdx.y * PF_TF;
   const int64_t bb0 = (int64_t)blockIdx.z * PF_NB;
+  const int c0 = PAIR ? 2 * lane : lane, c1 = PAIR ? 2 * lane + 1 : lane + 64;   // tile columns
   for (int idx = tid; idx < k * PF_TF; idx += 256) {
     int p = idx / PF_TF, f = f0 + idx % PF_TF;
     cf[idx] = (f < F) ? comp[(int64_t)p * F + f] : 0.0;
@@ -41,7 +48,7 @@ __global__ __launch_bounds__(256) void predict_full_kernel(
     int f = f0 + wr * 8 + r;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      int g = g0 + lane + 64 * c;
+      int g = g0 + (c == 0 ? c0 : c1);
       bool ok = (f < F) && (g < F);
       cu[r][c] = ok ? cun[(int64_t)f * F + g] * inv_ndiv : 0.0;
       ss[r][c] = ok ? sscale[f] * sscale[g] : 0.0;
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(256) void predict_full_kernel(
     for (int r = 0; r < 8; ++r) acc[r][0] = acc[r][1] = 0.0;
     for (int p = 0; p < k; ++p) {
       const double v = wv[p];
-      const double b0v = cg[p * PF_TG + lane] * v, b1v = cg[p * PF_TG + lane + 64] * v;
+      const double b0v = cg[p * PF_TG + c0] * v, b1v = cg[p * PF_TG + c1] * v;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const double a = cf[p * PF_TF + wr * 8 + r];
@@ -71,10 +78,12 @@ __global__ __launch_bounds__(256) void predict_full_kernel(
     for (int r = 0; r < 8; ++r) {
       int f = f0 + wr * 8 + r;
       if (f < F) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          int g = g0 + lane + 64 * c;
-          if (g < F) covb[(int64_t)f * F + g] = (acc[r][c] + cu[r][c]) * ss[r][c];
+        const double o0 = (acc[r][0] + cu[r][0]) * ss[r][0], o1 = (acc[r][1] + cu[r][1]) * ss[r][1];
+        if (PAIR) {
+          if (g0 + c0 < F) *reinterpret_cast<d2x *>(covb + (int64_t)f * F + g0 + c0) = d2x{o0, o1};   // F even => c1 < F too
+        } else {
+          if (g0 + c0 < F) covb[(int64_t)f * F + g0 + c0] = o0;
+          if (g0 + c1 < F) covb[(int64_t)f * F + g0 + c1] = o1;
         }
       }
     }
@@ -89,13 +98,115 @@ __global__ __launch_bounds__(256) void predict_full_kernel(
   }
 }
 
+
+// Row-streaming variant: a workgroup owns 8 whole rows (all columns, up to 512 per pass), so its stores
+// form one contiguous 8 * F * 8-byte stream per walker instead of 1 KiB pieces at a 4 KB stride.
+constexpr int PR_ROWS = 8;
+constexpr int PR_COLS = 512;   // 256 threads x 2 adjacent columns
+
+template <bool PAIR>
+__global__ __launch_bounds__(256) void predict_full_rows_kernel(
+    const double *__restrict__ mean, const double *__restrict__ var, const double *__restrict__ comp,
+    const double *__restrict__ smean, const double *__restrict__ sscale,
+    const double *__restrict__ cun, double *__restrict__ cv, double *__restrict__ cov, int64_t B,
+    int F, int k, double inv_ndiv) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *cf = sm;                    // [k][PR_ROWS]
+  double *cg = cf + k * PR_ROWS;      // [k][PR_COLS]
+  double *wv = cg + k * PR_COLS;      // [k]
+  const int tid = threadIdx.x;
+  const int g0 = blockIdx.x * PR_COLS, f0 = blockIdx.y * PR_ROWS;
+  const int64_t bb0 = (int64_t)blockIdx.z * PF_NB;
+  const int c0 = PAIR ? 2 * tid : tid, c1 = PAIR ? 2 * tid + 1 : tid + 256;
+  for (int idx = tid; idx < k * PR_ROWS; idx += 256) {
+    int p = idx / PR_ROWS, f = f0 + idx % PR_ROWS;
+    cf[idx] = (f < F) ? comp[(int64_t)p * F + f] : 0.0;
+  }
+  for (int idx = tid; idx < k * PR_COLS; idx += 256) {
+    int p = idx / PR_COLS, g = g0 + idx % PR_COLS;
+    cg[idx] = (g < F) ? comp[(int64_t)p * F + g] : 0.0;
+  }
+  double cu[PR_ROWS][2], ss[PR_ROWS][2];
+#pragma unroll
+  for (int r = 0; r < PR_ROWS; ++r) {
+    int f = f0 + r;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      int g = g0 + (c == 0 ? c0 : c1);
+      bool ok = (f < F) && (g < F);
+      cu[r][c] = ok ? cun[(int64_t)f * F + g] * inv_ndiv : 0.0;
+      ss[r][c] = ok ? sscale[f] * sscale[g] : 0.0;
+    }
+  }
+  for (int ib = 0; ib < PF_NB; ++ib) {
+    const int64_t b = bb0 + ib;
+    if (b >= B) break;
+    __syncthreads();
+    if (tid < k) wv[tid] = var[b * k + tid];
+    __syncthreads();
+    double acc[PR_ROWS][2];
+#pragma unroll
+    for (int r = 0; r < PR_ROWS; ++r) acc[r][0] = acc[r][1] = 0.0;
+    for (int p = 0; p < k; ++p) {
+      const double v = wv[p];
+      const double b0v = cg[p * PR_COLS + c0] * v, b1v = cg[p * PR_COLS + c1] * v;
+#pragma unroll
+      for (int r = 0; r < PR_ROWS; ++r) {
+        const double a = cf[p * PR_ROWS + r];
+        acc[r][0] = fma(a, b0v, acc[r][0]);
+        acc[r][1] = fma(a, b1v, acc[r][1]);
+      }
+    }
+    double *covb = cov + (int64_t)b * F * F;
+#pragma unroll
+    for (int r = 0; r < PR_ROWS; ++r) {
+      int f = f0 + r;
+      if (f < F) {
+        const double o0 = (acc[r][0] + cu[r][0]) * ss[r][0], o1 = (acc[r][1] + cu[r][1]) * ss[r][1];
+        if (PAIR) {
+          if (g0 + c0 < F) *reinterpret_cast<d2x *>(covb + (int64_t)f * F + g0 + c0) = d2x{o0, o1};
+        } else {
+          if (g0 + c0 < F) covb[(int64_t)f * F + g0 + c0] = o0;
+          if (g0 + c1 < F) covb[(int64_t)f * F + g0 + c1] = o1;
+        }
+      }
+    }
+    if (blockIdx.y == 0) {   // central value (ref: emulation.py:508-509), one column chunk per block
+      for (int g = g0 + tid; g < g0 + PR_COLS && g < F; g += 256) {
+        double s = 0.0;
+        for (int p = 0; p < k; ++p) s = fma(mean[b * k + p], cg[p * PR_COLS + (g - g0)], s);
+        cv[b * F + g] = s * sscale[g] + smean[g];
+      }
+    }
+  }
+}
+
 int launch_predict_full(gpemu_model *m, int64_t B, double n_div, double *dcv, double *dcov, hipStream_t st) {
   const int F = (int)m->F, k = (int)m->k;
   dim3 grid((unsigned)((F + PF_TG - 1) / PF_TG), (unsigned)((F + PF_TF - 1) / PF_TF),
             (unsigned)((B + PF_NB - 1) / PF_NB));
   size_t shm = sizeof(double) * (size_t)(k * (PF_TF + PF_TG) + k);
-  hipLaunchKernelGGL(predict_full_kernel, grid, dim3(256), shm, st, m->ws.mean, m->ws.var, m->comp,
-                     m->smean, m->sscale, m->cunexpl, dcv, dcov, B, F, k, 1.0 / n_div);
+  // 16-byte stores need every row start of dcov 16-byte aligned: F even and an aligned base
+  const bool pair = F % 2 == 0 && (reinterpret_cast<uintptr_t>(dcov) & 15) == 0;
+  const size_t shm_rows = sizeof(double) * (size_t)(k * (PR_ROWS + PR_COLS) + k);
+  if (shm_rows <= 64 * 1024) {   // whole rows per workgroup: contiguous store streams
+    dim3 g2((unsigned)((F + PR_COLS - 1) / PR_COLS), (unsigned)((F + PR_ROWS - 1) / PR_ROWS),
+            (unsigned)((B + PF_NB - 1) / PF_NB));
+    if (pair)
+      hipLaunchKernelGGL(predict_full_rows_kernel<true>, g2, dim3(256), shm_rows, st, m->ws.mean, m->ws.var, m->comp,
+                         m->smean, m->sscale, m->cunexpl, dcv, dcov, B, F, k, 1.0 / n_div);
+    else
+      hipLaunchKernelGGL(predict_full_rows_kernel<false>, g2, dim3(256), shm_rows, st, m->ws.mean, m->ws.var, m->comp,
+                         m->smean, m->sscale, m->cunexpl, dcv, dcov, B, F, k, 1.0 / n_div);
+    GP_HIP(hipGetLastError());
+    return GPEMU_OK;
+  }
+  if (pair)
+    hipLaunchKernelGGL(predict_full_kernel<true>, grid, dim3(256), shm, st, m->ws.mean, m->ws.var, m->comp,
+                       m->smean, m->sscale, m->cunexpl, dcv, dcov, B, F, k, 1.0 / n_div);
+  else
+    hipLaunchKernelGGL(predict_full_kernel<false>, grid, dim3(256), shm, st, m->ws.mean, m->ws.var, m->comp,
+                       m->smean, m->sscale, m->cunexpl, dcv, dcov, B, F, k, 1.0 / n_div);
   GP_HIP(hipGetLastError());
   return GPEMU_OK;
 }

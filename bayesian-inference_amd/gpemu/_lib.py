@@ -84,10 +84,28 @@ def exported_symbols():
     return sorted(_SIGNATURES)
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  If libgpemu
+    pulled in the system copy first, a later ``import torch`` would bring a second HIP runtime into the
+    process and see no GPUs.  Loading torch's copy first (by path, without importing torch) makes the
+    loader satisfy libgpemu's libamdhip64.so.7 dependency with it, so both share one runtime."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass   # fall back to the system ROCm runtime
+
+
 def lib():
     """Load libgpemu.so once; raise if it has not been built."""
     global _lib
     if _lib is None:
+        _preload_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise GpemuError(-100, f"{LIB_PATH} not found: build it with "
                                    "`python -c 'import __graft_entry__ as g; g.build()'` "

@@ -61,6 +61,35 @@ def build_workload(device=0):
                 cun=cun)
 
 
+def measure_predict(dm, n_samples=1024, reps=5):
+    """Metric 2 (BASELINE.json): emulation.predict throughput with outputs resident in HBM.
+    Algorithmic bytes: 8 (B F^2 + B F) out + 8 [k N (N+1)/2 + k N + N d + B d + F k + 2 F + F^2] in."""
+    import torch
+    from gpemu import synthetic
+    B, F, k, N, d = n_samples, dm.F, dm.k, dm.N, dm.d
+    dev = torch.device("cuda", dm.device)
+    X = torch.from_numpy(synthetic.make_walkers(B, seed=2)).to(dev)
+    cv = torch.empty((B, F), dtype=torch.float64, device=dev)
+    cov = torch.empty((B, F, F), dtype=torch.float64, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        dm.predict_full_dev(X.data_ptr(), B, float(B), cv.data_ptr(), cov.data_ptr(), stream=st.cuda_stream)
+        st.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            dm.predict_full_dev(X.data_ptr(), B, float(B), cv.data_ptr(), cov.data_ptr(), stream=st.cuda_stream)
+        e1.record(st)
+        st.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = 8 * (B * F * F + B * F) + 8 * (k * N * (N + 1) // 2 + k * N + N * d + B * d + F * k + 2 * F + F * F)
+    return {"metric": "GP predict GB/s (emulation.predict, full covariance, outputs in HBM)",
+            "value": nbytes / (ms * 1e-3) / 1e9, "unit": "GB/s", "samples_per_s": B / (ms * 1e-3),
+            "batch": B, "ms_per_batch": ms, "algorithmic_bytes": nbytes,
+            "roofline": {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0}}
+
+
 def committed_traffic(world):
     """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied).
@@ -203,6 +232,13 @@ def main():
                     "avg_launch_us": avg_s * 1e6, "launches": n_launch,
                     "kstar_avg_launch_us": prof["kstar"][0] / max(prof["kstar"][1], 1) * 1e3}
 
+    predict = None
+    if rank == 0:
+        try:
+            predict = measure_predict(dm)
+        except Exception as e:
+            predict = {"value": None, "error": repr(e)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -221,7 +257,7 @@ def main():
                           "n_walkers": N_WALKERS, "evals_per_step": N_WALKERS,
                           "parallelism": f"walkers sharded over {world} GPU(s)"},
                "acceptance_fraction_mean": float((nacc / max(iters, 1)).mean()),
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "cpu_baseline": cpu, "gp_predict": predict}
         print(json.dumps(out), flush=True)
     ds.close()
     dm.close()

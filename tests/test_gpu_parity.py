@@ -187,3 +187,18 @@ def test_argument_errors():
     with pytest.raises(ValueError):
         dm.gp_predict(np.zeros((3, 5)))
     dm.close()
+
+
+def test_one_hip_runtime_with_torch_imported_after_the_library():
+    """libgpemu loaded first must not leave the process with two HIP runtimes (torch bundles its own
+    libamdhip64): torch imported afterwards still sees the GPU."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from gpemu import _lib; n = _lib.device_count(); "
+            "import torch; print(n, int(torch.cuda.is_available()))" % os.path.join(root, "bayesian-inference_amd"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    n, ok = out.stdout.strip().splitlines()[-1].split()
+    assert int(n) >= 1 and int(ok) == 1
