@@ -250,7 +250,7 @@ int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int6
     rc = dev_alloc(&sA, N64 * N64);
     if (rc == GPEMU_OK) rc = dev_alloc(&sD, N64 * 64);
     if (rc == GPEMU_OK) rc = dev_alloc(&sW, N64 * N64);
-    if (rc == GPEMU_OK) rc = dev_alloc(&sT, 64 * N64);
+    if (rc == GPEMU_OK) rc = dev_alloc(&sT, N64 * N64);
     if (rc == GPEMU_OK && hipMemsetAsync(m->Wt, 0, sizeof(double) * (size_t)(k * Np * Np), st) != hipSuccess) {
       set_error("hipMemsetAsync failed");
       rc = GPEMU_ERR_HIP;

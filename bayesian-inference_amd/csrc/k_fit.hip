@@ -62,48 +62,55 @@ __global__ void kmat_kernel(const double *__restrict__ X, const double *__restri
 }
 
 // ---- 64 x 64 diagonal block: Cholesky + inverse ------------------------------------------------
-// One wave, lane = row.  do_factor = 0: the block already holds the factor (only invert).
-__global__ __launch_bounds__(64) void potrf_diag_kernel(double *A, int64_t lda, double *Dinv, int do_factor,
-                                                        int block_index, int *info) {
+// 256 threads, block in LDS.  Factorisation: per column one pivot, a column scale (64 threads) and the
+// rank-1 update of the trailing triangle spread over all 256 threads (thread = row, column phase).
+// Inverse X = L^-1: wave 0, lane = column of X, forward substitution with L read from LDS (broadcast)
+// and the X column held in registers.  do_factor = 0: the block already holds the factor.
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda, double *Dinv, int do_factor,
+                                                         int block_index, int *info) {
   __shared__ double D[NB][NB + 1];
-  __shared__ double Inv[NB][NB + 1];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   double *Ab = A + ((int64_t)blockIdx.x * NB) * lda + (int64_t)blockIdx.x * NB;
   double *Db = Dinv + (int64_t)blockIdx.x * NB * NB;
-  for (int c = 0; c < NB; ++c) D[lane][c] = (c <= lane) ? Ab[(int64_t)lane * lda + c] : 0.0;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    D[r][c] = (c <= r) ? Ab[(int64_t)r * lda + c] : 0.0;
+  }
+  __syncthreads();
   if (do_factor) {
+    const int i = tid >> 2, q = tid & 3;   // row, column phase of the trailing update
     for (int j = 0; j < NB; ++j) {
-      double piv = D[j][j];
-      if (!(piv > 0.0) && lane == 0 && info && *info == 0) *info = (block_index + (int)blockIdx.x) * NB + j + 1;
-      piv = sqrt(piv);
-      __builtin_amdgcn_wave_barrier();
-      if (lane == j) D[j][j] = piv;
-      if (lane > j) D[lane][j] = D[lane][j] / piv;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (lane > j) {
-        const double lij = D[lane][j];
-        for (int c = j + 1; c <= lane; ++c) D[lane][c] -= lij * D[c][j];
+      const double piv2 = D[j][j];
+      if (!(piv2 > 0.0) && tid == 0 && info && *info == 0) *info = (block_index + (int)blockIdx.x) * NB + j + 1;
+      const double piv = sqrt(piv2);
+      __syncthreads();                       // everyone has read the pivot
+      if (tid == j) D[j][j] = piv;
+      if (tid > j && tid < NB) D[tid][j] = D[tid][j] / piv;
+      __syncthreads();
+      if (i > j) {
+        const double lij = D[i][j];
+        for (int c = j + 1 + q; c <= i; c += 4) D[i][c] = fma(-lij, D[c][j], D[i][c]);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      __syncthreads();
     }
-    for (int c = 0; c < NB; ++c) Ab[(int64_t)lane * lda + c] = (c <= lane) ? D[lane][c] : 0.0;
-  }
-  // inverse: lane = column c of Inv; solve D x = e_c by forward substitution
-  {
-    const int c = lane;
-    for (int i = 0; i < NB; ++i) {
-      double s = (i == c) ? 1.0 : 0.0;
-      for (int mm = c; mm < i; ++mm) s = fma(-D[i][mm], Inv[mm][c], s);
-      Inv[i][c] = (i >= c) ? s / D[i][i] : 0.0;
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      Ab[(int64_t)r * lda + c] = D[r][c];    // zeros above the diagonal
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  for (int c = 0; c < NB; ++c) Db[lane * NB + c] = Inv[lane][c];
+  if (tid < NB) {
+    const int c = tid;
+    double inv[NB];
+#pragma unroll
+    for (int ii = 0; ii < NB; ++ii) {
+      double sacc = (ii == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int mm = 0; mm < ii; ++mm) sacc = fma(-D[ii][mm], inv[mm], sacc);   // uniform LDS address: broadcast
+      inv[ii] = (ii >= c) ? sacc / D[ii][ii] : 0.0;
+    }
+#pragma unroll
+    for (int ii = 0; ii < NB; ++ii) Db[ii * NB + c] = inv[ii];
+  }
 }
 
 __global__ void copy_block_kernel(const double *__restrict__ src, int64_t lds, double *__restrict__ dst,
@@ -129,7 +136,7 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, double *Pbuf, i
   for (int jb = 0; jb < nblk; ++jb) {
     const int64_t j0 = (int64_t)jb * NB;
     double *Ajj = A + j0 * Np + j0;
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, st, Ajj, Np, Dinv + (int64_t)jb * NB * NB, 1, jb, dinfo);
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, Ajj, Np, Dinv + (int64_t)jb * NB * NB, 1, jb, dinfo);
     GP_HIP(hipGetLastError());
     const int M = (int)(Np - j0 - NB);
     if (M <= 0) break;
@@ -153,29 +160,47 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, double *Pbuf, i
 }
 
 // W = L^-1 (lower, Np x Np, zero above the diagonal) from L (lower triangle of `L`, ld Np) and the
-// inverted diagonal blocks.  T is a [64][Np] scratch.
+// inverted 64 x 64 diagonal blocks.  Bottom-up merging: blocks of size b are already inverted on the
+// diagonal of W; a pair (W11, W22) becomes inv([[L11,0],[L21,L22]]) by  W21 = -W22 (L21 W11),
+// two GEMMs per level, batched over all pairs (blockIdx.z), so the whole inverse takes
+// 2 log2(Np/64) (+ ragged-tail) launches of large MFMA GEMMs.  T is an Np x Np scratch.
 int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double *W, double *T, hipStream_t st) {
   const int nblk = (int)(Np / NB);
   GP_HIP(hipMemsetAsync(W, 0, sizeof(double) * (size_t)(Np * Np), st));
+  // diagonal blocks: Dinv [nblk][64][64] -> W
   for (int ib = 0; ib < nblk; ++ib) {
-    const int64_t i0 = (int64_t)ib * NB;
-    int rc = copy_block(Dinv + (int64_t)ib * NB * NB, NB, W + i0 * Np + i0, Np, NB, NB, 1.0, st);
+    int rc = copy_block(Dinv + (int64_t)ib * NB * NB, NB, W + ((int64_t)ib * NB) * Np + (int64_t)ib * NB, Np, NB, NB, 1.0, st);
     if (rc != GPEMU_OK) return rc;
-    if (ib == 0) continue;
-    GemmArgs g;   // T = L[i, 0:i0] . W[0:i0, 0:i0]
-    g.A = L + i0 * Np; g.lda = Np;
-    g.B = W; g.ldb = Np;
-    g.C = T; g.ldc = Np;
-    g.M = NB; g.N = (int)i0; g.K = (int)i0;
-    rc = launch_gemm(g, false, true, 1, st);
-    if (rc != GPEMU_OK) return rc;
-    GemmArgs h;   // W[i, 0:i0] = -inv(L_ii) . T
-    h.A = Dinv + (int64_t)ib * NB * NB; h.lda = NB;
-    h.B = T; h.ldb = Np;
-    h.C = W + i0 * Np; h.ldc = Np;
-    h.M = NB; h.N = (int)i0; h.K = NB; h.alpha = -1.0;
-    rc = launch_gemm(h, false, true, 1, st);
-    if (rc != GPEMU_OK) return rc;
+  }
+  for (int64_t b = NB; b < Np; b *= 2) {
+    // pairs start at p0 = 2 b t; first block [p0, p0 + b), second [p0 + b, min(p0 + 2b, Np))
+    const int64_t nfull = Np / (2 * b);                      // pairs whose second block is complete
+    const int64_t rem = Np - nfull * 2 * b;                  // leftover rows after the full pairs
+    auto merge = [&](int64_t p0, int64_t b2, int batch) -> int {
+      // T21 = L21 . W11   (b2 x b) = (b2 x b) (b x b)
+      GemmArgs g;
+      g.A = L + (p0 + b) * Np + p0; g.lda = Np; g.strideA = 2 * b * Np + 2 * b;
+      g.B = W + p0 * Np + p0; g.ldb = Np; g.strideB = 2 * b * Np + 2 * b;
+      g.C = T + (p0 + b) * Np + p0; g.ldc = Np; g.strideC = 2 * b * Np + 2 * b;
+      g.M = (int)b2; g.N = (int)b; g.K = (int)b;
+      int rc = launch_gemm(g, false, true, batch, st);
+      if (rc != GPEMU_OK) return rc;
+      // W21 = -W22 . T21  (b2 x b) = (b2 x b2) (b2 x b)
+      GemmArgs h;
+      h.A = W + (p0 + b) * Np + (p0 + b); h.lda = Np; h.strideA = 2 * b * Np + 2 * b;
+      h.B = T + (p0 + b) * Np + p0; h.ldb = Np; h.strideB = 2 * b * Np + 2 * b;
+      h.C = W + (p0 + b) * Np + p0; h.ldc = Np; h.strideC = 2 * b * Np + 2 * b;
+      h.M = (int)b2; h.N = (int)b; h.K = (int)b2; h.alpha = -1.0;
+      return launch_gemm(h, false, true, batch, st);
+    };
+    if (nfull > 0) {
+      int rc = merge(0, b, (int)nfull);
+      if (rc != GPEMU_OK) return rc;
+    }
+    if (rem > b) {                                           // a ragged pair: (b, rem - b)
+      int rc = merge(nfull * 2 * b, rem - b, 1);
+      if (rc != GPEMU_OK) return rc;
+    }
   }
   return GPEMU_OK;
 }
@@ -328,12 +353,12 @@ __global__ void pad_lower_kernel(const double *__restrict__ L, int N, double *__
 }
 
 // W = L^-1 of one N x N lower factor (device pointer, ld N) written transposed into Wt (ld Npad).
-// scratch: A [Np*Np], Dinv [Np*64], W [Np*Np], T [64*Np]
+// scratch: A [Np*Np], Dinv [Np*64], W [Np*Np], T [Np*Np]
 int device_invert_factor_to_Wt(const double *dL, int64_t N, double *Wt, int64_t Npad, double *A, double *Dinv,
                                double *W, double *T, hipStream_t st) {
   const int64_t Np = round_up(N, NB);
   hipLaunchKernelGGL(pad_lower_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)Np), dim3(256), 0, st, dL, (int)N, A, (int)Np);
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3((unsigned)(Np / NB)), dim3(64), 0, st, A, Np, Dinv, 0, 0, (int *)nullptr);
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3((unsigned)(Np / NB)), dim3(256), 0, st, A, Np, Dinv, 0, 0, (int *)nullptr);
   GP_HIP(hipGetLastError());
   int rc = device_trtri_blocked(A, Np, Dinv, W, T, st);
   if (rc != GPEMU_OK) return rc;
@@ -448,7 +473,7 @@ int gpemu_fit_create(gpemu_fit **out, int device, int64_t N, int64_t d, const do
   hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
   auto A = [&](double **p, int64_t n) { if (e == hipSuccess) e = hipMalloc((void **)p, sizeof(double) * (size_t)(n > 0 ? n : 1)); };
   A(&f->X, Np * DPAD); A(&f->hp, DPAD + 2); A(&f->K, Np * Np); A(&f->Pbuf, Np * NB); A(&f->Dinv, Np * NB);
-  A(&f->W, Np * Np); A(&f->T, NB * Np); A(&f->Kinv, Np * Np); A(&f->y, Np); A(&f->v, Np); A(&f->alpha, Np);
+  A(&f->W, Np * Np); A(&f->T, Np * Np); A(&f->Kinv, Np * Np); A(&f->y, Np); A(&f->v, Np); A(&f->alpha, Np);
   A(&f->gpart, (int64_t)f->n_gparts * NTH_MAX); A(&f->scal, 4); A(&f->grad, NTH_MAX);
   if (e == hipSuccess) e = hipMalloc((void **)&f->info, sizeof(int));
   std::vector<double> hX((size_t)(Np * DPAD), 0.0);

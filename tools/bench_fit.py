@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Fit-side stress (BASELINE configs[4], "C5"): N_design = 5000 (and 1000): one log-marginal-likelihood
+evaluation = kernel matrix + blocked Cholesky (MFMA SYRK) + blocked triangular inverse + alpha
+(+ K^-1 = W^T W and the gradient contraction).  Reports wall time and FLOP rates against the fp64 peak."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "bayesian-inference_amd"))
+import numpy as np  # noqa: E402
+
+from gpemu import synthetic  # noqa: E402
+from gpemu.fit import DeviceFit  # noqa: E402
+
+PEAK = 78.6e12
+for N in [int(a) for a in (sys.argv[1:] or ["1000", "5000"])]:
+    prob = synthetic.make_problem(N, 8, seed=0)
+    X = prob["design"]
+    y = prob["Y"][:, 0] - prob["Y"][:, 0].mean()
+    theta = np.log(np.r_[(prob["hi"] - prob["lo"]) * 0.5, 0.05])
+    fit = DeviceFit(X, kernel_kind=0, has_noise=True, jitter=1e-10)
+    for grad in (False, True):
+        fit.lml(y, theta, eval_gradient=grad)
+        reps = 5 if N <= 2000 else 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fit.lml(y, theta, eval_gradient=grad)
+        dt = (time.perf_counter() - t0) / reps
+        flop = N ** 3 / 3 + N ** 3 / 3 + (2 * N ** 3 if grad else 0)      # chol + trtri (+ W^T W full GEMM)
+        print(f"N={N} grad={int(grad)}: {dt * 1e3:8.2f} ms per LML evaluation, "
+              f"{flop / dt / 1e12:6.2f} TFLOP/s ({flop / dt / PEAK:.3f} of fp64 peak)  lml={out[0] if grad else out:.6f}")
+    fit.close()
