@@ -54,13 +54,13 @@ int ensure_workspace(gpemu_model *m, int64_t B) {
   const int64_t k = m->k;
   GP_TRY(dev_alloc(&w.Xq, need * DPAD));
   GP_TRY(dev_alloc(&w.KS, k * m->Npad * need));
-  GP_TRY(dev_alloc(&w.mean_part, k * (m->Npad / JCHUNK) * need));
-  GP_TRY(dev_alloc(&w.vsq_part, k * m->vsq_nrb * need));
+  GP_TRY(dev_alloc(&w.mean_part, k * (m->Npad / 32) * need));   // sized for the 32-row small-batch form
+  GP_TRY(dev_alloc(&w.vsq_part, k * (m->Npad / 32) * need));   // sized for the 32-row small-batch form
   GP_TRY(dev_alloc(&w.mean, need * k));
   GP_TRY(dev_alloc(&w.var, need * k));
   GP_TRY(dev_alloc(&w.logp, need));
   GP_HIP(hipMemsetAsync(w.KS, 0, sizeof(double) * (size_t)(k * m->Npad * need), m->stream));
-  GP_HIP(hipMemsetAsync(w.vsq_part, 0, sizeof(double) * (size_t)(k * m->vsq_nrb * need), m->stream));
+  GP_HIP(hipMemsetAsync(w.vsq_part, 0, sizeof(double) * (size_t)(k * (m->Npad / 32) * need), m->stream));
   w.Bcap = need;
   return GPEMU_OK;
 }

@@ -43,11 +43,13 @@ struct Workspace {
   int64_t Bcap = 0;            // padded batch capacity (multiple of TILE)
   double *Xq = nullptr;        // [Bcap][DPAD]   query points (padded with 0)
   double *KS = nullptr;        // [k][Npad][Bcap] cross-kernel K_*^T per PC
-  double *mean_part = nullptr; // [Bcap][k][nchunk] partial K_* . alpha per 128-row chunk
-  double *vsq_part = nullptr;  // [Bcap][k][nrb]    partial ||W k_*||^2 per 64-row block
+  double *mean_part = nullptr; // [Bcap][k][nchunk] partial K_* . alpha per 128- (or 32-) row chunk
+  double *vsq_part = nullptr;  // [Bcap][k][nrb]    partial ||W k_*||^2 per 64- (or 32-) row block
   double *mean = nullptr;      // [Bcap][k]
   double *var = nullptr;       // [Bcap][k]
   double *logp = nullptr;      // [Bcap]
+  int cur_nrb = 0;             // row blocks of vsq_part written by the last triangular GEMM launch
+  int cur_nchunk = 0;          // row chunks of mean_part written by the last kstar launch
 };
 
 }  // namespace gpemu

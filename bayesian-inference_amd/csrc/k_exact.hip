@@ -299,7 +299,7 @@ int launch_loglik_exact(gpemu_model *m, int64_t B, const double *dXq, double *do
   hipLaunchKernelGGL(loglik_exact_kernel, dim3((unsigned)nwg), dim3(CHOL_THREADS), 0, st, dXq, m->lo,
                      m->hi, w.mean_part, w.vsq_part, m->kdiag, m->comp, m->smean, m->sscale,
                      m->cunexpl, m->yexp, m->yerr, m->blk_of, m->exact_scratch, dout, B, w.Bcap, (int)m->d,
-                     F, (int)m->k, (int)(m->Npad / JCHUNK), (int)m->vsq_nrb, 1.0 / m->n_div);
+                     F, (int)m->k, w.cur_nchunk, w.cur_nrb, 1.0 / m->n_div);
   GP_HIP(hipGetLastError());
   return GPEMU_OK;
 }

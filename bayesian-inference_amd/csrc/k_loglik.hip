@@ -296,7 +296,7 @@ int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq, double *
 #define GP_LAUNCH_LL(KM)                                                                            \
   hipLaunchKernelGGL(loglik_lowrank_kernel<KM>, grid, block, 0, st, dXq, m->lo, m->hi, w.mean_part,  \
                      w.vsq_part, m->kdiag, m->G, m->g0, m->scal, dout, w.mean, w.var, B, w.Bcap,     \
-                     (int)m->d, k, (int)(m->Npad / JCHUNK), (int)m->vsq_nrb, (int)m->nblk, accumulate, a)
+                     (int)m->d, k, w.cur_nchunk, w.cur_nrb, (int)m->nblk, accumulate, a)
   if (k <= 16) {
     GP_LAUNCH_LL(16);
   } else {
@@ -306,7 +306,7 @@ int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq, double *
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL(loglik_lowrank_lds_kernel, grid, block, shm, st, dXq, m->lo, m->hi, w.mean_part,
                        w.vsq_part, m->kdiag, m->G, m->g0, m->scal, dout, w.mean, w.var, B, w.Bcap,
-                       (int)m->d, k, (int)(m->Npad / JCHUNK), (int)m->vsq_nrb, (int)m->nblk, accumulate, a);
+                       (int)m->d, k, w.cur_nchunk, w.cur_nrb, (int)m->nblk, accumulate, a);
   }
 #undef GP_LAUNCH_LL
   GP_HIP(hipGetLastError());

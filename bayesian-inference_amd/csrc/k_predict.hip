@@ -53,7 +53,7 @@ __device__ __forceinline__ double base_kernel(double r2) {
 }
 
 // grid (Bcap/64, Npad/JCHUNK, k), block 256: lane <-> query b, wave <-> 32 training rows.
-template <int KIND>
+template <int KIND, int RPW>   // RPW = training rows per wave (32: large batches; 8: small batches, 4x the workgroups)
 __global__ __launch_bounds__(256) void kstar_kernel(
     double *__restrict__ Xq, const double *__restrict__ Xs, const double *__restrict__ ls,
     const double *__restrict__ constv, const double *__restrict__ alpha, double *__restrict__ KS,
@@ -94,13 +94,13 @@ __global__ __launch_bounds__(256) void kstar_kernel(
   }
   const double c = has_const ? constv[p] : 0.0;
 
-  const int64_t jbase = (int64_t)chunk * JCHUNK + wave * (JCHUNK / 4);
+  const int64_t jbase = (int64_t)chunk * (4 * RPW) + wave * RPW;
   const double *xs = Xs + ((int64_t)p * Npad + jbase) * DPAD;
   const double *al = alpha + (int64_t)p * Npad + jbase;
   double *ks = KS + ((int64_t)p * Npad + jbase) * Bcap + b;
   double macc = 0.0;
 #pragma unroll 4
-  for (int jj = 0; jj < JCHUNK / 4; ++jj) {
+  for (int jj = 0; jj < RPW; ++jj) {
     double r2 = 0.0;
 #pragma unroll
     for (int dd = 0; dd < DPAD; ++dd) {
@@ -125,14 +125,23 @@ int launch_kstar(gpemu_model *m, int64_t B, double *dXq, hipStream_t st, const P
   const ProposeArgs pargs = pa ? *pa : ProposeArgs();
   // only the column tiles that hold real queries; the rows of dXq up to round_up(B, TILE) must be
   // finite (pad_queries_kernel / the sampler's proposal buffer zero them)
-  const Workspace &w = m->ws;
-  dim3 grid((unsigned)(round_up(B, TILE) / 64), (unsigned)(m->Npad / JCHUNK), (unsigned)m->k), block(256);
+  Workspace &w = m->ws;
+  const bool small = B <= 256;                       // few columns: more, shorter workgroups
+  const int rows_per_wg = small ? 32 : JCHUNK;
+  w.cur_nchunk = (int)(m->Npad / rows_per_wg);
+  dim3 grid((unsigned)(round_up(B, TILE) / 64), (unsigned)w.cur_nchunk, (unsigned)m->k), block(256);
   const int pe0 = prof_mark(m, st);
   int kind = 0;
   if (m->kernel_kind == GPEMU_KERNEL_MATERN) kind = (m->nu == 0.5) ? 1 : (m->nu == 1.5 ? 2 : 3);
-#define GP_LAUNCH_KSTAR(KD)                                                                      \
-  hipLaunchKernelGGL(kstar_kernel<KD>, grid, block, 0, st, dXq, m->Xs, m->ls, m->constv, m->alpha, \
-                     w.KS, w.mean_part, m->N, m->Npad, w.Bcap, m->has_const, pargs)
+#define GP_LAUNCH_KSTAR(KD)                                                                              \
+  do {                                                                                                   \
+    if (small)                                                                                           \
+      hipLaunchKernelGGL((kstar_kernel<KD, 8>), grid, block, 0, st, dXq, m->Xs, m->ls, m->constv, m->alpha, \
+                         w.KS, w.mean_part, m->N, m->Npad, w.Bcap, m->has_const, pargs);                  \
+    else                                                                                                 \
+      hipLaunchKernelGGL((kstar_kernel<KD, 32>), grid, block, 0, st, dXq, m->Xs, m->ls, m->constv, m->alpha, \
+                         w.KS, w.mean_part, m->N, m->Npad, w.Bcap, m->has_const, pargs);                  \
+  } while (0)
   switch (kind) {
     case 0: GP_LAUNCH_KSTAR(0); break;
     case 1: GP_LAUNCH_KSTAR(1); break;
@@ -465,6 +474,137 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_persistent_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Small-batch form (B <= 256 per launch: a rank's slice of the proposing half on a multi-GPU run).
+// With few columns the 64 x 128 items are too few and too long (the longest, full-K item alone takes
+// ~80 us), so here an item is 32 rows x 64 columns and its K range is split four ways INSIDE the
+// workgroup: 8 waves = 4 K-slices x 2 column halves, each wave 32 x 32.  Slice s takes the k-tiles
+// t = s, s+4, ...; after the K loop the four partial V tiles are summed through LDS, squared and
+// column-summed.  Partials are per 32-row block (nrb = Npad / 32).
+constexpr int SB_TM = 32, SB_TN = 64, SB_KT = 16, SB_SL = 4;
+constexpr int SB_STRA = 48;   // (2 * 48) % 64 == 32
+constexpr int SB_STRB = 80;
+
+__global__ __launch_bounds__(512, 2) void trmm_vsq_smallb_kernel(const double *__restrict__ Wt,
+                                                                 const double *__restrict__ KS,
+                                                                 double *__restrict__ out, int64_t Npad,
+                                                                 int64_t Bcap, int k, int nrb, int ncb) {
+  // staging: [buf][slice][k][m or n]; reused as the reduction buffer [slice][32][64] at the end
+  __shared__ __attribute__((aligned(16))) double sA[2][SB_SL][SB_KT][SB_STRA];
+  __shared__ __attribute__((aligned(16))) double sB[2][SB_SL][SB_KT][SB_STRB];
+  const int ncombo = k * ncb;
+  const int rbi = blockIdx.x / ncombo;
+  const int combo = blockIdx.x - rbi * ncombo;
+  const int p = combo / ncb;
+  const int cb = combo - p * ncb;
+  const int rb = nrb - 1 - rbi;   // long K first
+  const int64_t i0 = (int64_t)rb * SB_TM, b0 = (int64_t)cb * SB_TN;
+  const int ntile = (int)((i0 + SB_TM + SB_KT - 1) / SB_KT);
+  const int nround = (ntile + SB_SL - 1) / SB_SL;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, ksl = wave >> 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  // staging per round: A 4 x (16 x 32) doubles = 1024 d2 (2 per thread), B 4 x (16 x 64) = 2048 d2 (4 per thread)
+  //   A: idx = tid + 512 r: slice = idx >> 8, row = (idx >> 4) & 15, c2 = idx & 15
+  //   B: idx = tid + 512 r: slice = idx >> 9, row = (idx >> 5) & 15, c2 = idx & 31
+  const double *Ab = Wt + (int64_t)p * Npad * Npad + i0;
+  const double *Bb = KS + (int64_t)p * Npad * Bcap + b0;
+  d2 ra[2], rbv[4];
+  auto gload = [&](int round) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int idx = tid + 512 * r, sl = idx >> 8, row = (idx >> 4) & 15, c2 = idx & 15;
+      int t = round * SB_SL + sl;
+      if (t >= ntile) t = ntile - 1;   // harmless re-read; the slice skips its MFMAs
+      ra[r] = *reinterpret_cast<const d2 *>(Ab + (int64_t)(t * SB_KT + row) * Npad + 2 * c2);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = tid + 512 * r, sl = idx >> 9, row = (idx >> 5) & 15, c2 = idx & 31;
+      int t = round * SB_SL + sl;
+      if (t >= ntile) t = ntile - 1;
+      rbv[r] = *reinterpret_cast<const d2 *>(Bb + (int64_t)(t * SB_KT + row) * Bcap + 2 * c2);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int idx = tid + 512 * r, sl = idx >> 8, row = (idx >> 4) & 15, c2 = idx & 15;
+      *reinterpret_cast<d2 *>(&sA[buf][sl][row][2 * c2]) = ra[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = tid + 512 * r, sl = idx >> 9, row = (idx >> 5) & 15, c2 = idx & 31;
+      *reinterpret_cast<d2 *>(&sB[buf][sl][row][2 * c2]) = rbv[r];
+    }
+  };
+
+  d4 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int round = 0; round < nround; ++round) {
+    const int buf = round & 1;
+    if (round + 1 < nround) gload(round + 1);
+    if (round * SB_SL + ksl < ntile) {
+#pragma unroll
+      for (int ks = 0; ks < SB_KT / 4; ++ks) {
+        double a[2], b[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) a[mi] = sA[buf][ksl][ks * 4 + lk][mi * 16 + lr];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) b[ni] = sB[buf][ksl][ks * 4 + lk][wn * 32 + ni * 16 + lr];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    if (round + 1 < nround) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  // sum the four K-slices: V[row][col] through LDS (reuse sB: 4 x 32 x 64 doubles = 64 KiB <= sizeof(sB))
+  double *red = &sB[0][0][0][0];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        red[(ksl * SB_TM + mi * 16 + lk + 4 * r) * SB_TN + wn * 32 + ni * 16 + lr] = acc[mi][ni][r];
+  __syncthreads();
+  // 512 threads: thread -> (column c = tid & 63, row group g = tid >> 6 of 4 rows)
+  {
+    const int c = tid & 63, g = tid >> 6;
+    double sq = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = g * 4 + rr;
+      const double v = (red[(0 * SB_TM + row) * SB_TN + c] + red[(1 * SB_TM + row) * SB_TN + c]) +
+                       (red[(2 * SB_TM + row) * SB_TN + c] + red[(3 * SB_TM + row) * SB_TN + c]);
+      sq = fma(v, v, sq);
+    }
+    double *colsum = &sA[0][0][0][0];   // [8][64]
+    colsum[g * 64 + c] = sq;
+    __syncthreads();
+    if (tid < 64) {
+      double tot = 0.0;
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) tot += colsum[gg * 64 + tid];
+      out[((b0 + tid) * k + p) * nrb + rb] = tot;
+    }
+  }
+}
+
 // host side: LPT schedule of the items of one launch shape (cached per model and column-tile count)
 static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &flat, std::vector<int> &cnt,
                                 int &max_items, int &nworkers) {
@@ -507,7 +647,20 @@ static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &
 }
 
 int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
-  const Workspace &w = m->ws;
+  Workspace &w = m->ws;
+  static const int smallb_max = getenv("GPEMU_SMALLB_MAX") ? atoi(getenv("GPEMU_SMALLB_MAX")) : 256;
+  if (B <= smallb_max) {   // small batch: 32 x 64 items with the K range split inside the workgroup
+    const int nrb32 = (int)(m->Npad / SB_TM);
+    const int ncb64 = (int)(round_up(B, SB_TN) / SB_TN);
+    w.cur_nrb = nrb32;
+    const int pe0s = prof_mark(m, st);
+    hipLaunchKernelGGL(trmm_vsq_smallb_kernel, dim3((unsigned)(nrb32 * (int)m->k * ncb64)), dim3(512), 0, st, m->Wt,
+                       w.KS, w.vsq_part, m->Npad, w.Bcap, (int)m->k, nrb32, ncb64);
+    GP_HIP(hipGetLastError());
+    prof_pair(m, 0, pe0s, prof_mark(m, st));
+    return GPEMU_OK;
+  }
+  w.cur_nrb = (int)m->vsq_nrb;
   const int nrb = (int)m->vsq_nrb;
   const int ncb = (int)(round_up(B, TILE) / TILE);  // only the column tiles that hold real queries
   static const bool use_simple = getenv("GPEMU_TRMM_SIMPLE") != nullptr;
@@ -595,7 +748,7 @@ int launch_reduce_mean_var(gpemu_model *m, int64_t B, double *dmean, double *dva
   int64_t n = B * m->k;
   hipLaunchKernelGGL(reduce_mean_var_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                      w.mean_part, w.vsq_part, m->kdiag, dmean, dvar, B, w.Bcap, (int)m->k,
-                     (int)(m->Npad / JCHUNK), (int)m->vsq_nrb);
+                     w.cur_nchunk, w.cur_nrb);
   GP_HIP(hipGetLastError());
   return GPEMU_OK;
 }

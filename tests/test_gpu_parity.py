@@ -169,12 +169,14 @@ def test_large_batch_is_chunked():
     dm.likelihood_setup(g["y_exp"], g["y_err"], g["lo"], g["hi"], 1.0)
     X = synthetic.make_walkers(5000, seed=11, lo=g["lo"], hi=g["hi"])
     lp = dm.logpost(X)
+    # same kernel path (> 256 rows per pass): bit-identical; the small-batch kernel sums its partial
+    # ||W k_*||^2 in a different order, so against it the agreement is to rounding
     np.testing.assert_array_equal(lp[:300], dm.logpost(X[:300]))
-    np.testing.assert_array_equal(lp[4090:4200], dm.logpost(X[4090:4200]))
+    np.testing.assert_allclose(lp[4090:4200], dm.logpost(X[4090:4200]), rtol=1e-12)
     m, v = dm.gp_predict(X)
     m2, v2 = dm.gp_predict(X[2040:2060])
-    np.testing.assert_array_equal(m[2040:2060], m2)
-    np.testing.assert_array_equal(v[2040:2060], v2)
+    np.testing.assert_allclose(m[2040:2060], m2, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(v[2040:2060], v2, rtol=1e-12, atol=1e-15)
     dm.close()
 
 
