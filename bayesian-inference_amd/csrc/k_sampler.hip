@@ -150,46 +150,40 @@ __global__ void build_sets_kernel(const int *inds, int *idx, int W) {
   }
 }
 
-__global__ void propose_kernel(const double *__restrict__ X, const int *__restrict__ idx_s,
-                               const int *__restrict__ idx_c, const double *__restrict__ zz,
-                               const int *__restrict__ rint, double *__restrict__ q,
-                               double *__restrict__ factors, int ns, int d) {
+// accept / reject of one half with log-probabilities gathered from all ranks.  The proposal is
+// recomputed from the ensemble (the complementary set is unchanged during this half), so no rank
+// needs the other ranks' proposal rows; optionally records the chain row of its walkers.
+__global__ void accept_kernel(double *__restrict__ X, double *__restrict__ logp,
+                              const int *__restrict__ idx_s, const int *__restrict__ idx_c,
+                              const double *__restrict__ zz, const int *__restrict__ rint,
+                              const double *__restrict__ newlp, const double *__restrict__ logu,
+                              long long *__restrict__ naccept, int *__restrict__ flags, int ns, int d,
+                              double *__restrict__ chain, double *__restrict__ lpchain) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ns) return;
   const int w = idx_s[i], j = idx_c[rint[i]];
   const double z = zz[i];
-#pragma unroll
-  for (int dd = 0; dd < DPAD; ++dd) {
-    double cj = X[j * DPAD + dd], sw = X[w * DPAD + dd];
-    q[i * DPAD + dd] = (dd < d) ? cj - (cj - sw) * z : 0.0;   // emcee moves/stretch.py get_proposal
-  }
-  factors[i] = (d - 1.0) * log(z);
-}
-
-__global__ void accept_kernel(double *__restrict__ X, double *__restrict__ logp,
-                              const int *__restrict__ idx_s, const double *__restrict__ q,
-                              const double *__restrict__ factors, const double *__restrict__ newlp,
-                              const double *__restrict__ logu, long long *__restrict__ naccept,
-                              int *__restrict__ flags, int ns) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ns) return;
-  const int w = idx_s[i];
   const double nlp = newlp[i];
   if (nlp != nlp) atomicAdd(flags, 1);  // emcee raises on NaN log-probability
-  const double lnpdiff = factors[i] + nlp - logp[w];
-  if (lnpdiff > logu[i]) {
+  const double oldlp = logp[w];
+  const double lnpdiff = (d - 1.0) * log(z) + nlp - oldlp;
+  const bool acc = lnpdiff > logu[i];
 #pragma unroll
-    for (int dd = 0; dd < DPAD; ++dd) X[w * DPAD + dd] = q[i * DPAD + dd];
+  for (int dd = 0; dd < DPAD; ++dd) {
+    const double sw = X[w * DPAD + dd];
+    double v = sw;
+    if (acc && dd < d) {
+      const double cj = X[j * DPAD + dd];
+      v = cj - (cj - sw) * z;              // emcee moves/stretch.py get_proposal
+      X[w * DPAD + dd] = v;
+    }
+    if (chain && dd < d) chain[(int64_t)w * d + dd] = v;
+  }
+  if (acc) {
     logp[w] = nlp;
     naccept[w] += 1;
   }
-}
-
-__global__ void record_kernel(const double *__restrict__ X, const double *__restrict__ logp,
-                              double *__restrict__ chain, double *__restrict__ lpchain, int W, int d) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < W * d) chain[idx] = X[(idx / d) * DPAD + idx % d];
-  if (idx < W) lpchain[idx] = logp[idx];
+  if (lpchain) lpchain[w] = acc ? nlp : oldlp;
 }
 
 __global__ void pad_rows_kernel(const double *__restrict__ src, double *__restrict__ dst, int n, int d) {
@@ -255,39 +249,44 @@ static int launch_rng(gpemu_sampler *s, hipStream_t st, int64_t ahead = 1) {
 
 static inline size_t rslot(const gpemu_sampler *s) { return (size_t)(s->step_counter % RNG_RING); }
 
-static int launch_propose(gpemu_sampler *s, int h, hipStream_t st) {
+static int launch_accept(gpemu_sampler *s, int h, const double *dnewlp, int store_chain, hipStream_t st) {
   const int ns = (int)s->ns[h];
   const size_t o2 = rslot(s) * 2 * s->W;
-  hipLaunchKernelGGL(propose_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, s->X,
+  double *chain = nullptr, *lpchain = nullptr;
+  if (store_chain) {
+    int rc = ensure_chain(s, s->chain_len + 1);
+    if (rc != GPEMU_OK) return rc;
+    chain = s->chain + s->chain_len * s->W * s->d;
+    lpchain = s->lpchain + s->chain_len * s->W;
+  }
+  hipLaunchKernelGGL(accept_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, s->X, s->logp,
                      s->idx + o2 + h * s->W, s->idx + o2 + (1 - h) * s->W, s->zz + o2 + h * s->W,
-                     s->rint + o2 + h * s->W, s->q, s->factors, ns, (int)s->d);
+                     s->rint + o2 + h * s->W, dnewlp, s->logu + o2 + h * s->W, s->naccept, s->flags, ns,
+                     (int)s->d, chain, lpchain);
   GP_HIP(hipGetLastError());
   return GPEMU_OK;
 }
 
-static int launch_accept(gpemu_sampler *s, int h, const double *dnewlp, hipStream_t st) {
-  const int ns = (int)s->ns[h];
+// ProposeArgs of half h for proposals [lo, lo + n)
+static ProposeArgs propose_args(gpemu_sampler *s, int h, int64_t lo, int64_t n) {
   const size_t o2 = rslot(s) * 2 * s->W;
-  hipLaunchKernelGGL(accept_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, s->X, s->logp,
-                     s->idx + o2 + h * s->W, s->q, s->factors, dnewlp, s->logu + o2 + h * s->W,
-                     s->naccept, s->flags, ns);
-  GP_HIP(hipGetLastError());
-  return GPEMU_OK;
+  ProposeArgs pa;
+  pa.enabled = 1;
+  pa.X = s->X;
+  pa.idx_s = s->idx + o2 + h * s->W + lo;
+  pa.idx_c = s->idx + o2 + (1 - h) * s->W;
+  pa.zz = s->zz + o2 + h * s->W + lo;
+  pa.rint = s->rint + o2 + h * s->W + lo;
+  pa.factors = s->factors + lo;
+  pa.n = (int)n;
+  pa.d = (int)s->d;
+  return pa;
 }
 
 // propose + log-posterior + (fused) accept / record of one half on this device
 static int half_step_fused(gpemu_sampler *s, int h, int store_chain, hipStream_t st) {
   const size_t o2 = rslot(s) * 2 * s->W;
-  ProposeArgs pa;
-  pa.enabled = 1;
-  pa.X = s->X;
-  pa.idx_s = s->idx + o2 + h * s->W;
-  pa.idx_c = s->idx + o2 + (1 - h) * s->W;
-  pa.zz = s->zz + o2 + h * s->W;
-  pa.rint = s->rint + o2 + h * s->W;
-  pa.factors = s->factors;
-  pa.n = (int)s->ns[h];
-  pa.d = (int)s->d;
+  const ProposeArgs pa = propose_args(s, h, 0, s->ns[h]);
   AcceptArgs aa;
   aa.enabled = 1;
   aa.X = s->X; aa.logp = s->logp;
@@ -302,20 +301,10 @@ static int half_step_fused(gpemu_sampler *s, int h, int store_chain, hipStream_t
   return eval_logpost(s, s->q, s->ns[h], s->newlp, st, &aa, &pa);
 }
 
-// bookkeeping after both halves; `recorded` = the chain row was already written by the fused kernels
-static int end_step(gpemu_sampler *s, int store_chain, hipStream_t st, bool recorded = false) {
-  if (store_chain && recorded) {
-    s->chain_len += 1;
-  } else if (store_chain) {
-    int rc = ensure_chain(s, s->chain_len + 1);
-    if (rc != GPEMU_OK) return rc;
-    const int n = (int)(s->W * s->d);
-    hipLaunchKernelGGL(record_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->X, s->logp,
-                       s->chain + s->chain_len * s->W * s->d, s->lpchain + s->chain_len * s->W,
-                       (int)s->W, (int)s->d);
-    GP_HIP(hipGetLastError());
-    s->chain_len += 1;
-  }
+// bookkeeping after both halves (the chain row was written by the fused / accept kernels)
+static int end_step(gpemu_sampler *s, int store_chain, hipStream_t st, bool recorded = true) {
+  (void)st; (void)recorded;
+  if (store_chain) s->chain_len += 1;
   s->iterations += 1;
   s->step_counter += 1;
   return GPEMU_OK;
@@ -559,6 +548,12 @@ int gpemu_sampler_get_counts(gpemu_sampler *s, int64_t *naccepted, int64_t *iter
 }
 
 // ---- phases for the multi-GPU driver (walkers sharded over ranks; RCCL all-gather in between) ----
+int gpemu_sampler_reserve_chain(gpemu_sampler *s, int64_t additional_steps) {
+  GP_ARG(s && additional_steps >= 0, "sampler / steps");
+  GP_HIP(hipSetDevice(s->device));
+  return ensure_chain(s, s->chain_len + additional_steps);
+}
+
 int gpemu_sampler_begin_step(gpemu_sampler *s) {
   GP_ARG(s, "sampler");
   GP_HIP(hipSetDevice(s->device));
@@ -570,25 +565,25 @@ int gpemu_sampler_half_propose_eval(gpemu_sampler *s, int half, int64_t lo, int6
   GP_ARG(s && (half == 0 || half == 1), "half");
   GP_ARG(lo >= 0 && lo <= hi && hi <= s->ns[half] && dnewlp_slice, "slice");
   GP_HIP(hipSetDevice(s->device));
-  GP_TRY(launch_propose(s, half, s->stream));
   if (hi > lo) {
-    GP_TRY(eval_logpost(s, s->q + lo * DPAD, hi - lo, s->newlp, s->stream));
-    GP_HIP(hipMemcpyAsync(dnewlp_slice, s->newlp, sizeof(double) * (hi - lo), hipMemcpyDeviceToDevice,
-                          s->stream));
+    // the cross-kernel kernel builds this rank's proposal rows itself; the likelihood kernel writes the
+    // log-probabilities straight into the caller's all-gather buffer
+    const ProposeArgs pa = propose_args(s, half, lo, hi - lo);
+    GP_TRY(eval_logpost(s, s->q, hi - lo, dnewlp_slice, s->stream, nullptr, &pa));
   }
   return GPEMU_OK;
 }
 
-int gpemu_sampler_half_accept(gpemu_sampler *s, int half, const double *dnewlp_all) {
+int gpemu_sampler_half_accept(gpemu_sampler *s, int half, const double *dnewlp_all, int store_chain) {
   GP_ARG(s && (half == 0 || half == 1) && dnewlp_all, "half / newlp");
   GP_HIP(hipSetDevice(s->device));
-  return launch_accept(s, half, dnewlp_all, s->stream);
+  return launch_accept(s, half, dnewlp_all, store_chain, s->stream);
 }
 
 int gpemu_sampler_end_step(gpemu_sampler *s, int store_chain) {
   GP_ARG(s, "sampler");
   GP_HIP(hipSetDevice(s->device));
-  return end_step(s, store_chain, s->stream);
+  return end_step(s, store_chain, s->stream, true);   // the accept kernels recorded the chain row
 }
 
 int gpemu_sampler_check(gpemu_sampler *s) {

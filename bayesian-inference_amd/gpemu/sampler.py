@@ -156,7 +156,7 @@ class DeviceSampler:
         return chain, lp
 
     # -- multi-GPU: one process per GPU, the ensemble replicated, proposals sharded -------------
-    def run_sharded(self, steps, store=True, group=None, force=False):
+    def run_sharded(self, steps, store=True, group=None, force=False, emulate_world=None):
         """Same chain as ``run`` (every rank draws identical randomness); rank r evaluates its
         block of each half's proposals and the log-probabilities are all-gathered.
 
@@ -179,7 +179,13 @@ class DeviceSampler:
         stream = self._tstream
         stream.wait_stream(torch.cuda.current_stream(dev))
         check(L.gpemu_sampler_set_stream(self._h, C.c_void_p(stream.cuda_stream)))
-        bounds = [shard_bounds(self.ns[h], world, rank) for h in (0, 1)]
+        if store:
+            check(L.gpemu_sampler_reserve_chain(self._h, int(steps)))
+        if emulate_world:   # measurement aid: do one rank's share of an `emulate_world`-GPU run (results are NOT a valid chain)
+            bounds = [shard_bounds(self.ns[h], int(emulate_world), 0) for h in (0, 1)]
+            bounds = [(lo, hi, self.ns[h]) for h, (lo, hi, _p) in enumerate(bounds)]
+        else:
+            bounds = [shard_bounds(self.ns[h], world, rank) for h in (0, 1)]
         with torch.cuda.stream(stream):
             mine = [torch.zeros(b[2], dtype=torch.float64, device=dev) for b in bounds]
             full = [torch.zeros(b[2] * world, dtype=torch.float64, device=dev) for b in bounds]
@@ -197,7 +203,7 @@ class DeviceSampler:
                         host_full = torch.empty(full[h].shape, dtype=torch.float64)
                         dist.all_gather_into_tensor(host_full, host_mine, group=group)
                         full[h].copy_(host_full)
-                    check(L.gpemu_sampler_half_accept(self._h, h, C.c_void_p(full[h].data_ptr())))
+                    check(L.gpemu_sampler_half_accept(self._h, h, C.c_void_p(full[h].data_ptr()), int(bool(store))))
                 check(L.gpemu_sampler_end_step(self._h, int(bool(store))))
             rc = L.gpemu_sampler_check(self._h)
             if rc == 1:

@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostic: time ONE rank's share of an N-GPU step on this GPU (world-1 RCCL gather); "
+                         "the printed value is NOT a throughput claim")
     args = ap.parse_args()
 
     import torch
@@ -173,8 +176,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    if world > 1 or args.emulate_world:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ["MASTER_PORT"] = str(29400 + os.getpid() % 500)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
 
     from gpemu import synthetic
     from gpemu.model import DeviceModel
@@ -190,7 +196,9 @@ def main():
     ds.set_state(synthetic.make_walkers(N_WALKERS, seed=1))
 
     def run(steps):
-        if world > 1:
+        if args.emulate_world:
+            ds.run_sharded(steps, store=True, force=True, emulate_world=args.emulate_world)
+        elif world > 1:
             ds.run_sharded(steps, store=True)
         else:
             ds.run(steps, store=True)
@@ -251,7 +259,7 @@ def main():
         out = {"metric": "log-posterior evals/sec", "value": evals / dt, "unit": "evals/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "scaling": "strong", "vs_baseline": None, "emulate_world": args.emulate_world or None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "C3: N_design=1000 x N_obs=500, 10 PCs, d=6, 1024-walker "
                                       "stretch-move MCMC, RBF+White fixed theta",
                           "n_walkers": N_WALKERS, "evals_per_step": N_WALKERS,
@@ -261,7 +269,7 @@ def main():
         print(json.dumps(out), flush=True)
     ds.close()
     dm.close()
-    if world > 1:
+    if world > 1 or args.emulate_world:
         dist.destroy_process_group()
 
 

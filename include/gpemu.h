@@ -181,13 +181,15 @@ int gpemu_sampler_get_chain(gpemu_sampler *s, int64_t first, int64_t n, double *
 int gpemu_sampler_get_counts(gpemu_sampler *s, int64_t *naccepted /*[W]*/, int64_t *iterations,
                              int64_t *chain_len);
 /* Phases of one step for the multi-GPU driver: every rank holds the whole ensemble and draws the
- * same randomness; rank r evaluates proposals [lo, hi) of the half and the ranks all-gather the
- * new log-probabilities (RCCL, done by the caller on the sampler's stream) before accepting.
- * dnewlp_* are DEVICE pointers. */
+ * same randomness; rank r evaluates proposals [lo, hi) of the half (the log-probabilities land in
+ * dnewlp_slice[0 .. hi-lo), typically the caller's all-gather input) and the ranks all-gather them
+ * (RCCL, done by the caller on the sampler's stream) before every rank accepts identically; the
+ * accept kernels also record the chain row when store_chain is set.  dnewlp_* are DEVICE pointers. */
+int gpemu_sampler_reserve_chain(gpemu_sampler *s, int64_t additional_steps); /* grow the chain buffer once, up front */
 int gpemu_sampler_begin_step(gpemu_sampler *s);
 int gpemu_sampler_half_propose_eval(gpemu_sampler *s, int half, int64_t lo, int64_t hi,
                                     double *dnewlp_slice);
-int gpemu_sampler_half_accept(gpemu_sampler *s, int half, const double *dnewlp_all);
+int gpemu_sampler_half_accept(gpemu_sampler *s, int half, const double *dnewlp_all, int store_chain);
 int gpemu_sampler_end_step(gpemu_sampler *s, int store_chain);
 int gpemu_sampler_check(gpemu_sampler *s); /* synchronise; 1 if a NaN log-probability was seen */
 
