@@ -445,8 +445,10 @@ int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_
 }
 
 int gpemu_logpost_dev(gpemu_model *m, int64_t B, const double *dX, double *dout, int mode, void *stream) {
-  GP_ARG(m && dX && dout, "null pointer");
-  GP_ARG(B > 0, "B must be positive");
+  GP_ARG(m, "null pointer");
+  GP_ARG(B >= 0, "B must not be negative");
+  if (B == 0) return GPEMU_OK;   /* empty batch -> empty result (ref: log_posterior.py:59,68) */
+  GP_ARG(dX && dout, "null pointer");
   GP_ARG(mode == GPEMU_LOGPOST_LOWRANK || mode == GPEMU_LOGPOST_EXACT, "mode");
   if (!m->lik_ready) { set_error("gpemu_likelihood_setup has not been called"); return GPEMU_ERR_STATE; }
   GP_HIP(hipSetDevice(m->device));
@@ -461,8 +463,10 @@ int gpemu_logpost_dev(gpemu_model *m, int64_t B, const double *dX, double *dout,
 }
 
 int gpemu_logpost(gpemu_model *m, int64_t B, const double *X, double *out, int mode) {
-  GP_ARG(m && X && out, "null pointer");
-  GP_ARG(B > 0, "B must be positive");
+  GP_ARG(m, "null pointer");
+  GP_ARG(B >= 0, "B must not be negative");
+  if (B == 0) return GPEMU_OK;
+  GP_ARG(X && out, "null pointer");
   GP_HIP(hipSetDevice(m->device));
   hipStream_t st = m->stream;
   double *dX = nullptr, *dout = nullptr;
