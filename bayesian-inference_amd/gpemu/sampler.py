@@ -187,7 +187,9 @@ class DeviceSampler:
         else:
             bounds = [shard_bounds(self.ns[h], world, rank) for h in (0, 1)]
         with torch.cuda.stream(stream):
-            mine = [torch.zeros(b[2], dtype=torch.float64, device=dev) for b in bounds]
+            # emulation: proposals nobody evaluates carry -inf, i.e. are rejected
+            mine = [torch.full((b[2],), float("-inf") if emulate_world else 0.0, dtype=torch.float64, device=dev)
+                    for b in bounds]
             full = [torch.zeros(b[2] * world, dtype=torch.float64, device=dev) for b in bounds]
         try:
           with torch.cuda.stream(stream):

@@ -30,8 +30,8 @@ def _compare_chains(chain, lps, ochain, olps):
     np.testing.assert_allclose(lps[fin], olps[fin], rtol=1e-8)
 
 
-@pytest.mark.parametrize("W", [24, 33])
-def test_device_philox_chain_equals_oracle(W):
+@pytest.mark.parametrize("W,steps", [(12, 12), (24, 12), (33, 12), (130, 8), (1025, 4), (8192, 2)])
+def test_device_philox_chain_equals_oracle(W, steps):
     from gpemu import synthetic
     from gpemu.sampler import DeviceSampler
     g, model, dm, oracle_lp = _setup()
@@ -41,12 +41,12 @@ def test_device_philox_chain_equals_oracle(W):
     X, lp0 = ds.get_state()
     np.testing.assert_array_equal(X, X0)
     np.testing.assert_allclose(lp0, oracle_lp(X0), rtol=1e-8)
-    ds.run(12)
+    ds.run(steps)
     chain, lps = ds.get_chain()
-    ochain, olps, onacc = SO.run(X0, oracle_lp, SO.PhiloxStream(0xC0FFEE12345), 12)
+    ochain, olps, onacc = SO.run(X0, oracle_lp, SO.PhiloxStream(0xC0FFEE12345), steps)
     _compare_chains(chain, lps, ochain, olps)
     nacc, iters, clen = ds.counts()
-    assert iters == 12 and clen == 12
+    assert iters == steps and clen == steps
     np.testing.assert_array_equal(nacc, onacc)
     # reset() clears chain and counters but keeps the state; the RNG stream continues
     ds.reset()
