@@ -14,6 +14,13 @@
 // draw order (gpemu_sampler_step_host_rng) to replay a numpy RandomState stream.
 #include "internal.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
 namespace gpemu {
 
 // ---- Philox4x32-10 (Salmon et al., SC'11) ----------------------------------------------------
@@ -68,6 +75,11 @@ struct gpemu_sampler {
   double *chain = nullptr;     // [chain_cap][W][d]
   double *lpchain = nullptr;   // [chain_cap][W]
   int64_t chain_cap = 0, chain_len = 0;
+  // multi-GPU: this rank's slice / the gathered log-probabilities of each half ([per] / [per*world])
+  double *gmine[2] = {nullptr, nullptr};
+  double *gfull[2] = {nullptr, nullptr};
+  int64_t gper[2] = {0, 0};
+  int gworld = 0;
 };
 
 namespace gpemu {
@@ -386,6 +398,7 @@ int gpemu_sampler_destroy(gpemu_sampler *s) {
   (void)hipFree(s->zz); (void)hipFree(s->logu); (void)hipFree(s->rint); (void)hipFree(s->q);
   (void)hipFree(s->factors); (void)hipFree(s->newlp); (void)hipFree(s->naccept); (void)hipFree(s->flags);
   (void)hipFree(s->chain); (void)hipFree(s->lpchain);
+  for (int h = 0; h < 2; ++h) { (void)hipFree(s->gmine[h]); (void)hipFree(s->gfull[h]); }
   delete s;
   return GPEMU_OK;
 }
@@ -598,6 +611,157 @@ int gpemu_sampler_set_stream(gpemu_sampler *s, void *stream) {
   GP_HIP(hipStreamSynchronize(s->stream));
   s->stream = stream ? (hipStream_t)stream : s->groups[0]->stream;
   return GPEMU_OK;
+}
+
+// ---- RCCL communicator + the whole sharded run in one call -----------------------------------------
+// librccl is bound at run time (dlopen) so that the process keeps ONE copy of it: the host side passes the
+// path of the copy torch.distributed already loaded, or NULL for the system "librccl.so".
+struct RcclApi {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int load_rccl(const char *path) {
+  if (g_rccl.lib) return GPEMU_OK;
+  const char *name = (path && path[0]) ? path : "librccl.so";
+  void *lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+  if (!lib) { set_error("cannot load RCCL (%s): %s", name, dlerror()); return GPEMU_ERR_STATE; }
+  RcclApi api;
+  api.lib = lib;
+  *(void **)&api.GetUniqueId = dlsym(lib, "ncclGetUniqueId");
+  *(void **)&api.CommInitRank = dlsym(lib, "ncclCommInitRank");
+  *(void **)&api.CommDestroy = dlsym(lib, "ncclCommDestroy");
+  *(void **)&api.AllGather = dlsym(lib, "ncclAllGather");
+  *(void **)&api.GetErrorString = dlsym(lib, "ncclGetErrorString");
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString) {
+    set_error("%s does not export the RCCL entry points", name);
+    dlclose(lib);
+    return GPEMU_ERR_STATE;
+  }
+  g_rccl = api;
+  return GPEMU_OK;
+}
+
+#define GP_RCCL(call)                                                                      \
+  do {                                                                                     \
+    ncclResult_t r_ = (call);                                                              \
+    if (r_ != ncclSuccess) {                                                               \
+      set_error("%s: %s", #call, g_rccl.GetErrorString(r_));                               \
+      return GPEMU_ERR_HIP;                                                                \
+    }                                                                                      \
+  } while (0)
+
+struct gpemu_comm {
+  int device = 0, rank = 0, world = 1;
+  ncclComm_t comm = nullptr;
+};
+
+int gpemu_comm_unique_id(const char *librccl_path, char *id_out128) {
+  GP_ARG(id_out128, "id_out");
+  GP_TRY(load_rccl(librccl_path));
+  ncclUniqueId id;
+  GP_RCCL(g_rccl.GetUniqueId(&id));
+  memcpy(id_out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+  return GPEMU_OK;
+}
+
+int gpemu_comm_create(gpemu_comm **out, int device, int rank, int world, const char *id128,
+                      const char *librccl_path) {
+  GP_ARG(out && id128, "null pointer");
+  GP_ARG(world >= 1 && rank >= 0 && rank < world, "rank / world");
+  GP_TRY(load_rccl(librccl_path));
+  GP_HIP(hipSetDevice(device));
+  gpemu_comm *c = new gpemu_comm();
+  c->device = device; c->rank = rank; c->world = world;
+  ncclUniqueId id;
+  memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+  ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) {
+    set_error("ncclCommInitRank: %s", g_rccl.GetErrorString(r));
+    delete c;
+    return GPEMU_ERR_HIP;
+  }
+  *out = c;
+  return GPEMU_OK;
+}
+
+int gpemu_comm_destroy(gpemu_comm *c) {
+  if (!c) return GPEMU_OK;
+  (void)hipSetDevice(c->device);
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  delete c;
+  return GPEMU_OK;
+}
+
+int gpemu_comm_dims(const gpemu_comm *c, int *rank, int *world) {
+  GP_ARG(c, "comm");
+  if (rank) *rank = c->rank;
+  if (world) *world = c->world;
+  return GPEMU_OK;
+}
+
+int gpemu_comm_all_gather(gpemu_comm *c, const double *dsend, double *drecv, int64_t count, void *stream) {
+  GP_ARG(c && dsend && drecv && count > 0, "all_gather arguments");
+  GP_HIP(hipSetDevice(c->device));
+  GP_RCCL(g_rccl.AllGather(dsend, drecv, (size_t)count, ncclDouble, c->comm, (hipStream_t)stream));
+  return GPEMU_OK;
+}
+
+__global__ void fill_kernel(double *p, int64_t n, double v) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// Walkers sharded over the communicator's ranks: every rank draws the same randomness, evaluates its block
+// of each half's proposals, all-gathers the log-probabilities (8 bytes per proposal) and applies the same
+// accept decisions to its replica of the ensemble.  emulate_world > 0 (measurement aid, communicator of one
+// rank): evaluate only the share rank 0 of an `emulate_world`-rank job would; everything else is rejected.
+int gpemu_sampler_run_sharded(gpemu_sampler *s, gpemu_comm *c, int64_t steps, int store_chain,
+                              int emulate_world) {
+  GP_ARG(s && c && steps >= 0, "sampler / comm / steps");
+  GP_ARG(c->device == s->device, "communicator and sampler are bound to different devices");
+  GP_ARG(emulate_world >= 0 && (emulate_world == 0 || c->world == 1), "emulate_world needs a one-rank communicator");
+  GP_HIP(hipSetDevice(s->device));
+  hipStream_t st = s->stream;
+  const int world = c->world;
+  const int split = emulate_world > 0 ? emulate_world : world;
+  int64_t lo[2], hi[2];
+  for (int h = 0; h < 2; ++h) {
+    const int64_t share = (s->ns[h] + split - 1) / split;       // == sampler.shard_bounds()
+    const int64_t per = emulate_world > 0 ? s->ns[h] : share;
+    const int r = emulate_world > 0 ? 0 : c->rank;
+    lo[h] = std::min<int64_t>((int64_t)r * share, s->ns[h]);
+    hi[h] = std::min<int64_t>(lo[h] + share, s->ns[h]);
+    if (s->gworld != world || s->gper[h] != per) {
+      (void)hipFree(s->gmine[h]); (void)hipFree(s->gfull[h]);
+      s->gmine[h] = s->gfull[h] = nullptr;
+      GP_HIP(hipMalloc((void **)&s->gmine[h], sizeof(double) * per));
+      GP_HIP(hipMalloc((void **)&s->gfull[h], sizeof(double) * per * world));
+      s->gper[h] = per;
+    }
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, s->gmine[h], per,
+                       emulate_world > 0 ? -INFINITY : 0.0);
+  }
+  s->gworld = world;
+  if (store_chain) GP_TRY(ensure_chain(s, s->chain_len + steps));
+  for (int64_t it = 0; it < steps; ++it) {
+    GP_TRY(launch_rng(s, st, steps - it));
+    for (int h = 0; h < 2; ++h) {
+      if (hi[h] > lo[h]) {
+        const ProposeArgs pa = propose_args(s, h, lo[h], hi[h] - lo[h]);
+        GP_TRY(eval_logpost(s, s->q, hi[h] - lo[h], s->gmine[h], st, nullptr, &pa));
+      }
+      GP_RCCL(g_rccl.AllGather(s->gmine[h], s->gfull[h], (size_t)s->gper[h], ncclDouble, c->comm, st));
+      GP_TRY(launch_accept(s, h, s->gfull[h], store_chain, st));
+    }
+    GP_TRY(end_step(s, store_chain, st, true));
+  }
+  return check_nan(s);
 }
 
 }  // extern "C"

@@ -77,6 +77,12 @@ _SIGNATURES = {
     "gpemu_sampler_half_accept": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "gpemu_sampler_end_step": (C.c_int, [C.c_void_p, C.c_int]),
     "gpemu_sampler_check": (C.c_int, [C.c_void_p]),
+    "gpemu_comm_unique_id": (C.c_int, [C.c_char_p, C.c_void_p]),
+    "gpemu_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_char_p]),
+    "gpemu_comm_destroy": (C.c_int, [C.c_void_p]),
+    "gpemu_comm_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gpemu_comm_all_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p]),
+    "gpemu_sampler_run_sharded": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int]),
     "gpemu_philox4x32": (C.c_int, [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]),
 }
 

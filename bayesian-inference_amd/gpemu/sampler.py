@@ -13,6 +13,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -100,6 +101,8 @@ class DeviceSampler:
         self.device = self.models[0].device
 
     def close(self):
+        for h in self.__dict__.pop("_comms", {}).values():
+            _lib.lib().gpemu_comm_destroy(h)
         if getattr(self, "_h", None):
             _lib.lib().gpemu_sampler_destroy(self._h)
             self._h = None
@@ -156,12 +159,42 @@ class DeviceSampler:
         return chain, lp
 
     # -- multi-GPU: one process per GPU, the ensemble replicated, proposals sharded -------------
-    def run_sharded(self, steps, store=True, group=None, force=False, emulate_world=None):
+    def _rccl_comm(self, group):
+        """RCCL communicator owned by the library (one per sampler and process group), bootstrapped
+        through torch.distributed: rank 0's 128-byte id is broadcast, then every rank joins."""
+        import torch
+        import torch.distributed as dist
+        key = id(group) if group is not None else 0
+        comms = self.__dict__.setdefault("_comms", {})
+        if key in comms:
+            return comms[key]
+        L = _lib.lib()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = torch.device("cuda", self.device)
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = bundled.encode() if os.path.exists(bundled) else None   # the copy torch already loaded
+        ident = (C.c_char * 128)()
+        if rank == 0:
+            check(L.gpemu_comm_unique_id(path, C.cast(ident, C.c_void_p)))
+        t = torch.tensor(list(ident.raw), dtype=torch.uint8, device=dev)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(t, src=src, group=group)
+        raw = bytes(t.cpu().tolist())
+        buf = C.create_string_buffer(raw, 128)
+        h = C.c_void_p()
+        check(L.gpemu_comm_create(C.byref(h), int(self.device), int(rank), int(world), C.cast(buf, C.c_void_p), path))
+        comms[key] = h
+        return h
+
+    def run_sharded(self, steps, store=True, group=None, force=False, emulate_world=None, transport=None):
         """Same chain as ``run`` (every rank draws identical randomness); rank r evaluates its
         block of each half's proposals and the log-probabilities are all-gathered.
 
-        Backend "nccl" (RCCL over xGMI): the gather runs on device buffers on the sampler's stream.
-        Any other backend (gloo, for tests): the 8-byte-per-walker payload is staged through the host.
+        Backend "nccl" (RCCL over xGMI), transport "rccl" (default): the whole loop runs inside the
+        library on its own RCCL communicator (``gpemu_sampler_run_sharded``), no host work per step.
+        transport "torch" (or env GPEMU_SHARDED_TRANSPORT=torch): per-phase calls with torch.distributed's
+        all-gather on a shared stream.  Any other backend (gloo, for tests): the 8-byte-per-walker payload
+        is staged through the host.
         """
         import torch
         import torch.distributed as dist
@@ -171,6 +204,14 @@ class DeviceSampler:
         L = _lib.lib()
         dev = torch.device("cuda", self.device)
         on_device = dist.get_backend(group) == "nccl"
+        transport = transport or os.environ.get("GPEMU_SHARDED_TRANSPORT", "rccl")
+        if on_device and transport == "rccl":
+            comm = self._rccl_comm(group)
+            rc = L.gpemu_sampler_run_sharded(self._h, comm, int(steps), int(bool(store)), int(emulate_world or 0))
+            if rc == 1:
+                raise ValueError("Probability function returned NaN")
+            check(rc)
+            return None
         # a dedicated (non-null) torch stream carries the library's launches AND the collectives, so
         # they are ordered by the stream; torch's default stream has handle 0, which the C ABI reads
         # as "use the handle's own stream"

@@ -193,6 +193,26 @@ int gpemu_sampler_half_accept(gpemu_sampler *s, int half, const double *dnewlp_a
 int gpemu_sampler_end_step(gpemu_sampler *s, int store_chain);
 int gpemu_sampler_check(gpemu_sampler *s); /* synchronise; 1 if a NaN log-probability was seen */
 
+/* ---- RCCL communicator (one rank per GPU) and the sharded run in a single call ----------------
+ * Replaces the multiprocessing pool of ref: mcmc.py:77-85 across GPUs.  librccl is bound with dlopen:
+ * pass the path of the copy the process already uses (torch.distributed's) or NULL for "librccl.so".
+ * Rank 0 obtains a 128-byte id with gpemu_comm_unique_id and ships it to the other ranks by any means
+ * (torch.distributed broadcast, a file, MPI); every rank then calls gpemu_comm_create (collective). */
+typedef struct gpemu_comm gpemu_comm;
+int gpemu_comm_unique_id(const char *librccl_path, char *id_out128);
+int gpemu_comm_create(gpemu_comm **out, int device, int rank, int world, const char *id128,
+                      const char *librccl_path);
+int gpemu_comm_destroy(gpemu_comm *c);
+int gpemu_comm_dims(const gpemu_comm *c, int *rank, int *world);
+/* all-gather of `count` doubles per rank, DEVICE pointers, enqueued on `stream` */
+int gpemu_comm_all_gather(gpemu_comm *c, const double *dsend, double *drecv, int64_t count, void *stream);
+/* `steps` stretch-move steps with each half's proposals split over the communicator's ranks (contiguous
+ * blocks of ceil(n/world)); one 8-byte-per-proposal all-gather per half-step, no host round trip inside
+ * the loop.  Same chain as gpemu_sampler_run on every rank.  emulate_world > 0 (one-rank communicator
+ * only): evaluate just the share of rank 0 of an emulate_world-rank job -- a timing aid, not a valid chain. */
+int gpemu_sampler_run_sharded(gpemu_sampler *s, gpemu_comm *c, int64_t steps, int store_chain,
+                              int emulate_world);
+
 /* Philox4x32-10 block function (host copy of the device generator; for tests) */
 int gpemu_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                      uint32_t *out4);

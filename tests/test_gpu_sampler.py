@@ -193,22 +193,39 @@ def _rccl_worker(rank, port, out_dir):
     g, model, dm, _ = _setup()
     W = 24
     X0 = synthetic.make_walkers(W, seed=3, lo=g["lo"], hi=g["hi"])
-    a = DeviceSampler([dm], W, seed=5)
-    a.set_state(X0)
-    a.run_sharded(6, force=True)
-    ca, la = a.get_chain()
     b = DeviceSampler([dm], W, seed=5)
     b.set_state(X0)
     b.run(6)
     cb, lb = b.get_chain()
-    np.save(os.path.join(out_dir, "ok.npy"), np.array([np.array_equal(ca, cb), np.array_equal(la, lb)]))
-    a.close(); b.close(); dm.close()
+    ok = []
+    for transport in ("rccl", "torch"):     # library-owned communicator / torch.distributed's
+        a = DeviceSampler([dm], W, seed=5)
+        a.set_state(X0)
+        a.run_sharded(4, force=True, transport=transport)
+        a.run_sharded(2, force=True, transport=transport)
+        ca, la = a.get_chain()
+        ok += [np.array_equal(ca, cb), np.array_equal(la, lb)]
+        if transport == "rccl":             # the communicator's stand-alone all-gather entry point
+            import ctypes as C
+            from gpemu import _lib
+            src = torch.arange(5, dtype=torch.float64, device="cuda")
+            dst = torch.zeros(5, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            comm = a._rccl_comm(None)
+            _lib.check(_lib.lib().gpemu_comm_all_gather(comm, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()),
+                                                        5, None))
+            torch.cuda.synchronize()
+            ok.append(bool(torch.equal(src, dst)))
+        a.close()
+    np.save(os.path.join(out_dir, "ok.npy"), np.array(ok))
+    b.close(); dm.close()
     dist.destroy_process_group()
 
 
 def test_sharded_path_over_rccl_world1(tmp_path):
-    """The RCCL (backend "nccl") plumbing of the sharded step -- device buffers, dedicated stream,
-    all_gather_into_tensor -- exercised with a single-rank group (one GPU is all this box has)."""
+    """The RCCL (backend "nccl") plumbing of the sharded run -- the library's own communicator
+    (gpemu_comm_* / gpemu_sampler_run_sharded) and the torch.distributed transport -- exercised with a
+    single-rank group (one GPU is all this box has)."""
     import os
     import torch.multiprocessing as mp
     mp.spawn(_rccl_worker, args=(29700 + (os.getpid() % 2000), str(tmp_path)), nprocs=1, join=True)
