@@ -85,21 +85,36 @@ int launch_lik_setup(gpemu_model *m, double *dA, double *dPT, double *dZ, int *d
 //   * optionally finishes the stretch move for its walker (accept / reject, state update, chain
 //     record: emcee moves/red_blue.py), so a half-step needs no further launch.
 // sums the partials of walker b; returns (mu, sd) of PC `lane`
+template <int KP>   // power of two >= k, <= 64
 __device__ __forceinline__ void walker_mean_sd(const double *__restrict__ mean_part,
                                                const double *__restrict__ vsq_part,
                                                const double *__restrict__ kdiag, double *mean_out,
                                                double *var_out, int64_t b, int64_t Bcap, int k,
                                                int nchunk, int nrb, int lane, double &mu, double &sd) {
+  // lane = sub * KP + pc: SUBS = 64 / KP lanes share one PC's partial sums (independent loads in flight
+  // instead of one long dependent chain), combined by xor-shuffles; lanes < k end up with the totals
+  constexpr int SUBS = 64 / KP;
+  const int pc = lane & (KP - 1), sub = lane / KP;
+  double mu_p = 0.0, vs_p = 0.0;
+  if (pc < k) {
+    // parts of one (walker, PC) are contiguous
+    const double *mp = mean_part + (b * k + pc) * nchunk;
+    const double *vp = vsq_part + (b * k + pc) * nrb;
+#pragma unroll 8
+    for (int c = sub; c < nchunk; c += SUBS) mu_p += mp[c];
+#pragma unroll 8
+    for (int r = sub; r < nrb; r += SUBS) vs_p += vp[r];
+  }
+#pragma unroll
+  for (int off = KP; off < 64; off <<= 1) {
+    mu_p += __shfl_xor(mu_p, off);
+    vs_p += __shfl_xor(vs_p, off);
+  }
   mu = 0.0;
   sd = 0.0;
   if (lane < k) {
-    double vs = 0.0;
-    // parts of one (walker, PC) are contiguous: the loop walks one or two cache lines
-    const double *mp = mean_part + (b * k + lane) * nchunk;
-    const double *vp = vsq_part + (b * k + lane) * nrb;
-    for (int c = 0; c < nchunk; ++c) mu += mp[c];
-    for (int r = 0; r < nrb; ++r) vs += vp[r];
-    double v = kdiag[lane] - vs;
+    mu = mu_p;
+    double v = kdiag[lane] - vs_p;
     if (v < 0.0) v = 0.0;     // skl _gpr.py:479-485
     sd = sqrt(v);
     if (mean_out) mean_out[b * k + lane] = mu;
@@ -136,6 +151,24 @@ __device__ __forceinline__ void finish_walker(double total, const double *__rest
   }
 }
 
+// value of lane `l` (compile-time / wave-uniform index) as a scalar: v_readlane, no LDS round trip
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+template <int KMAX>
+__device__ __forceinline__ double sum_first_lanes(double v) {
+  double s = readlane_f64(v, 0);
+#pragma unroll
+  for (int q = 1; q < KMAX; ++q) s += readlane_f64(v, q);
+  return s;
+}
+
+// k <= KMAX <= 16.  The k x k matrix M = I + D^1/2 G D^1/2 is padded to KMAX x KMAX with the identity, so
+// the factorisation below is branch-free; lane = row, the row lives in registers, and every cross-lane
+// operand is a v_readlane of a compile-time lane.
 template <int KMAX>
 __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
     const double *__restrict__ Xq, const double *__restrict__ lo, const double *__restrict__ hi,
@@ -154,7 +187,7 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
   const bool inside = __all(in);
 
   double mu, sd;
-  walker_mean_sd(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
+  walker_mean_sd<16>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
   double total = -INFINITY;
   if (inside) {
     total = 0.0;
@@ -165,46 +198,32 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
       double h = 0.0;
 #pragma unroll
       for (int q = 0; q < KMAX; ++q) {
-        double gq = (q < k && lane < k) ? Go[q * k + lane] : 0.0;
-        h = fma(gq, __shfl(mu, q), h);
-        row[q] = ((lane == q) ? 1.0 : 0.0) + sd * gq * __shfl(sd, q);   // M = I + D^1/2 G D^1/2
+        const double gq = (q < k && lane < k) ? Go[q * k + lane] : 0.0;
+        h = fma(gq, readlane_f64(mu, q), h);
+        row[q] = ((lane == q) ? 1.0 : 0.0) + sd * gq * readlane_f64(sd, q);
       }
       const double gl = (lane < k) ? g0[(int64_t)o * k + lane] : 0.0;
       h += gl;
-      double t = (lane < k) ? mu * (h + gl) : 0.0;
-      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-      const double quadA = t + scal[2 * o];
-      // right-looking Cholesky, lane = row; y = L_M^-1 (sd o h) by forward substitution alongside.
-      // One reciprocal square root per pivot on the critical path; the logarithms of the pivots are
-      // taken after the loop, one per lane in parallel.
+      const double quadA = sum_first_lanes<KMAX>((lane < k) ? mu * (h + gl) : 0.0) + scal[2 * o];
+      // right-looking Cholesky; y = L_M^-1 (sd o h) by forward substitution alongside.  One reciprocal
+      // square root per pivot on the critical path; the logarithms of the pivots are taken after the
+      // loop, one per lane in parallel.  Entries above the diagonal (lane < column) are never read.
       double y = (lane < k) ? sd * h : 0.0;
       double mypiv2 = 1.0;
 #pragma unroll
       for (int jx = 0; jx < KMAX; ++jx) {
-        if (jx < k) {
-          const double piv2 = __shfl(row[jx], jx);
-          const double rinv = 1.0 / sqrt(piv2);
-          if (lane == jx) mypiv2 = piv2;
-          const double lj = row[jx] * rinv;                           // column jx of L (lanes >= jx)
-          const double zj = __shfl(y, jx) * rinv;
-          if (lane == jx) y = zj;
-          if (lane > jx) y = fma(-lj, zj, y);
+        const double piv2 = readlane_f64(row[jx], jx);
+        const double rinv = 1.0 / sqrt(piv2);
+        if (lane == jx) mypiv2 = piv2;
+        const double lj = row[jx] * rinv;                             // column jx of L (lanes >= jx)
+        const double zj = readlane_f64(y, jx) * rinv;
+        y = (lane == jx) ? zj : ((lane > jx) ? fma(-lj, zj, y) : y);
 #pragma unroll
-          for (int c = jx + 1; c < KMAX; ++c) {
-            if (c < k) {
-              const double lc = __shfl(lj, c);
-              if (lane >= c) row[c] = fma(-lj, lc, row[c]);
-            }
-          }
-        }
+        for (int c = jx + 1; c < KMAX; ++c) row[c] = fma(-lj, readlane_f64(lj, c), row[c]);
       }
-      const double logdiag = (lane < k) ? 0.5 * log(mypiv2) : 0.0;
-      double ww = (lane < k) ? y * y : 0.0;
-      double ldsum = logdiag;
-      for (int off = 32; off > 0; off >>= 1) {
-        ww += __shfl_xor(ww, off);
-        ldsum += __shfl_xor(ldsum, off);
-      }
+      const double logdiag = 0.5 * log(mypiv2);                       // lanes >= k hold pivot 1
+      const double ww = sum_first_lanes<KMAX>(y * y);
+      const double ldsum = sum_first_lanes<KMAX>(logdiag);
       total += -0.5 * (quadA - ww) - 0.5 * (scal[2 * o + 1] + 2.0 * ldsum);
     }
   }
@@ -230,7 +249,8 @@ __global__ __launch_bounds__(256) void loglik_lowrank_lds_kernel(
   if (lane < d) in = (Xq[b * DPAD + lane] > lo[lane]) && (Xq[b * DPAD + lane] < hi[lane]);
   const bool inside = __all(in);
   double mu, sd;
-  walker_mean_sd(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
+  if (k <= 32) walker_mean_sd<32>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
+  else walker_mean_sd<64>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
   double total = -INFINITY;
   if (inside) {
     total = 0.0;
@@ -297,7 +317,13 @@ int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq, double *
   hipLaunchKernelGGL(loglik_lowrank_kernel<KM>, grid, block, 0, st, dXq, m->lo, m->hi, w.mean_part,  \
                      w.vsq_part, m->kdiag, m->G, m->g0, m->scal, dout, w.mean, w.var, B, w.Bcap,     \
                      (int)m->d, k, w.cur_nchunk, w.cur_nrb, (int)m->nblk, accumulate, a)
-  if (k <= 16) {
+  if (k <= 4) {
+    GP_LAUNCH_LL(4);
+  } else if (k <= 8) {
+    GP_LAUNCH_LL(8);
+  } else if (k <= 12) {
+    GP_LAUNCH_LL(12);
+  } else if (k <= 16) {
     GP_LAUNCH_LL(16);
   } else {
     size_t shm = sizeof(double) * 4 * (size_t)k * (k + 1);

@@ -127,6 +127,10 @@ class DeviceSampler:
     def reset(self):
         check(_lib.lib().gpemu_sampler_reset(self._h))
 
+    def reserve(self, steps):
+        """Grow the device chain buffer for ``steps`` more stored steps now (otherwise it grows on demand)."""
+        check(_lib.lib().gpemu_sampler_reserve_chain(self._h, int(steps)))
+
     def run(self, steps, store=True):
         rc = _lib.lib().gpemu_sampler_run(self._h, int(steps), int(bool(store)))
         if rc == 1:

@@ -195,13 +195,13 @@ def main():
     ds = DeviceSampler([dm], N_WALKERS, a=2.0, seed=1)
     ds.set_state(synthetic.make_walkers(N_WALKERS, seed=1))
 
-    def run(steps):
+    def run(steps, store=True):
         if args.emulate_world:
-            ds.run_sharded(steps, store=True, force=True, emulate_world=args.emulate_world)
+            ds.run_sharded(steps, store=store, force=True, emulate_world=args.emulate_world)
         elif world > 1:
-            ds.run_sharded(steps, store=True)
+            ds.run_sharded(steps, store=store)
         else:
-            ds.run(steps, store=True)
+            ds.run(steps, store=store)
 
     def barrier():
         if world > 1:
@@ -209,6 +209,13 @@ def main():
         torch.cuda.synchronize()
         dm.sync()
 
+    ds.reserve(args.warmup + 2 * args.steps)      # chain storage for the warm-up, timed and profiled passes
+    # Untimed pre-warm before the W warm-up steps: the clocks of an idle MI355X take tens of ms of load to
+    # ramp; with a short W the ramp otherwise lands inside the timed region (seen as a bimodal ms_per_step).
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.3:
+        run(100, store=False)
+        barrier()
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -230,13 +237,15 @@ def main():
     ms_tot, n_launch = prof["trmm_vsq"]
     roofline = None
     if n_launch > 0:
-        evals_per_launch = (N_WALKERS * args.steps) / n_launch      # 512 at N = 1, 512 / world sharded
+        split = args.emulate_world or world
+        evals_per_launch = -(-(N_WALKERS // 2) // split)            # this rank's block of a half: 512 at N = 1
         flop_per_launch = N_PC * N_DESIGN ** 2 * evals_per_launch
         avg_s = ms_tot / n_launch * 1e-3
         achieved = flop_per_launch / avg_s / 1e12
-        roofline = {"bound": "mfma", "kernel": "trmm_vsq_persistent_kernel", "achieved": achieved,
+        kern = "trmm_vsq_persistent_kernel" if evals_per_launch > 256 else "trmm_vsq_smallb_kernel"
+        roofline = {"bound": "mfma", "kernel": kern, "achieved": achieved,
                     "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": committed_traffic(world),
+                    "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": committed_traffic(split),
                     "avg_launch_us": avg_s * 1e6, "launches": n_launch,
                     "kstar_avg_launch_us": prof["kstar"][0] / max(prof["kstar"][1], 1) * 1e3}
 
