@@ -62,34 +62,71 @@ __global__ void kmat_kernel(const double *__restrict__ X, const double *__restri
 }
 
 // ---- 64 x 64 diagonal block: Cholesky + inverse ------------------------------------------------
-// 256 threads, block in LDS.  Factorisation: per column one pivot, a column scale (64 threads) and the
-// rank-1 update of the trailing triangle spread over all 256 threads (thread = row, column phase).
-// Inverse X = L^-1: wave 0, lane = column of X, forward substitution with L read from LDS (broadcast)
-// and the X column held in registers.  do_factor = 0: the block already holds the factor.
+// 256 threads, block in LDS, both phases blocked by 16 so that only 4 x 16 pivots are serial:
+//   factor   per 16-column panel: wave 0 holds the panel rows in registers (lane = row) and runs the
+//            right-looking column sweep with v_readlane broadcasts -- this factors the 16 x 16 diagonal
+//            block and solves the rows below it in one go; then all 256 threads apply the rank-16 update
+//            to the trailing lower triangle in LDS.
+//   inverse  the four 16 x 16 diagonal blocks by forward substitution (one wave each, lane = column),
+//            then two levels of  X21 = -X22 (L21 X11)  as small LDS matrix products on all threads.
+// do_factor = 0: the block already holds the factor.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda, double *Dinv, int do_factor,
                                                          int block_index, int *info) {
-  __shared__ double D[NB][NB + 1];
-  const int tid = threadIdx.x;
+  constexpr int PB = 16;
+  __shared__ double D[NB][NB + 1];     // the factor
+  __shared__ double X[NB][NB + 1];     // its inverse
+  __shared__ double T[32][32 + 1];     // L21 X11 of the merge in flight
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double *Ab = A + ((int64_t)blockIdx.x * NB) * lda + (int64_t)blockIdx.x * NB;
   double *Db = Dinv + (int64_t)blockIdx.x * NB * NB;
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
     D[r][c] = (c <= r) ? Ab[(int64_t)r * lda + c] : 0.0;
+    X[r][c] = 0.0;
   }
   __syncthreads();
   if (do_factor) {
-    const int i = tid >> 2, q = tid & 3;   // row, column phase of the trailing update
-    for (int j = 0; j < NB; ++j) {
-      const double piv2 = D[j][j];
-      if (!(piv2 > 0.0) && tid == 0 && info && *info == 0) *info = (block_index + (int)blockIdx.x) * NB + j + 1;
-      const double piv = sqrt(piv2);
-      __syncthreads();                       // everyone has read the pivot
-      if (tid == j) D[j][j] = piv;
-      if (tid > j && tid < NB) D[tid][j] = D[tid][j] / piv;
+    for (int j0 = 0; j0 < NB; j0 += PB) {
+      if (wave == 0) {
+        const int r = j0 + lane;
+        const bool act = r < NB;
+        double row[PB];
+#pragma unroll
+        for (int c = 0; c < PB; ++c) row[c] = act ? D[act ? r : 0][j0 + c] : 0.0;
+        int bad = 0;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+          const double piv2 = readlane_f64(row[j], j);
+          if (!(piv2 > 0.0) && bad == 0) bad = j0 + j + 1;
+          const double rinv = 1.0 / sqrt(piv2);
+          const double lj = row[j] * rinv;      // lanes >= j: column j0+j of L; lanes < j hold zeros
+          row[j] = lj;
+#pragma unroll
+          for (int c = j + 1; c < PB; ++c) row[c] = fma(-lj, readlane_f64(lj, c), row[c]);
+        }
+        if (bad && lane == 0 && info && *info == 0) *info = (block_index + (int)blockIdx.x) * NB + bad;
+        if (act) {
+#pragma unroll
+          for (int c = 0; c < PB; ++c)
+            if (lane >= PB || c <= lane) D[r][j0 + c] = row[c];   // nothing above the diagonal
+        }
+      }
       __syncthreads();
-      if (i > j) {
-        const double lij = D[i][j];
-        for (int c = j + 1 + q; c <= i; c += 4) D[i][c] = fma(-lij, D[c][j], D[i][c]);
+      const int t0 = j0 + PB, m = NB - t0;       // trailing block [t0, 64)^2, lower triangle
+      for (int idx = tid; idx < m * m; idx += 256) {
+        const int i = idx / m, c = idx - i * m;
+        if (c <= i) {
+          double acc = D[t0 + i][t0 + c];
+#pragma unroll
+          for (int t = 0; t < PB; ++t) acc = fma(-D[t0 + i][j0 + t], D[t0 + c][j0 + t], acc);
+          D[t0 + i][t0 + c] = acc;
+        }
       }
       __syncthreads();
     }
@@ -98,18 +135,46 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda,
       Ab[(int64_t)r * lda + c] = D[r][c];    // zeros above the diagonal
     }
   }
-  if (tid < NB) {
-    const int c = tid;
-    double inv[NB];
+  // inverse of the four 16 x 16 diagonal blocks: wave w, lane = column
+  if (lane < PB) {
+    const int b0 = wave * PB, c = lane;
+    double x[PB];
 #pragma unroll
-    for (int ii = 0; ii < NB; ++ii) {
+    for (int ii = 0; ii < PB; ++ii) {
       double sacc = (ii == c) ? 1.0 : 0.0;
 #pragma unroll
-      for (int mm = 0; mm < ii; ++mm) sacc = fma(-D[ii][mm], inv[mm], sacc);   // uniform LDS address: broadcast
-      inv[ii] = (ii >= c) ? sacc / D[ii][ii] : 0.0;
+      for (int mm = 0; mm < ii; ++mm) sacc = fma(-D[b0 + ii][b0 + mm], x[mm], sacc);   // uniform address: broadcast
+      x[ii] = (ii >= c) ? sacc / D[b0 + ii][b0 + ii] : 0.0;
     }
 #pragma unroll
-    for (int ii = 0; ii < NB; ++ii) Db[ii * NB + c] = inv[ii];
+    for (int ii = 0; ii < PB; ++ii) X[b0 + ii][b0 + c] = x[ii];
+  }
+  __syncthreads();
+  // merge pairs of inverted diagonal blocks of size b into blocks of size 2b
+  for (int b = PB; b < NB; b *= 2) {
+    const int npair = NB / (2 * b);
+    // T = L21 . X11 for every pair (X11 lower triangular: k >= column)
+    for (int idx = tid; idx < npair * b * b; idx += 256) {
+      const int pr = idx / (b * b), rem = idx - pr * b * b, i = rem / b, c = rem - i * b;
+      const int p0 = pr * 2 * b;
+      double acc = 0.0;
+      for (int kk = c; kk < b; ++kk) acc = fma(D[p0 + b + i][p0 + kk], X[p0 + kk][p0 + c], acc);
+      T[(pr * b + i) & 31][c] = acc;
+    }
+    __syncthreads();
+    // X21 = -X22 . T  (X22 lower triangular: k <= row)
+    for (int idx = tid; idx < npair * b * b; idx += 256) {
+      const int pr = idx / (b * b), rem = idx - pr * b * b, i = rem / b, c = rem - i * b;
+      const int p0 = pr * 2 * b;
+      double acc = 0.0;
+      for (int kk = 0; kk <= i; ++kk) acc = fma(X[p0 + b + i][p0 + b + kk], T[(pr * b + kk) & 31][c], acc);
+      X[p0 + b + i][p0 + c] = -acc;
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < NB * NB; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    Db[idx] = X[r][c];
   }
 }
 
@@ -224,6 +289,34 @@ __global__ void gemv_kernel(const double *__restrict__ Mx, int64_t ld, const dou
     for (int j = 0; j < n; ++j) s = fma(Mx[(int64_t)j * ld + col], v[j], s);
     out[col] = s;
   }
+}
+
+// out[col] = sum_j M[j][col] v[j] in two deterministic passes: 64-row chunks (grid.y) into part[chunk][col],
+// then a column sum over the chunks
+__global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double *__restrict__ Mx, int64_t ld,
+                                                             const double *__restrict__ v, double *__restrict__ part,
+                                                             int n) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int j0 = blockIdx.y * 64;
+  if (col >= n) return;
+  double s0 = 0.0, s1 = 0.0;
+  const int j1 = (j0 + 64 < n) ? j0 + 64 : n;
+  int j = j0;
+  for (; j + 1 < j1; j += 2) {
+    s0 = fma(Mx[(int64_t)j * ld + col], v[j], s0);
+    s1 = fma(Mx[(int64_t)(j + 1) * ld + col], v[j + 1], s1);
+  }
+  if (j < j1) s0 = fma(Mx[(int64_t)j * ld + col], v[j], s0);
+  part[(int64_t)blockIdx.y * n + col] = s0 + s1;
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const double *__restrict__ part, int nchunk, int n,
+                                                     double *__restrict__ out) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= n) return;
+  double s = 0.0;
+  for (int c = 0; c < nchunk; ++c) s += part[(int64_t)c * n + col];
+  out[col] = s;
 }
 
 // scal[0] = y.alpha ; scal[1] = sum_{i<N} log L_ii   (one workgroup)
@@ -416,7 +509,13 @@ static int fit_eval(gpemu_fit *f, const double *y, const double *theta, int64_t 
   GP_TRY(device_trtri_blocked(f->K, Np, f->Dinv, f->W, f->T, st));
   // alpha = W^T (W y)
   hipLaunchKernelGGL(gemv_kernel, dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, st, f->W, Np, f->y, f->v, (int)Np, 0);
-  hipLaunchKernelGGL(gemv_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, f->W, Np, f->v, f->alpha, (int)Np, 1);
+  {
+    const int nchunk = (int)((Np + 63) / 64);                 // T (Np x Np) is free again after the inverse
+    hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)nchunk), dim3(256), 0, st,
+                       f->W, Np, f->v, f->T, (int)Np);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, f->T, nchunk, (int)Np,
+                       f->alpha);
+  }
   hipLaunchKernelGGL(lml_terms_kernel, dim3(1), dim3(1024), 0, st, f->y, f->alpha, f->K, Np, (int)N, f->scal);
   GP_HIP(hipGetLastError());
   if (want_grad) {
