@@ -102,7 +102,8 @@ class DeviceSampler:
 
     def close(self):
         for h in self.__dict__.pop("_comms", {}).values():
-            _lib.lib().gpemu_comm_destroy(h)
+            if h is not None:
+                _lib.lib().gpemu_comm_destroy(h)
         if getattr(self, "_h", None):
             _lib.lib().gpemu_sampler_destroy(self._h)
             self._h = None
@@ -190,6 +191,30 @@ class DeviceSampler:
         comms[key] = h
         return h
 
+    def _rccl_comm_agreed(self, group):
+        """The library's communicator, or None on every rank if any rank failed to create it (the ranks
+        agree through a torch.distributed all-reduce, so they all take the same transport)."""
+        import warnings
+        import torch
+        import torch.distributed as dist
+        key = id(group) if group is not None else 0
+        if key in self.__dict__.get("_comms", {}):
+            return self._comms[key]
+        comm, err = None, None
+        try:
+            comm = self._rccl_comm(group)
+        except Exception as e:      # missing librccl symbol, ncclCommInitRank failure, ...
+            err = e
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=torch.device("cuda", self.device))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 1:
+            return comm
+        if comm is not None:
+            _lib.lib().gpemu_comm_destroy(self._comms.pop(key))
+        warnings.warn(f"library-owned RCCL communicator unavailable ({err!r}); using torch.distributed's all-gather")
+        self.__dict__.setdefault("_comms", {})[key] = None
+        return None
+
     def run_sharded(self, steps, store=True, group=None, force=False, emulate_world=None, transport=None):
         """Same chain as ``run`` (every rank draws identical randomness); rank r evaluates its
         block of each half's proposals and the log-probabilities are all-gathered.
@@ -210,7 +235,10 @@ class DeviceSampler:
         on_device = dist.get_backend(group) == "nccl"
         transport = transport or os.environ.get("GPEMU_SHARDED_TRANSPORT", "rccl")
         if on_device and transport == "rccl":
-            comm = self._rccl_comm(group)
+            comm = self._rccl_comm_agreed(group)
+            if comm is None:
+                transport = "torch"
+        if on_device and transport == "rccl":
             rc = L.gpemu_sampler_run_sharded(self._h, comm, int(steps), int(bool(store)), int(emulate_world or 0))
             if rc == 1:
                 raise ValueError("Probability function returned NaN")

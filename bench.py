@@ -276,6 +276,8 @@ def main():
                "acceptance_fraction_mean": float((nacc / max(iters, 1)).mean()),
                "roofline": roofline, "cpu_baseline": cpu, "gp_predict": predict}
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()          # rank 0 also measured metric 2 / printed; tear down together
     ds.close()
     dm.close()
     if world > 1 or args.emulate_world:
