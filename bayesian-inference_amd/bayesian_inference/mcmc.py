@@ -28,14 +28,29 @@ def _data_IO():
     return data_IO
 
 
-def _rank():
+def _rank_world():
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
-            return dist.get_rank()
+            return dist.get_rank(), dist.get_world_size()
     except Exception:
         pass
-    return 0
+    return 0, 1
+
+
+def _rank():
+    return _rank_world()[0]
+
+
+def closure_owner(closure_index, world):
+    """Closure tests (ref: steer_analysis.py:168-183) are independent chains, one per validation design
+    point: with one process per GPU every rank walks the caller's loop, rank ``closure_index % world``
+    runs that chain whole on its GPU and writes its own ``closure/results/<index>/`` files, the others skip
+    it -- N chains in flight on N GPUs, no communication.  GPEMU_CLOSURE_REPLICAS=0 restores walker
+    sharding for closure runs too."""
+    if closure_index < 0 or world <= 1 or os.environ.get("GPEMU_CLOSURE_REPLICAS", "1") == "0":
+        return None
+    return closure_index % world
 
 
 ####################################################################################################
@@ -45,6 +60,12 @@ def run_mcmc(config, closure_index=-1):
     par = config.analysis_config['parameterization'][config.parameterization]
     names, lo, hi = par['names'], par['min'], par['max']
     ndim = len(names)
+    rank, world = _rank_world()
+    owner = closure_owner(closure_index, world)
+    if owner is not None and owner != rank:
+        logger.info(f'closure test {closure_index}: runs on rank {owner}')
+        return
+    replica = owner is not None          # this rank runs the whole chain alone
 
     emulation_config = emulation.EmulationConfig.from_config_file(
         analysis_name=config.analysis_name, parameterization=config.parameterization,
@@ -56,14 +77,22 @@ def run_mcmc(config, closure_index=-1):
     experimental_results = data_IO.data_array_from_h5(config.output_dir, 'observables.h5', pseudodata_index=closure_index,
                                                       observable_filter=emulation_config.observable_filter)
 
+    if closure_index >= 0 and world > 1 and not replica:
+        # walker-sharded closure run: the pseudo-data carries random smearing (ref: data_IO.py:371), every
+        # rank must condition on rank 0's draw
+        experimental_results = dict(experimental_results)
+        for key in ('y', 'y_err'):
+            experimental_results[key] = _broadcast_from_rank0(np.asarray(experimental_results[key], dtype=np.float64))
     # the reference replicates this state into every pool worker (mcmc.py:77-78); here it is uploaded once
     log_posterior.initialize_pool_variables(lo, hi, emulation_config, emulation_results, experimental_results,
                                             emulator_cov_unexplained)
     logger.info('Initializing sampler...')
-    sampler = LoggingEnsembleSampler(config.n_walkers, ndim, log_posterior.log_posterior)
+    sampler = LoggingEnsembleSampler(config.n_walkers, ndim, log_posterior.log_posterior,
+                                     sharded=False if replica else None)
 
     random_pos = np.random.uniform(lo, hi, (config.n_walkers, ndim))
-    random_pos = _broadcast_from_rank0(random_pos)
+    if not replica:
+        random_pos = _broadcast_from_rank0(random_pos)
 
     logger.info(f'Parallelizing over {sampler.world_size} GPU process(es)...')
     logger.info('Starting initial burn-in...')
@@ -80,7 +109,7 @@ def run_mcmc(config, closure_index=-1):
     logger.info('Starting production...')
     sampler.run_mcmc(X0, config.n_sampling_steps, n_logging_steps=config.n_logging_steps)
 
-    if _rank() != 0:
+    if rank != 0 and not replica:
         return
     logger.info('Writing chain to file...')
     output_dict = {}

@@ -415,8 +415,9 @@ class EnsembleSampler:
     """
 
     def __init__(self, nwalkers, ndim, log_prob_fn, pool=None, a=2.0, seed=None, vectorize=False,
-                 args=None, kwargs=None, **_ignored):
+                 args=None, kwargs=None, sharded=None, **_ignored):
         self.nwalkers, self.ndim = int(nwalkers), int(ndim)
+        self._sharded = sharded          # None: shard whenever torch.distributed has more than one rank
         self.log_prob_fn = log_prob_fn
         self.pool = pool
         self.a = float(a)
@@ -429,6 +430,8 @@ class EnsembleSampler:
     # -- backends -------------------------------------------------------------------------------
     @property
     def world_size(self):
+        if self._sharded is False:       # an independent chain on this rank (replica parallelism)
+            return 1
         try:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():

@@ -156,3 +156,49 @@ def test_sharded_host_ensemble_gloo_world2(tmp_path):
     he.set_state(np.random.default_rng(9).normal(size=(W, d)))
     he.run(30)
     np.testing.assert_array_equal(np.stack(he.chain), c0)   # and it equals the single-process chain
+
+
+# ---- closure tests as independent replicas (one chain per rank) ---------------------------------
+def _closure_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bayesian_inference import mcmc
+    from gpemu.sampler import EnsembleSampler
+
+    class Cfg:      # only what run_mcmc reads before it decides who owns the closure index
+        parameterization = "p"
+        analysis_config = {"parameterization": {"p": {"names": ["a", "b"], "min": [0.0, 0.0], "max": [1.0, 1.0]}}}
+
+    skipped = []
+    for idx in range(5):
+        if mcmc.closure_owner(idx, world) != rank:
+            assert mcmc.run_mcmc(Cfg(), closure_index=idx) is None      # returns before touching any file or GPU
+            skipped.append(idx)
+    # a replica sampler is unsharded even though torch.distributed has two ranks: different seeds per rank
+    # give different chains and no collective is entered (a sharded run with unequal step counts would hang)
+    f = _gauss_logp(np.array([0.2, -0.1]), np.eye(2))
+    es = EnsembleSampler(12, 2, f, seed=100 + rank, vectorize=True, sharded=False)
+    assert es.world_size == 1
+    es.run_mcmc(np.random.default_rng(rank).normal(size=(12, 2)), 5 + 3 * rank)
+    np.save(os.path.join(out_dir, f"skipped_{rank}.npy"), np.array(skipped))
+    np.save(os.path.join(out_dir, f"chain_{rank}.npy"), es.get_chain())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_closure_tests_run_as_replicas_gloo_world2(tmp_path, monkeypatch):
+    import torch.multiprocessing as mp
+    from bayesian_inference import mcmc
+    assert mcmc.closure_owner(-1, 8) is None and mcmc.closure_owner(3, 1) is None
+    assert [mcmc.closure_owner(i, 4) for i in range(6)] == [0, 1, 2, 3, 0, 1]
+    monkeypatch.setenv("GPEMU_CLOSURE_REPLICAS", "0")
+    assert mcmc.closure_owner(3, 4) is None
+    monkeypatch.delenv("GPEMU_CLOSURE_REPLICAS")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_closure_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    s0, s1 = np.load(tmp_path / "skipped_0.npy"), np.load(tmp_path / "skipped_1.npy")
+    assert sorted(np.r_[s0, s1]) == [0, 1, 2, 3, 4] and list(s0) == [1, 3] and list(s1) == [0, 2, 4]
+    assert np.load(tmp_path / "chain_0.npy").shape == (5, 12, 2)
+    assert np.load(tmp_path / "chain_1.npy").shape == (8, 12, 2)
