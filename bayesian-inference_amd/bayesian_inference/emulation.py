@@ -105,15 +105,9 @@ def fit_emulator_group(config: "EmulationGroupConfig") -> dict[str, Any]:
     logger.info("")
     logger.info('Fitting GPs...')
     logger.info(f'  The design has {design.shape[1]} parameters')
-    from gpemu.fit import DeviceFit
-    dfit = DeviceFit(design, kernel.kind, kernel.nu, kernel.has_const, kernel.has_noise, config.alpha)
-    try:
-        emulators = [estimators.GaussianProcessRegressor(kernel=kernel, alpha=config.alpha,
-                                                         n_restarts_optimizer=config.n_restarts,
-                                                         copy_X_train=False).fit(design, y, _device_fit=dfit)
-                     for y in Y_pca_truncated.T]
-    finally:
-        dfit.close()
+    # the n_pc GPs and their restarts are independent optimisations: run them concurrently on the device
+    emulators = estimators.fit_gps(design, Y_pca_truncated, kernel, alpha=config.alpha,
+                                   n_restarts_optimizer=config.n_restarts, copy_X_train=False)
 
     logger.info("")
     logger.info('Kernel hyperparameters:')

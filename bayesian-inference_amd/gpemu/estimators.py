@@ -9,6 +9,7 @@ without scikit-learn.  All arithmetic runs on the device through libgpemu; there
 from __future__ import annotations
 
 import math
+import os
 import warnings
 from operator import itemgetter
 
@@ -220,6 +221,20 @@ class GaussianProcessRegressor:
         self._y_train_mean, self._y_train_std = 0.0, 1.0
         return self
 
+    def _adopt(self, dfit, X, y, optima):
+        """Take the best of ``optima`` [(theta, -lml)] and factorise there (skl _gpr.py:339-364)."""
+        self.X_train_, self.y_train_ = X, y
+        if not hasattr(self, "kernel_"):
+            self.kernel_ = self.kernel.clone()
+        k = self.kernel_
+        if optima:
+            lml_values = list(map(itemgetter(1), optima))
+            k.theta = optima[int(np.argmin(lml_values))][0]
+            self._check_bounds(k)
+        self.L_, self.alpha_, self.log_marginal_likelihood_value_ = dfit.factor(y, k.theta)
+        self._y_train_mean, self._y_train_std = 0.0, 1.0
+        return self
+
     @staticmethod
     def _check_bounds(k):
         th, b = k.theta, k.bounds
@@ -258,3 +273,72 @@ class GaussianProcessRegressor:
         if return_std:
             return mean[:, 0], np.sqrt(var[:, 0])
         return mean[:, 0]
+
+
+def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy_X_train=False, device=0,
+            n_streams=None):
+    """One GaussianProcessRegressor per column of ``Y_columns`` (N x k), fitted concurrently.
+
+    The k GPs and their restarts are ``k (1 + n_restarts)`` independent L-BFGS-B problems on the same design
+    (ref: emulation.py:169-172 fits them one after the other).  They are spread over a pool of host threads,
+    each driving its own ``DeviceFit`` -- its own HIP stream and workspace -- so that the short, latency-bound
+    kernels of one log-marginal-likelihood evaluation overlap with those of the others on the GPU.  The
+    restart points are drawn first, from numpy's global RandomState in the order the sequential loop draws
+    them, so the result does not depend on the thread schedule.  ``n_streams`` (env GPEMU_FIT_STREAMS,
+    default 8): 1 reproduces the sequential loop.
+    """
+    import concurrent.futures
+    import threading
+
+    X = np.array(design, dtype=np.float64) if copy_X_train else np.asarray(design, dtype=np.float64)
+    Yc = np.asarray(Y_columns, dtype=np.float64)
+    k_gp = Yc.shape[1]
+    gprs = [GaussianProcessRegressor(kernel=kernel, alpha=alpha, n_restarts_optimizer=n_restarts_optimizer,
+                                     copy_X_train=copy_X_train, device=device) for _ in range(k_gp)]
+    for g in gprs:
+        g.kernel_ = g.kernel.clone()
+    kk = gprs[0].kernel_ if gprs else None
+    optimise = bool(gprs) and gprs[0].optimizer is not None and kk.n_dims > 0
+    starts = [[] for _ in range(k_gp)]
+    if optimise:
+        bounds = kk.bounds
+        if n_restarts_optimizer > 0 and not np.isfinite(bounds).all():
+            raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) requires that all "
+                             "bounds are finite.")
+        rng = np.random.mtrand._rand
+        for i in range(k_gp):
+            starts[i].append(np.array(kk.theta))
+            for _ in range(n_restarts_optimizer):
+                starts[i].append(rng.uniform(bounds[:, 0], bounds[:, 1]))
+    if n_streams is None:
+        n_streams = int(os.environ.get("GPEMU_FIT_STREAMS", "8"))
+    tasks = [(i, j) for i in range(k_gp) for j in range(len(starts[i]))]
+    n_threads = max(1, min(int(n_streams), max(len(tasks), k_gp)))
+    local = threading.local()
+    handles, hlock = [], threading.Lock()
+
+    def dfit():
+        if getattr(local, "dfit", None) is None:
+            local.dfit = _fit.DeviceFit(X, kk.kind, kk.nu, kk.has_const, kk.has_noise, alpha, device)
+            with hlock:
+                handles.append(local.dfit)
+        return local.dfit
+
+    def run_start(task):
+        i, j = task
+        return gprs[i]._optimise(dfit(), Yc[:, i], starts[i][j], kk.bounds)
+
+    def finish(i, optima):
+        return gprs[i]._adopt(dfit(), X, Yc[:, i], optima)
+
+    try:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=n_threads) as pool:
+            optima = list(pool.map(run_start, tasks))
+            per_gp = [[] for _ in range(k_gp)]
+            for (i, _j), opt in zip(tasks, optima):
+                per_gp[i].append(opt)
+            list(pool.map(finish, range(k_gp), per_gp))
+    finally:
+        for h in handles:
+            h.close()
+    return gprs

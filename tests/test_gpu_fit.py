@@ -116,3 +116,28 @@ def test_scaler_pca_vs_reference(name):
     out5 = pca_fit(Y, n_components=k)
     np.testing.assert_array_equal(out5["components"], out["components"][:k])
     assert 2 <= out["n_sweeps"] <= 30
+
+
+def test_concurrent_gp_fits_equal_the_sequential_loop():
+    """fit_gps (k GPs x (1 + restarts) optimisations over a pool of host threads, one DeviceFit / HIP stream each)
+    gives exactly what the sequential per-PC loop gives for the same numpy seed."""
+    from gpemu import estimators as E
+    g = GU.load("g1_matern15_noise")
+    spec = GU.spec_of(g)
+    X, Yc = g["design"], g["Y_pca_truncated"]
+    ls0 = g["hi"] - g["lo"]
+    kern = E.ARDKernel(kind=spec.kind, nu=spec.nu, length_scale=ls0,
+                       length_scale_bounds=np.outer(ls0, (0.01, 100.0)), noise_level=0.1,
+                       noise_level_bounds=(1e-3, 1e1))
+    np.random.seed(99)
+    seq = [E.GaussianProcessRegressor(kernel=kern, alpha=1e-10, n_restarts_optimizer=2).fit(X, y) for y in Yc.T]
+    np.random.seed(99)
+    par = E.fit_gps(X, Yc, kern, alpha=1e-10, n_restarts_optimizer=2, n_streams=6)
+    np.random.seed(99)
+    one = E.fit_gps(X, Yc, kern, alpha=1e-10, n_restarts_optimizer=2, n_streams=1)
+    for a, b, c in zip(seq, par, one):
+        np.testing.assert_array_equal(a.kernel_.theta, b.kernel_.theta)
+        np.testing.assert_array_equal(a.kernel_.theta, c.kernel_.theta)
+        np.testing.assert_array_equal(a.L_, b.L_)
+        np.testing.assert_array_equal(a.alpha_, b.alpha_)
+        assert a.log_marginal_likelihood_value_ == b.log_marginal_likelihood_value_
