@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void predict_full_rows_kernel(
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *cf = sm;                    // [k][PR_ROWS]
   double *cg = cf + k * PR_ROWS;      // [k][PR_COLS]
-  double *wv = cg + k * PR_COLS;      // [k]
+  double *wv = cg + k * PR_COLS;      // [PF_NB][k]  variances of this workgroup's samples
   const int tid = threadIdx.x;
   const int g0 = blockIdx.x * PR_COLS, f0 = blockIdx.y * PR_ROWS;
   const int64_t bb0 = (int64_t)blockIdx.z * PF_NB;
@@ -125,6 +125,10 @@ __global__ __launch_bounds__(256) void predict_full_rows_kernel(
   for (int idx = tid; idx < k * PR_COLS; idx += 256) {
     int p = idx / PR_COLS, g = g0 + idx % PR_COLS;
     cg[idx] = (g < F) ? comp[(int64_t)p * F + g] : 0.0;
+  }
+  for (int idx = tid; idx < k * PF_NB; idx += 256) {
+    const int64_t b = bb0 + idx / k;
+    wv[idx] = (b < B) ? var[b * k + idx % k] : 0.0;
   }
   double cu[PR_ROWS][2], ss[PR_ROWS][2];
 #pragma unroll
@@ -141,14 +145,12 @@ __global__ __launch_bounds__(256) void predict_full_rows_kernel(
   for (int ib = 0; ib < PF_NB; ++ib) {
     const int64_t b = bb0 + ib;
     if (b >= B) break;
-    __syncthreads();
-    if (tid < k) wv[tid] = var[b * k + tid];
-    __syncthreads();
+    if (ib == 0) __syncthreads();
     double acc[PR_ROWS][2];
 #pragma unroll
     for (int r = 0; r < PR_ROWS; ++r) acc[r][0] = acc[r][1] = 0.0;
     for (int p = 0; p < k; ++p) {
-      const double v = wv[p];
+      const double v = wv[ib * k + p];
       const double b0v = cg[p * PR_COLS + c0] * v, b1v = cg[p * PR_COLS + c1] * v;
 #pragma unroll
       for (int r = 0; r < PR_ROWS; ++r) {
@@ -183,29 +185,30 @@ __global__ __launch_bounds__(256) void predict_full_rows_kernel(
 
 int launch_predict_full(gpemu_model *m, int64_t B, double n_div, double *dcv, double *dcov, hipStream_t st) {
   const int F = (int)m->F, k = (int)m->k;
+  const double *dmean = m->ws.mean, *dvar = m->ws.var;
   dim3 grid((unsigned)((F + PF_TG - 1) / PF_TG), (unsigned)((F + PF_TF - 1) / PF_TF),
             (unsigned)((B + PF_NB - 1) / PF_NB));
   size_t shm = sizeof(double) * (size_t)(k * (PF_TF + PF_TG) + k);
   // 16-byte stores need every row start of dcov 16-byte aligned: F even and an aligned base
   const bool pair = F % 2 == 0 && (reinterpret_cast<uintptr_t>(dcov) & 15) == 0;
-  const size_t shm_rows = sizeof(double) * (size_t)(k * (PR_ROWS + PR_COLS) + k);
+  const size_t shm_rows = sizeof(double) * (size_t)(k * (PR_ROWS + PR_COLS) + k * PF_NB);
   if (shm_rows <= 64 * 1024) {   // whole rows per workgroup: contiguous store streams
     dim3 g2((unsigned)((F + PR_COLS - 1) / PR_COLS), (unsigned)((F + PR_ROWS - 1) / PR_ROWS),
             (unsigned)((B + PF_NB - 1) / PF_NB));
     if (pair)
-      hipLaunchKernelGGL(predict_full_rows_kernel<true>, g2, dim3(256), shm_rows, st, m->ws.mean, m->ws.var, m->comp,
+      hipLaunchKernelGGL(predict_full_rows_kernel<true>, g2, dim3(256), shm_rows, st, dmean, dvar, m->comp,
                          m->smean, m->sscale, m->cunexpl, dcv, dcov, B, F, k, 1.0 / n_div);
     else
-      hipLaunchKernelGGL(predict_full_rows_kernel<false>, g2, dim3(256), shm_rows, st, m->ws.mean, m->ws.var, m->comp,
+      hipLaunchKernelGGL(predict_full_rows_kernel<false>, g2, dim3(256), shm_rows, st, dmean, dvar, m->comp,
                          m->smean, m->sscale, m->cunexpl, dcv, dcov, B, F, k, 1.0 / n_div);
     GP_HIP(hipGetLastError());
     return GPEMU_OK;
   }
   if (pair)
-    hipLaunchKernelGGL(predict_full_kernel<true>, grid, dim3(256), shm, st, m->ws.mean, m->ws.var, m->comp,
+    hipLaunchKernelGGL(predict_full_kernel<true>, grid, dim3(256), shm, st, dmean, dvar, m->comp,
                        m->smean, m->sscale, m->cunexpl, dcv, dcov, B, F, k, 1.0 / n_div);
   else
-    hipLaunchKernelGGL(predict_full_kernel<false>, grid, dim3(256), shm, st, m->ws.mean, m->ws.var, m->comp,
+    hipLaunchKernelGGL(predict_full_kernel<false>, grid, dim3(256), shm, st, dmean, dvar, m->comp,
                        m->smean, m->sscale, m->cunexpl, dcv, dcov, B, F, k, 1.0 / n_div);
   GP_HIP(hipGetLastError());
   return GPEMU_OK;

@@ -35,6 +35,25 @@ __global__ __launch_bounds__(256) void fill16_nt(d2 *p, size_t n16, size_t piece
   }
 }
 
+// the covariance writer's pattern: workgroup = 8 rows x 500 doubles (32,000 B contiguous) of one 500 x 500 sample,
+// thread t stores 16 B at row * 4000 + 16 t (t < 250), i.e. rows start 32 B off the 128-byte lines;
+// flat = 1: the same 32,000 bytes written as a flat aligned stream instead
+__global__ __launch_bounds__(256) void rows500(double *p, int nsamples, int flat, double v) {
+  // grid: (63 row blocks, nsamples / 8); each workgroup walks 8 samples like predict_full_rows_kernel
+  const int rb = blockIdx.x;
+  for (int ib = 0; ib < 8; ++ib) {
+    const size_t sample = (size_t)blockIdx.y * 8 + ib;
+    double *base = p + sample * 250000 + (size_t)rb * 4000;
+    const int rows = (rb == 62) ? 4 : 8;
+    if (flat) {
+      for (int e = 2 * threadIdx.x; e < rows * 500; e += 512) *reinterpret_cast<d2 *>(base + e) = d2{v, v + 1.0};
+    } else {
+      if (threadIdx.x < 250)
+        for (int r = 0; r < rows; ++r) *reinterpret_cast<d2 *>(base + r * 500 + 2 * threadIdx.x) = d2{v, v + 1.0};
+    }
+  }
+}
+
 int main() {
   const size_t bytes = (size_t)2 << 30;   // 2 GiB, the size of one 1024-sample covariance batch at F = 500
   d2 *p = nullptr;
@@ -66,6 +85,22 @@ int main() {
   }
   time_it("fill16_nt grid=2048 piece=32768 B",
           [&] { hipLaunchKernelGGL(fill16_nt, dim3(2048), dim3(256), 0, 0, p, n16, (size_t)32768 / 16, 1.0); });
+  {
+    const int ns = 1024;   // 1024 x 500 x 500 doubles = 2.048e9 B
+    auto t2 = [&](const char *name, int flat) {
+      for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(rows500, dim3(63, ns / 8), dim3(256), 0, 0, (double *)p, ns, flat, 1.0);
+      (void)hipDeviceSynchronize();
+      (void)hipEventRecord(e0);
+      for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(rows500, dim3(63, ns / 8), dim3(256), 0, 0, (double *)p, ns, flat, 1.0);
+      (void)hipEventRecord(e1);
+      (void)hipEventSynchronize(e1);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      printf("%-44s %8.3f ms  %7.1f GB/s\n", name, ms / 10, 2.048e9 / (ms / 10 * 1e-3) / 1e9);
+    };
+    t2("rows500 (writer pattern, 32 B-offset rows)", 0);
+    t2("rows500 flat (aligned 1 KiB wave stores)", 1);
+  }
   CK(hipFree(p));
   return 0;
 }

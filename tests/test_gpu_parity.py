@@ -162,7 +162,7 @@ def test_many_pcs_lds_likelihood_path(k):
 
 
 def test_large_batch_is_chunked():
-    """B larger than one pass of the pipeline (2048 rows) gives the same rows as small calls."""
+    """B larger than one pass of the pipeline (512 rows) gives the same rows as small calls."""
     from gpemu import synthetic
     g, model = _load("g1_rbf_noise")
     dm = GU.device_model(model)
@@ -174,9 +174,13 @@ def test_large_batch_is_chunked():
     np.testing.assert_array_equal(lp[:300], dm.logpost(X[:300]))
     np.testing.assert_allclose(lp[4090:4200], dm.logpost(X[4090:4200]), rtol=1e-12)
     m, v = dm.gp_predict(X)
-    m2, v2 = dm.gp_predict(X[2040:2060])
+    m2, v2 = dm.gp_predict(X[2040:2060])          # straddles the pass boundary at row 2048
     np.testing.assert_allclose(m[2040:2060], m2, rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(v[2040:2060], v2, rtol=1e-12, atol=1e-15)
+    cv, cov = dm.predict_full(X[:1100], n_div=1100.0)
+    cv2, cov2 = dm.predict_full(X[500:530], n_div=1100.0)
+    np.testing.assert_allclose(cv[500:530], cv2, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(cov[500:530], cov2, rtol=1e-12, atol=1e-16)
     dm.close()
 
 
