@@ -476,6 +476,201 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_persistent_kernel(
 
 
 // ------------------------------------------------------------------------------------------
+// LDS-direct variant of the persistent kernel: the k-tiles are streamed from L2 into LDS by
+// global_load_lds_dwordx4 (each wave-load lands as one contiguous 1 KiB chunk, lane l -> bytes 16 l .. 16 l + 15),
+// so there is no register staging and no ds_write on the waves' instruction streams.  The LDS tiles are
+// unpadded, k-major ([k][64] for W, [k][128] for K_*^T); bank conflicts of the fragment reads are avoided by
+// storing the odd k-rows with their 16-double blocks swapped (position = index ^ 16) -- the swizzle is applied
+// on the GLOBAL side (which pair a lane fetches), the LDS side of a DMA load is always contiguous.  Two LDS
+// buffers as distinct arrays (so that hipcc's waitcnt insertion can tell the buffer being filled from the
+// one being read); three buffers: the loads of k-tile s+2 are issued at the start of k-tile s and the barrier
+// that ends k-tile s waits (s_waitcnt vmcnt(6), written by hand) only for the loads of k-tile s+1.
+typedef const __attribute__((address_space(1))) void *gas_ptr;
+typedef __attribute__((address_space(3))) void *las_ptr;
+
+__global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
+    const double *__restrict__ Wt, const double *__restrict__ KS, double *__restrict__ out,
+    const TrmmItem *__restrict__ sched, const int *__restrict__ sched_cnt, int max_items,
+    int64_t Npad, int64_t Bcap, int k, int nrb) {
+  constexpr int BUFD = KT * TM + KT * TILE;            // one k-tile: [W tile | K_*^T tile], 48 KiB
+  __shared__ __attribute__((aligned(16))) double L0[BUFD];
+  __shared__ __attribute__((aligned(16))) double L1[BUFD];
+  __shared__ __attribute__((aligned(16))) double L2[BUFD];
+  __shared__ double red[2][TILE];
+  __shared__ TrmmItem s_items[TRMM_MAX_ITEMS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 15, lk = lane >> 4;
+
+  const int nitems = sched_cnt[blockIdx.x];
+  if (tid < nitems) s_items[tid] = sched[(int64_t)blockIdx.x * max_items + tid];
+  __syncthreads();
+  if (nitems == 0) return;
+  const TrmmItem *my = s_items;
+
+  // per-lane source offsets (doubles) of the wave's six 1 KiB chunks of a k-tile
+  int offA[2], offB[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int kk = 2 * (wave * 2 + j) + (lane >> 5);          // chunk = two k-rows of the W tile
+    offA[j] = kk * (int)Npad + ((2 * (lane & 31)) ^ ((kk & 1) << 4));
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int kk = wave * 4 + r;                              // chunk = one k-row of the K_*^T tile
+    offB[r] = kk * (int)Bcap + ((2 * lane) ^ ((kk & 1) << 4));
+  }
+  const int64_t astep = (int64_t)KT * Npad, bstep = (int64_t)KT * Bcap;
+
+  // ---- load cursor (one k-tile ahead of the compute cursor) ----
+  int l_item = 0, l_t = 0, l_nt = 1;
+  const double *l_pa = Wt, *l_pb = KS;
+  auto l_open = [&]() {
+    const TrmmItem it = my[l_item];
+    const int64_t i0 = (int64_t)it.rb * TM;
+    l_nt = (int)((i0 + TM + KT - 1) / KT);
+    l_pa = Wt + (int64_t)it.p * Npad * Npad + i0;
+    l_pb = KS + (int64_t)it.p * Npad * Bcap + (it.col0 & ~(TILE - 1));
+    l_t = 0;
+  };
+  // Issued as inline assembly: with the builtin, hipcc's waitcnt insertion treats every later LDS read as a
+  // possible reader of the in-flight destination and drains vmcnt to 0, which defeats the two-tile lookahead;
+  // the waits for these loads are the hand-written s_waitcnt vmcnt(6) of tile_barrier().
+  auto dma1 = [&](const double *src, double *dst_wave_uniform) {
+    const unsigned lds_off = (unsigned)(uintptr_t)((las_ptr)dst_wave_uniform);
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+                 :
+                 : "s"(lds_off), "v"(src)
+                 : "memory");
+  };
+  auto dma = [&](double *dA) {
+    double *dB = dA + KT * TM;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma1(l_pa + offA[j], dA + (wave * 2 + j) * 128);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dma1(l_pb + offB[r], dB + (wave * 4 + r) * 128);
+    if (l_item < nitems) {
+      if (++l_t == l_nt) {
+        if (++l_item < nitems) l_open();   // else: stay on the last k-tile (harmless re-read)
+      } else {
+        l_pa += astep;
+        l_pb += bstep;
+      }
+    }
+  };
+
+  // vmcnt(6) lgkmcnt(0): everything but this wave's six newest loads has landed, every LDS read has returned
+  auto tile_barrier = [&]() {
+    __builtin_amdgcn_s_waitcnt(0x0076);
+    __builtin_amdgcn_s_barrier();
+  };
+  l_open();
+  dma(L0);
+  dma(L1);
+  tile_barrier();
+
+  d4 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+
+  int c_item = 0, c_t = 0;
+  TrmmItem cur = my[0];
+  int c_nt = (int)(((int64_t)cur.rb * TM + TM + KT - 1) / KT);
+  const int sw = (lk & 1) << 4;                                 // this lane's k-rows are odd <=> lk odd
+  const int ia0 = lk * TM + ((wm * 32 + lr) ^ sw), ia1 = lk * TM + ((wm * 32 + 16 + lr) ^ sw);
+
+  auto step = [&](const double *cA, double *nA) -> bool {
+    const double *cB = cA + KT * TM;
+    dma(nA);                                                    // k-tile +2 -> the buffer k-tile -1 was read from
+    if (cur.half) {
+      const int ib = lk * TILE + (((cur.col0 & 64) + wn * 16 + lr) ^ sw);
+      double a[2][2], b[2];
+      a[0][0] = cA[ia0];
+      a[0][1] = cA[ia1];
+      b[0] = cB[ib];
+#pragma unroll
+      for (int ks = 0; ks < KT / 4; ++ks) {
+        const int cu = ks & 1, nx = cu ^ 1;
+        if (ks + 1 < KT / 4) {
+          a[nx][0] = cA[(ks + 1) * 4 * TM + ia0];
+          a[nx][1] = cA[(ks + 1) * 4 * TM + ia1];
+          b[nx] = cB[(ks + 1) * 4 * TILE + ib];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[mi][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cu][mi], b[cu], acc[mi][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      const int ib0 = lk * TILE + ((wn * 32 + lr) ^ sw), ib1 = lk * TILE + ((wn * 32 + 16 + lr) ^ sw);
+      double a[2][2], b[2][2];
+      a[0][0] = cA[ia0];
+      a[0][1] = cA[ia1];
+      b[0][0] = cB[ib0];
+      b[0][1] = cB[ib1];
+#pragma unroll
+      for (int ks = 0; ks < KT / 4; ++ks) {
+        const int cu = ks & 1, nx = cu ^ 1;
+        if (ks + 1 < KT / 4) {
+          a[nx][0] = cA[(ks + 1) * 4 * TM + ia0];
+          a[nx][1] = cA[(ks + 1) * 4 * TM + ia1];
+          b[nx][0] = cB[(ks + 1) * 4 * TILE + ib0];
+          b[nx][1] = cB[(ks + 1) * 4 * TILE + ib1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cu][mi], b[cu][ni], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    tile_barrier();
+    if (++c_t == c_nt) {
+      const int ncols = cur.half ? 64 : TILE;
+      const int wcol = cur.half ? wn * 16 : wn * 32;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        if (ni == 0 || !cur.half) {
+          double sq = 0.0;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sq = fma(acc[mi][ni][r], acc[mi][ni][r], sq);
+          sq += __shfl_xor(sq, 16);
+          sq += __shfl_xor(sq, 32);
+          if (lk == 0) red[wm][wcol + ni * 16 + lr] = sq;
+        }
+      }
+      __syncthreads();
+      if (tid < ncols)
+        out[(((int64_t)cur.col0 + tid) * k + cur.p) * nrb + cur.rb] = red[0][tid] + red[1][tid];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+      if (++c_item == nitems) return true;
+      cur = my[c_item];
+      c_nt = (int)(((int64_t)cur.rb * TM + TM + KT - 1) / KT);
+      c_t = 0;
+    }
+    return false;
+  };
+  for (;;) {
+    if (step(L0, L2)) break;
+    if (step(L1, L0)) break;
+    if (step(L2, L1)) break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Small-batch form (B <= 256 per launch: a rank's slice of the proposing half on a multi-GPU run).
 // With few columns the 64 x 128 items are too few and too long (the longest, full-K item alone takes
 // ~80 us), so here an item is 32 rows x 64 columns and its K range is split four ways INSIDE the
@@ -629,12 +824,33 @@ static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &
   nworkers = m->num_cu < (int)items.size() ? m->num_cu : (int)items.size();
   std::vector<std::vector<TrmmItem>> per(nworkers);
   std::vector<double> load(nworkers, 0.0);
-  for (const It &x : items) {  // longest processing time first onto the least loaded worker
-    int best = 0;
-    for (int w = 1; w < nworkers; ++w)
-      if (load[w] < load[best]) best = w;
-    per[best].push_back(x.it);
-    load[best] += x.cost;
+  // XCD-aware placement.  Workgroups are dispatched round-robin over the 8 XCDs (worker w runs on XCD w % 8),
+  // each with its own 4 MiB L2.  All items of one (PC, column block) group read the same K_*^T block and the
+  // groups of one PC read the same W_p; every group costs the same, so when the groups divide evenly they are
+  // dealt to the XCDs in (PC, column block) order -- an XCD then works on at most two or three PCs, and the
+  // column-block items of one (PC, row block), equally long, start together and stream the same W rows through
+  // that L2 -- and LPT runs within each XCD's workers.  Otherwise: plain LPT over all workers.
+  const int nxcd = 8, ngroups = k * ncb;
+  static const bool xcd_aware = getenv("GPEMU_TRMM_NO_XCD") == nullptr;
+  if (xcd_aware && nworkers == m->num_cu && nworkers % nxcd == 0 && ngroups % nxcd == 0) {
+    const int gper = ngroups / nxcd;
+    for (const It &x : items) {
+      const int g = x.it.p * ncb + x.it.col0 / TILE;
+      const int xcd = g / gper;
+      int best = xcd;
+      for (int w = xcd; w < nworkers; w += nxcd)
+        if (load[w] < load[best]) best = w;
+      per[best].push_back(x.it);
+      load[best] += x.cost;
+    }
+  } else {
+    for (const It &x : items) {  // longest processing time first onto the least loaded worker
+      int best = 0;
+      for (int w = 1; w < nworkers; ++w)
+        if (load[w] < load[best]) best = w;
+      per[best].push_back(x.it);
+      load[best] += x.cost;
+    }
   }
   max_items = 1;
   for (auto &v : per) max_items = v.size() > (size_t)max_items ? (int)v.size() : max_items;
@@ -693,9 +909,15 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
     m->sched_ncb = ncb; m->sched_max_items = max_items; m->sched_workers = nworkers;
   }
   const int pe0 = prof_mark(m, st);
-  hipLaunchKernelGGL(trmm_vsq_persistent_kernel, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
-                     w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
-                     m->Npad, w.Bcap, (int)m->k, nrb);
+  static const bool use_dma = getenv("GPEMU_TRMM_NO_DMA") == nullptr;   // register-staged variant kept for comparison
+  if (use_dma)
+    hipLaunchKernelGGL(trmm_vsq_dma_kernel, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
+                       w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
+                       m->Npad, w.Bcap, (int)m->k, nrb);
+  else
+    hipLaunchKernelGGL(trmm_vsq_persistent_kernel, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
+                       w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
+                       m->Npad, w.Bcap, (int)m->k, nrb);
   GP_HIP(hipGetLastError());
   prof_pair(m, 0, pe0, prof_mark(m, st));
 #ifdef GPEMU_TRMM_STAMPS
