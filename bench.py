@@ -92,14 +92,14 @@ def measure_predict(dm, n_samples=1024, reps=5):
 
 def committed_traffic(world):
     """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied).
+    (profiles/r01_e_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied).
     The counters cannot be collected from inside this process; null when the file or shape differs."""
     if world != 1:
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            k = json.load(f)["kernels"]["gpemu::trmm_vsq_persistent_kernel"]
-        return {"bytes_per_launch": k["bytes_per_launch_corrected"], "source": "profiles/r01_traffic.json"}
+        with open(os.path.join(ROOT, "profiles", "r01_e_traffic.json")) as f:
+            k = json.load(f)["kernels"]["gpemu::trmm_vsq_dma_kernel"]
+        return {"bytes_per_launch": k["bytes_per_launch_corrected"], "source": "profiles/r01_e_traffic.json"}
     except Exception:
         return None
 
