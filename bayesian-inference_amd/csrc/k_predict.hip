@@ -8,7 +8,11 @@
 // the epilogue -- V is never written to memory.
 //
 //   kstar_kernel      K_*^T[p][j][b] (HBM/L2 workspace) + partial means   (VALU f64, HBM-write)
-//   trmm_vsq_kernel   sum_i (W_p K_*^T)[i][b]^2 per 64-row block           (MFMA f64)
+//   trmm_vsq_*        sum_i (W_p K_*^T)[i][b]^2 per 64-row block           (MFMA f64)
+//       _dma_kernel         B > 256: persistent, LDS-direct loads, XCD-aware LPT schedule (the default)
+//       _persistent_kernel  same schedule, register-staged loads (GPEMU_TRMM_NO_DMA=1)
+//       _kernel             one item per workgroup (GPEMU_TRMM_SIMPLE=1)
+//       _smallb_kernel      B <= 256: 32 x 64 items, K split inside the workgroup
 //   reduce_kernel     sums the partials, var = kdiag - vsq, clip, std^2
 #include <algorithm>
 
