@@ -219,6 +219,7 @@ int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int6
 #define GP_STEP(expr) if ((rc = (expr)) != GPEMU_OK) return fail(rc)
   GP_STEP(dev_alloc(&m->Xs, k * Np * DPAD));
   GP_STEP(dev_alloc(&m->ls, k * DPAD));
+  GP_STEP(dev_alloc(&m->inv_ls, k * DPAD));
   GP_STEP(dev_alloc(&m->constv, k));
   GP_STEP(dev_alloc(&m->kdiag, k));
   GP_STEP(dev_alloc(&m->alpha, k * Np));
@@ -230,6 +231,12 @@ int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int6
   GP_STEP(dev_alloc(&dL, k * N * N));
   GP_STEP(upload(m->Xs, hXs.data(), k * Np * DPAD, st));
   GP_STEP(upload(m->ls, hls.data(), k * DPAD, st));
+  {
+    std::vector<double> hinv(hls.size());
+    for (size_t i = 0; i < hls.size(); ++i) hinv[i] = 1.0 / hls[i];
+    GP_STEP(upload(m->inv_ls, hinv.data(), k * DPAD, st));
+    GP_HIP(hipStreamSynchronize(st));   // hinv goes out of scope
+  }
   GP_STEP(upload(m->constv, hc.data(), k, st));
   GP_STEP(upload(m->kdiag, hkd.data(), k, st));
   GP_STEP(upload(m->alpha, hal.data(), k * Np, st));

@@ -71,7 +71,7 @@ struct gpemu_model {
 
   // per-PC GP state on the device
   double *Xs = nullptr;        // [k][Npad][DPAD]  X_train / ls_p  (padded rows/dims = 0)
-  double *inv_ls = nullptr;    // [k][DPAD]        (unused dims 0) -- kept as ls for exact division
+  double *inv_ls = nullptr;    // [k][DPAD]        1 / ls (the query side multiplies; the training side X / ls is exact)
   double *ls = nullptr;        // [k][DPAD]        length scales (padded dims = 1)
   double *constv = nullptr;    // [k]
   double *kdiag = nullptr;     // [k]  kernel_.diag = 1 (+const) (+noise)
