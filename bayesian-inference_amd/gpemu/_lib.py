@@ -135,6 +135,21 @@ def device_count() -> int:
     return int(lib().gpemu_device_count())
 
 
+def default_device():
+    """Device of this process: one process per GPU under torch.distributed.run (LOCAL_RANK), else device 0.
+    GPEMU_DEVICE overrides.  Taken modulo the number of visible devices."""
+    n = require_device()
+    idx = os.environ.get("GPEMU_DEVICE", os.environ.get("LOCAL_RANK", "0"))
+    try:
+        return int(idx) % n
+    except ValueError:
+        return 0
+
+
+def resolve_device(device):
+    return default_device() if device is None else int(device)
+
+
 def require_device():
     n = device_count()
     if n <= 0:

@@ -54,7 +54,7 @@ class PCA:
         return np.asarray(X, dtype=np.float64) @ self.components_ + self.mean_
 
 
-def scale_and_pca(Y, n_components=None, device=0):
+def scale_and_pca(Y, n_components=None, device=None):
     """``pca.fit_transform(scaler.fit_transform(Y))`` on the device (ref: emulation.py:109-117).
     Returns (scaler, pca, Y_pca (N, n_components))."""
     out = _fit.pca_fit(Y, n_components=n_components, device=device)
@@ -166,7 +166,7 @@ class GaussianProcessRegressor:
     """
 
     def __init__(self, kernel, alpha=1e-10, n_restarts_optimizer=0, copy_X_train=True, optimizer="fmin_l_bfgs_b",
-                 device=0):
+                 device=None):
         self.kernel = kernel
         self.alpha = alpha
         self.n_restarts_optimizer = n_restarts_optimizer
@@ -275,7 +275,7 @@ class GaussianProcessRegressor:
         return mean[:, 0]
 
 
-def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy_X_train=False, device=0,
+def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy_X_train=False, device=None,
             n_streams=None):
     """One GaussianProcessRegressor per column of ``Y_columns`` (N x k), fitted concurrently.
 

@@ -20,8 +20,9 @@ class DeviceFit:
     theta follows sklearn: log([l_1..l_d, (constant_value), (noise_level)]) (skl kernels.py:733-760).
     """
 
-    def __init__(self, X, kernel_kind=0, nu=np.inf, has_const=False, has_noise=False, jitter=1e-10, device=0):
+    def __init__(self, X, kernel_kind=0, nu=np.inf, has_const=False, has_noise=False, jitter=1e-10, device=None):
         _lib.require_device()
+        device = _lib.resolve_device(device)
         X = as_f64(X)
         self.N, self.d = X.shape
         self.n_theta = self.d + int(has_const) + int(has_noise)
@@ -67,7 +68,8 @@ class DeviceFit:
         return L, alpha, val.value
 
 
-def kernel_matrix(X, theta, kernel_kind=0, nu=np.inf, has_const=False, has_noise=False, jitter=0.0, device=0):
+def kernel_matrix(X, theta, kernel_kind=0, nu=np.inf, has_const=False, has_noise=False, jitter=0.0, device=None):
+    device = _lib.resolve_device(device)
     X = as_f64(X)
     N, d = X.shape
     theta = as_f64(theta)
@@ -78,8 +80,9 @@ def kernel_matrix(X, theta, kernel_kind=0, nu=np.inf, has_const=False, has_noise
     return K
 
 
-def cholesky(A, device=0):
+def cholesky(A, device=None):
     """Lower Cholesky factor on the device (scipy.linalg.cholesky(A, lower=True))."""
+    device = _lib.resolve_device(device)
     A = np.array(A, dtype=np.float64, order="C")
     rc = _lib.lib().gpemu_cholesky(int(device), A.shape[0], ptr(A))
     if rc > 0:
@@ -88,10 +91,11 @@ def cholesky(A, device=0):
     return A
 
 
-def pca_fit(Y, n_components=None, device=0):
+def pca_fit(Y, n_components=None, device=None):
     """StandardScaler + full PCA on the device.  Returns a dict with scaler_mean/scale/var, pca_mean,
     components (nc,F), explained_variance(_ratio) (nc,), Y_pca (N,nc), flip_argmax (nc,), n_sweeps."""
     _lib.require_device()
+    device = _lib.resolve_device(device)
     Y = as_f64(Y)
     N, F = Y.shape
     nc = min(N, F) if n_components is None else int(n_components)

@@ -22,8 +22,9 @@ class DeviceModel:
     """
 
     def __init__(self, X_train, ls, alpha, L, components, scaler_mean, scaler_scale,
-                 kernel_kind=RBF, nu=np.inf, const=None, noise=None, cov_unexplained=None, device=0):
+                 kernel_kind=RBF, nu=np.inf, const=None, noise=None, cov_unexplained=None, device=None):
         _lib.require_device()
+        device = _lib.resolve_device(device)
         X_train = as_f64(X_train)
         N, d = X_train.shape
         ls = as_f64(ls)

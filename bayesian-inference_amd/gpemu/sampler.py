@@ -203,14 +203,26 @@ class DeviceSampler:
         comm, err = None, None
         try:
             comm = self._rccl_comm(group)
-        except Exception as e:      # missing librccl symbol, ncclCommInitRank failure, ...
+            # one all-gather of the rank indices through the new communicator before the chain depends on it
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            dev = torch.device("cuda", self.device)
+            src = torch.full((1,), float(rank), dtype=torch.float64, device=dev)
+            dst = torch.full((world,), -1.0, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize(dev)
+            check(_lib.lib().gpemu_comm_all_gather(comm, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), 1, None))
+            torch.cuda.synchronize(dev)
+            if dst.cpu().tolist() != [float(r) for r in range(world)]:
+                raise RuntimeError(f"RCCL all-gather self-check returned {dst.cpu().tolist()}")
+        except Exception as e:      # missing librccl symbol, ncclCommInitRank failure, wrong data ...
             err = e
+            comm = None
         ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=torch.device("cuda", self.device))
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         if int(ok.item()) == 1:
             return comm
-        if comm is not None:
-            _lib.lib().gpemu_comm_destroy(self._comms.pop(key))
+        stale = self.__dict__.get("_comms", {}).pop(key, None)
+        if stale is not None:
+            _lib.lib().gpemu_comm_destroy(stale)
         warnings.warn(f"library-owned RCCL communicator unavailable ({err!r}); using torch.distributed's all-gather")
         self.__dict__.setdefault("_comms", {})[key] = None
         return None
