@@ -42,12 +42,31 @@ def _data_IO():
 
 
 ####################################################################################################
+def _rank_world():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:
+        pass
+    return 0, 1
+
+
 def fit_emulators(emulation_config: "EmulationConfig") -> None:
-    """PCA + GP fit for every emulation group; writes one pickle per group (ref: emulation.py:38-50)."""
-    for name, group_config in emulation_config.emulation_groups_config.items():
+    """PCA + GP fit for every emulation group; writes one pickle per group (ref: emulation.py:38-50).
+
+    One process per GPU (torch.distributed initialised): the groups are independent, group i is fitted and
+    written by rank i % world on its own GPU; all ranks leave together so that the next stage finds every file."""
+    rank, world = _rank_world()
+    for i, (name, group_config) in enumerate(emulation_config.emulation_groups_config.items()):
+        if i % world != rank:
+            continue
         result = fit_emulator_group(group_config)
         if result:   # an existing emulator is not overwritten (ref: emulation.py:46-48)
             write_emulators(config=group_config, output_dict=result)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
 
 
 def build_kernel(config) -> estimators.ARDKernel:
