@@ -106,14 +106,29 @@ __global__ __launch_bounds__(256) void kstar_kernel(
     const double *__restrict__ constv, const double *__restrict__ alpha, double *__restrict__ KS,
     double *__restrict__ mean_part, int64_t N, int64_t Npad, int64_t Bcap, int has_const, ProposeArgs pa) {
   __shared__ double s_tab[32];
-  if (threadIdx.x < 32) s_tab[threadIdx.x] = c_exp2_32[threadIdx.x];
-  __syncthreads();
+  __shared__ __attribute__((aligned(16))) double s_xs[4 * RPW * DPAD];   // this workgroup's training rows (scaled)
+  __shared__ double s_al[4 * RPW];                                       // and their alpha
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = blockIdx.z;
   const int chunk = blockIdx.y;
   const int nchunk = gridDim.y;
   const int64_t b = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t jb0 = (int64_t)chunk * (4 * RPW);
+
+  // issue the loads of the workgroup's rows first (contiguous in memory): their latency overlaps with the
+  // dependent index -> position chain of the proposal below
+  constexpr int NPAIR = 4 * RPW * DPAD / 2;            // 16-byte pairs to stage
+  constexpr int PER_T = (NPAIR + 255) / 256;
+  d2 stage[PER_T];
+  const d2 *xsrc = reinterpret_cast<const d2 *>(Xs + ((int64_t)p * Npad + jb0) * DPAD);
+#pragma unroll
+  for (int t = 0; t < PER_T; ++t) {
+    const int idx = threadIdx.x + 256 * t;
+    stage[t] = (idx < NPAIR) ? xsrc[idx] : d2{0.0, 0.0};
+  }
+  double al_stage = 0.0;
+  if (threadIdx.x < 4 * RPW) al_stage = alpha[(int64_t)p * Npad + jb0 + threadIdx.x];
 
   double xq[DPAD];
   if (pa.enabled) {
@@ -144,9 +159,18 @@ __global__ __launch_bounds__(256) void kstar_kernel(
   }
   const double c = has_const ? constv[p] : 0.0;
 
-  const int64_t jbase = (int64_t)chunk * (4 * RPW) + wave * RPW;
-  const double *xs = Xs + ((int64_t)p * Npad + jbase) * DPAD;
-  const double *al = alpha + (int64_t)p * Npad + jbase;
+  if (threadIdx.x < 32) s_tab[threadIdx.x] = c_exp2_32[threadIdx.x];
+#pragma unroll
+  for (int t = 0; t < PER_T; ++t) {
+    const int idx = threadIdx.x + 256 * t;
+    if (idx < NPAIR) reinterpret_cast<d2 *>(s_xs)[idx] = stage[t];
+  }
+  if (threadIdx.x < 4 * RPW) s_al[threadIdx.x] = al_stage;
+  __syncthreads();
+
+  const int64_t jbase = jb0 + wave * RPW;
+  const double *xs = s_xs + wave * RPW * DPAD;       // wave-uniform LDS addresses: broadcast reads
+  const double *al = s_al + wave * RPW;
   double *ks = KS + ((int64_t)p * Npad + jbase) * Bcap + b;
   double macc = 0.0;
 #pragma unroll 4
@@ -154,7 +178,7 @@ __global__ __launch_bounds__(256) void kstar_kernel(
     double r2 = 0.0;
 #pragma unroll
     for (int dd = 0; dd < DPAD; ++dd) {
-      double df = xq[dd] - xs[jj * DPAD + dd];  // wave-uniform address -> scalar loads
+      double df = xq[dd] - xs[jj * DPAD + dd];
       r2 = fma(df, df, r2);
     }
     double v = base_kernel_fast<KIND>(r2, s_tab) + c;
