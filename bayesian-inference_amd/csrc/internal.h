@@ -141,8 +141,6 @@ struct ProposeArgs {
 int ensure_workspace(gpemu_model *m, int64_t B);
 
 // kernels (launchers; all asynchronous on `st`)
-int launch_trtri_lower_to_Wt(const double *dL, double *dWt, int64_t k, int64_t N, int64_t Npad,
-                             hipStream_t st);
 // dXq_padded is read, or -- with pa->enabled -- written (rows [0, round_up(B, 128))) by the kernel
 int launch_kstar(gpemu_model *m, int64_t B, double *dXq_padded, hipStream_t st, const ProposeArgs *pa = nullptr);
 int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st);

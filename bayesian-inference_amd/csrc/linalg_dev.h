@@ -171,6 +171,5 @@ __device__ inline double wg_sum(double v) {
   return total;
 }
 
-int launch_cholesky(double *dA, int n, int ld, double *dscratch, int *dinfo, hipStream_t st);
 
 }  // namespace gpemu
