@@ -76,6 +76,88 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
+// One 16-column panel of the 64 x 64 block (columns J0 .. J0+15): wave 0 factors the diagonal 16 x 16 block and
+// solves the rows below it with the rows held in registers (lane = row), then all threads apply the rank-16
+// update to the trailing lower triangle.
+template <int J0>
+__device__ __forceinline__ void panel_step(double (*D)[NB + 1], int tid, int blk, int *info) {
+  constexpr int PB = 16;
+  const int lane = tid & 63, wave = tid >> 6;
+  if (wave == 0) {
+    const int r = J0 + lane;
+    const bool act = r < NB;
+    double row[PB];
+#pragma unroll
+    for (int c = 0; c < PB; ++c) row[c] = act ? D[act ? r : 0][J0 + c] : 0.0;
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const double piv2 = readlane_f64(row[j], j);
+      if (!(piv2 > 0.0) && bad == 0) bad = J0 + j + 1;
+      const double rinv = 1.0 / sqrt(piv2);
+      const double lj = row[j] * rinv;      // lanes >= j: column J0+j of L; lanes < j hold zeros
+      row[j] = lj;
+#pragma unroll
+      for (int c = j + 1; c < PB; ++c) row[c] = fma(-lj, readlane_f64(lj, c), row[c]);
+    }
+    if (bad && lane == 0 && info && *info == 0) *info = blk * NB + bad;
+    if (act) {
+#pragma unroll
+      for (int c = 0; c < PB; ++c)
+        if (lane >= PB || c <= lane) D[r][J0 + c] = row[c];   // nothing above the diagonal
+    }
+  }
+  __syncthreads();
+  constexpr int T0 = J0 + PB, M = NB - T0;       // trailing block [T0, 64)^2, lower triangle
+  if (M > 0) {
+    for (int idx = tid; idx < M * M; idx += 256) {
+      const int i = idx / (M > 0 ? M : 1), c = idx % (M > 0 ? M : 1);
+      if (c <= i) {
+        double acc0 = D[T0 + i][T0 + c], acc1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < PB; t += 2) {
+          acc0 = fma(-D[T0 + i][J0 + t], D[T0 + c][J0 + t], acc0);
+          acc1 = fma(-D[T0 + i][J0 + t + 1], D[T0 + c][J0 + t + 1], acc1);
+        }
+        D[T0 + i][T0 + c] = acc0 + acc1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// X21 = -X22 (L21 X11) for every pair of adjacent B x B diagonal blocks of the 64 x 64 factor D / inverse X
+template <int B>
+__device__ __forceinline__ void merge_level(double (*D)[NB + 1], double (*X)[NB + 1], double (*T)[32 + 1], int tid) {
+  constexpr int NPAIR = NB / (2 * B);
+  // T = L21 . X11
+  for (int idx = tid; idx < NPAIR * B * B; idx += 256) {
+    const int pr = idx / (B * B), i = (idx / B) % B, c = idx % B;
+    const int p0 = pr * 2 * B;
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < B; kk += 2) {
+      acc0 = fma(D[p0 + B + i][p0 + kk], X[p0 + kk][p0 + c], acc0);
+      acc1 = fma(D[p0 + B + i][p0 + kk + 1], X[p0 + kk + 1][p0 + c], acc1);
+    }
+    T[(pr * B + i) & 31][c] = acc0 + acc1;
+  }
+  __syncthreads();
+  // X21 = -X22 . T
+  for (int idx = tid; idx < NPAIR * B * B; idx += 256) {
+    const int pr = idx / (B * B), i = (idx / B) % B, c = idx % B;
+    const int p0 = pr * 2 * B;
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < B; kk += 2) {
+      acc0 = fma(X[p0 + B + i][p0 + B + kk], T[(pr * B + kk) & 31][c], acc0);
+      acc1 = fma(X[p0 + B + i][p0 + B + kk + 1], T[(pr * B + kk + 1) & 31][c], acc1);
+    }
+    X[p0 + B + i][p0 + c] = -(acc0 + acc1);
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda, double *Dinv, int do_factor,
                                                          int block_index, int *info) {
   constexpr int PB = 16;
@@ -92,44 +174,11 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda,
   }
   __syncthreads();
   if (do_factor) {
-    for (int j0 = 0; j0 < NB; j0 += PB) {
-      if (wave == 0) {
-        const int r = j0 + lane;
-        const bool act = r < NB;
-        double row[PB];
-#pragma unroll
-        for (int c = 0; c < PB; ++c) row[c] = act ? D[act ? r : 0][j0 + c] : 0.0;
-        int bad = 0;
-#pragma unroll
-        for (int j = 0; j < PB; ++j) {
-          const double piv2 = readlane_f64(row[j], j);
-          if (!(piv2 > 0.0) && bad == 0) bad = j0 + j + 1;
-          const double rinv = 1.0 / sqrt(piv2);
-          const double lj = row[j] * rinv;      // lanes >= j: column j0+j of L; lanes < j hold zeros
-          row[j] = lj;
-#pragma unroll
-          for (int c = j + 1; c < PB; ++c) row[c] = fma(-lj, readlane_f64(lj, c), row[c]);
-        }
-        if (bad && lane == 0 && info && *info == 0) *info = (block_index + (int)blockIdx.x) * NB + bad;
-        if (act) {
-#pragma unroll
-          for (int c = 0; c < PB; ++c)
-            if (lane >= PB || c <= lane) D[r][j0 + c] = row[c];   // nothing above the diagonal
-        }
-      }
-      __syncthreads();
-      const int t0 = j0 + PB, m = NB - t0;       // trailing block [t0, 64)^2, lower triangle
-      for (int idx = tid; idx < m * m; idx += 256) {
-        const int i = idx / m, c = idx - i * m;
-        if (c <= i) {
-          double acc = D[t0 + i][t0 + c];
-#pragma unroll
-          for (int t = 0; t < PB; ++t) acc = fma(-D[t0 + i][j0 + t], D[t0 + c][j0 + t], acc);
-          D[t0 + i][t0 + c] = acc;
-        }
-      }
-      __syncthreads();
-    }
+    const int blk = block_index + (int)blockIdx.x;
+    panel_step<0>(D, tid, blk, info);
+    panel_step<16>(D, tid, blk, info);
+    panel_step<32>(D, tid, blk, info);
+    panel_step<48>(D, tid, blk, info);
     for (int idx = tid; idx < NB * NB; idx += 256) {
       const int r = idx >> 6, c = idx & 63;
       Ab[(int64_t)r * lda + c] = D[r][c];    // zeros above the diagonal
@@ -150,28 +199,11 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda,
     for (int ii = 0; ii < PB; ++ii) X[b0 + ii][b0 + c] = x[ii];
   }
   __syncthreads();
-  // merge pairs of inverted diagonal blocks of size b into blocks of size 2b
-  for (int b = PB; b < NB; b *= 2) {
-    const int npair = NB / (2 * b);
-    // T = L21 . X11 for every pair (X11 lower triangular: k >= column)
-    for (int idx = tid; idx < npair * b * b; idx += 256) {
-      const int pr = idx / (b * b), rem = idx - pr * b * b, i = rem / b, c = rem - i * b;
-      const int p0 = pr * 2 * b;
-      double acc = 0.0;
-      for (int kk = c; kk < b; ++kk) acc = fma(D[p0 + b + i][p0 + kk], X[p0 + kk][p0 + c], acc);
-      T[(pr * b + i) & 31][c] = acc;
-    }
-    __syncthreads();
-    // X21 = -X22 . T  (X22 lower triangular: k <= row)
-    for (int idx = tid; idx < npair * b * b; idx += 256) {
-      const int pr = idx / (b * b), rem = idx - pr * b * b, i = rem / b, c = rem - i * b;
-      const int p0 = pr * 2 * b;
-      double acc = 0.0;
-      for (int kk = 0; kk <= i; ++kk) acc = fma(X[p0 + b + i][p0 + b + kk], T[(pr * b + kk) & 31][c], acc);
-      X[p0 + b + i][p0 + c] = -acc;
-    }
-    __syncthreads();
-  }
+  // merge pairs of inverted diagonal blocks of size b into blocks of size 2b (b = 16, then 32); the loops run
+  // over the full b (X holds zeros above the diagonal, so the triangular structure needs no bounds) and are
+  // unrolled, which lets the LDS reads of one output pipeline instead of waiting on a data-dependent trip count
+  merge_level<16>(D, X, T, tid);
+  merge_level<32>(D, X, T, tid);
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
     Db[idx] = X[r][c];
