@@ -210,25 +210,18 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda,
   }
 }
 
-__global__ void copy_block_kernel(const double *__restrict__ src, int64_t lds, double *__restrict__ dst,
-                                  int64_t ldd, int rows, int cols, double scale) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  const int r = blockIdx.y;
-  if (c < cols && r < rows) dst[(int64_t)r * ldd + c] = scale * src[(int64_t)r * lds + c];
-}
-
-static int copy_block(const double *src, int64_t lds, double *dst, int64_t ldd, int rows, int cols,
-                      double scale, hipStream_t st) {
-  if (rows <= 0 || cols <= 0) return GPEMU_OK;
-  hipLaunchKernelGGL(copy_block_kernel, dim3((unsigned)((cols + 255) / 256), (unsigned)rows), dim3(256), 0, st,
-                     src, lds, dst, ldd, rows, cols, scale);
-  GP_HIP(hipGetLastError());
-  return GPEMU_OK;
+// W[ib*64 + r][ib*64 + c] = Dinv[ib][r][c] for every 64 x 64 diagonal block ib = blockIdx.x
+__global__ __launch_bounds__(256) void scatter_diag_blocks_kernel(const double *__restrict__ Dinv, double *__restrict__ W,
+                                                                  int64_t Np) {
+  const int64_t ib = blockIdx.x;
+  const double *src = Dinv + ib * NB * NB;
+  double *dst = W + (ib * NB) * Np + ib * NB;
+  for (int idx = threadIdx.x; idx < NB * NB; idx += 256) dst[(int64_t)(idx >> 6) * Np + (idx & 63)] = src[idx];
 }
 
 // In-place lower Cholesky of the Np x Np matrix A (Np multiple of 64); Dinv receives the inverted
-// diagonal blocks [Np/64][64][64]; Pbuf is an [Np][64] panel buffer.
-int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, double *Pbuf, int *dinfo, hipStream_t st) {
+// diagonal blocks [Np/64][64][64].
+int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hipStream_t st) {
   const int nblk = (int)(Np / NB);
   for (int jb = 0; jb < nblk; ++jb) {
     const int64_t j0 = (int64_t)jb * NB;
@@ -237,17 +230,16 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, double *Pbuf, i
     GP_HIP(hipGetLastError());
     const int M = (int)(Np - j0 - NB);
     if (M <= 0) break;
-    GemmArgs g;   // panel = A21 . inv(L11)^T
-    g.A = A + (j0 + NB) * Np + j0; g.lda = Np;
+    double *A21 = A + (j0 + NB) * Np + j0;
+    GemmArgs g;   // panel = A21 . inv(L11)^T, in place: a workgroup owns whole 64-wide rows of the panel and has
+    g.A = A21; g.lda = Np;   // read them completely (K = 64) before it stores
     g.B = Dinv + (int64_t)jb * NB * NB; g.ldb = NB;
-    g.C = Pbuf; g.ldc = NB;
+    g.C = A21; g.ldc = Np;
     g.M = M; g.N = NB; g.K = NB;
     int rc = launch_gemm(g, false, false, 1, st);
     if (rc != GPEMU_OK) return rc;
-    rc = copy_block(Pbuf, NB, A + (j0 + NB) * Np + j0, Np, M, NB, 1.0, st);
-    if (rc != GPEMU_OK) return rc;
     GemmArgs s;   // A22 -= panel . panel^T (lower tiles)
-    s.A = Pbuf; s.lda = NB; s.B = Pbuf; s.ldb = NB;
+    s.A = A21; s.lda = Np; s.B = A21; s.ldb = Np;
     s.C = A + (j0 + NB) * Np + (j0 + NB); s.ldc = Np;
     s.M = M; s.N = M; s.K = NB; s.alpha = -1.0; s.beta = 1.0; s.lower_only = 1;
     rc = launch_gemm(s, false, false, 1, st);
@@ -264,11 +256,9 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, double *Pbuf, i
 int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double *W, double *T, hipStream_t st) {
   const int nblk = (int)(Np / NB);
   GP_HIP(hipMemsetAsync(W, 0, sizeof(double) * (size_t)(Np * Np), st));
-  // diagonal blocks: Dinv [nblk][64][64] -> W
-  for (int ib = 0; ib < nblk; ++ib) {
-    int rc = copy_block(Dinv + (int64_t)ib * NB * NB, NB, W + ((int64_t)ib * NB) * Np + (int64_t)ib * NB, Np, NB, NB, 1.0, st);
-    if (rc != GPEMU_OK) return rc;
-  }
+  // diagonal blocks: Dinv [nblk][64][64] -> W, one launch
+  hipLaunchKernelGGL(scatter_diag_blocks_kernel, dim3((unsigned)nblk), dim3(256), 0, st, Dinv, W, Np);
+  GP_HIP(hipGetLastError());
   for (int64_t b = NB; b < Np; b *= 2) {
     // pairs start at p0 = 2 b t; first block [p0, p0 + b), second [p0 + b, min(p0 + 2b, Np))
     const int64_t nfull = Np / (2 * b);                      // pairs whose second block is complete
@@ -499,7 +489,7 @@ struct gpemu_fit {
   int kind = 0, has_const = 0, has_noise = 0;
   double jitter = 0.0;
   hipStream_t stream = nullptr;
-  double *X = nullptr, *hp = nullptr, *K = nullptr, *Pbuf = nullptr, *Dinv = nullptr, *W = nullptr,
+  double *X = nullptr, *hp = nullptr, *K = nullptr, *Dinv = nullptr, *W = nullptr,
          *T = nullptr, *Kinv = nullptr, *y = nullptr, *v = nullptr, *alpha = nullptr, *gpart = nullptr,
          *scal = nullptr, *grad = nullptr;
   int *info = nullptr;
@@ -537,7 +527,7 @@ static int fit_eval(gpemu_fit *f, const double *y, const double *theta, int64_t 
   hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)Np), dim3(256), 0, st, f->X, f->hp,
                      f->K, (int)N, (int)Np, f->kind, f->jitter);
   GP_HIP(hipGetLastError());
-  GP_TRY(device_cholesky_blocked(f->K, Np, f->Dinv, f->Pbuf, f->info, st));
+  GP_TRY(device_cholesky_blocked(f->K, Np, f->Dinv, f->info, st));
   GP_TRY(device_trtri_blocked(f->K, Np, f->Dinv, f->W, f->T, st));
   // alpha = W^T (W y)
   hipLaunchKernelGGL(gemv_kernel, dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, st, f->W, Np, f->y, f->v, (int)Np, 0);
@@ -603,7 +593,7 @@ int gpemu_fit_create(gpemu_fit **out, int device, int64_t N, int64_t d, const do
   f->n_gparts = (int)(((N + 255) / 256) * N);
   hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
   auto A = [&](double **p, int64_t n) { if (e == hipSuccess) e = hipMalloc((void **)p, sizeof(double) * (size_t)(n > 0 ? n : 1)); };
-  A(&f->X, Np * DPAD); A(&f->hp, DPAD + 2); A(&f->K, Np * Np); A(&f->Pbuf, Np * NB); A(&f->Dinv, Np * NB);
+  A(&f->X, Np * DPAD); A(&f->hp, DPAD + 2); A(&f->K, Np * Np); A(&f->Dinv, Np * NB);
   A(&f->W, Np * Np); A(&f->T, Np * Np); A(&f->Kinv, Np * Np); A(&f->y, Np); A(&f->v, Np); A(&f->alpha, Np);
   A(&f->gpart, (int64_t)f->n_gparts * NTH_MAX); A(&f->scal, 4); A(&f->grad, NTH_MAX);
   if (e == hipSuccess) e = hipMalloc((void **)&f->info, sizeof(int));
@@ -624,7 +614,7 @@ int gpemu_fit_destroy(gpemu_fit *f) {
   if (!f) return GPEMU_OK;
   (void)hipSetDevice(f->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
-  double *ptrs[] = {f->X, f->hp, f->K, f->Pbuf, f->Dinv, f->W, f->T, f->Kinv, f->y, f->v, f->alpha, f->gpart, f->scal, f->grad};
+  double *ptrs[] = {f->X, f->hp, f->K, f->Dinv, f->W, f->T, f->Kinv, f->y, f->v, f->alpha, f->gpart, f->scal, f->grad};
   for (double *p : ptrs) (void)hipFree(p);
   (void)hipFree(f->info);
   if (f->stream) (void)hipStreamDestroy(f->stream);
@@ -690,11 +680,10 @@ int gpemu_cholesky(int device, int64_t N, double *A_inout) {
   GP_ARG(device >= 0 && device < ndev, "device");
   GP_HIP(hipSetDevice(device));
   const int64_t Np = round_up(N, NB);
-  double *A = nullptr, *Dinv = nullptr, *P = nullptr;
+  double *A = nullptr, *Dinv = nullptr;
   int *dinfo = nullptr;
   hipError_t e = hipMalloc((void **)&A, sizeof(double) * Np * Np);
   if (e == hipSuccess) e = hipMalloc((void **)&Dinv, sizeof(double) * Np * NB);
-  if (e == hipSuccess) e = hipMalloc((void **)&P, sizeof(double) * Np * NB);
   if (e == hipSuccess) e = hipMalloc((void **)&dinfo, sizeof(int));
   std::vector<double> h((size_t)(Np * Np), 0.0);
   for (int64_t i = 0; i < Np; ++i)
@@ -702,11 +691,11 @@ int gpemu_cholesky(int device, int64_t N, double *A_inout) {
   int rc = GPEMU_OK, info = 0;
   if (e == hipSuccess) e = hipMemcpy(A, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(dinfo, 0, sizeof(int));
-  if (e == hipSuccess) rc = device_cholesky_blocked(A, Np, Dinv, P, dinfo, nullptr);
+  if (e == hipSuccess) rc = device_cholesky_blocked(A, Np, Dinv, dinfo, nullptr);
   if (e == hipSuccess && rc == GPEMU_OK) e = hipDeviceSynchronize();
   if (e == hipSuccess && rc == GPEMU_OK) e = hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost);
   if (e == hipSuccess && rc == GPEMU_OK) e = hipMemcpy(h.data(), A, sizeof(double) * h.size(), hipMemcpyDeviceToHost);
-  (void)hipFree(A); (void)hipFree(Dinv); (void)hipFree(P); (void)hipFree(dinfo);
+  (void)hipFree(A); (void)hipFree(Dinv); (void)hipFree(dinfo);
   if (e != hipSuccess) { set_error("cholesky: %s", hipGetErrorString(e)); return GPEMU_ERR_HIP; }
   if (rc != GPEMU_OK) return rc;
   if (info != 0) { set_error("matrix is not positive definite (pivot %d)", info); return info; }
