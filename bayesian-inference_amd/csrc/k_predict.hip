@@ -12,7 +12,7 @@
 //       _dma_kernel         B > 256: persistent, LDS-direct loads, XCD-aware LPT schedule (the default)
 //       _persistent_kernel  same schedule, register-staged loads (GPEMU_TRMM_NO_DMA=1)
 //       _kernel             one item per workgroup (GPEMU_TRMM_SIMPLE=1)
-//       _smallb_kernel      B <= 256: 32 x 64 items, K split inside the workgroup
+//       _smallb_kernel      B <= 128: 32 x 64 items, K split inside the workgroup
 //   reduce_kernel     sums the partials, var = kdiag - vsq, clip, std^2
 #include <algorithm>
 
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Small-batch form (B <= 256 per launch: a rank's slice of the proposing half on a multi-GPU run).
+// Small-batch form (B <= 128 per launch: a rank's slice of the proposing half on a multi-GPU run).
 // With few columns the 64 x 128 items are too few and too long (the longest, full-K item alone takes
 // ~80 us), so here an item is 32 rows x 64 columns and its K range is split four ways INSIDE the
 // workgroup: 8 waves = 4 K-slices x 2 column halves, each wave 32 x 32.  Slice s takes the k-tiles
@@ -887,7 +887,10 @@ static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &
   const int nrb = (int)m->vsq_nrb, k = (int)m->k;
   struct It { double cost; TrmmItem it; };
   std::vector<It> items;
-  const int split_below = nrb / 4;   // row blocks with short K are issued as two 64-column halves
+  // row blocks with short K are issued as two 64-column halves; with one or two column blocks (B <= 256) there
+  // are too few items for 256 workers unless every row block is
+  static const int split_all_ncb = getenv("GPEMU_TRMM_SPLIT_ALL_NCB") ? atoi(getenv("GPEMU_TRMM_SPLIT_ALL_NCB")) : 2;
+  const int split_below = (ncb <= split_all_ncb) ? nrb : nrb / 4;
   const double ov = 0.15;            // per-item cost of the epilogue, in k-tiles
   for (int rb = 0; rb < nrb; ++rb) {
     const double nt = (double)(((int64_t)rb * TM + TM + KT - 1) / KT);
@@ -945,8 +948,9 @@ static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &
 
 int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
   Workspace &w = m->ws;
-  static const int smallb_max = getenv("GPEMU_SMALLB_MAX") ? atoi(getenv("GPEMU_SMALLB_MAX")) : 256;
-  if (B <= smallb_max) {   // small batch: 32 x 64 items with the K range split inside the workgroup
+  static const int smallb_max = getenv("GPEMU_SMALLB_MAX") ? atoi(getenv("GPEMU_SMALLB_MAX")) : 128;
+  if (B <= smallb_max) {   // small batch: 32 x 64 items with the K range split inside the workgroup (at 129..256
+                           // rows the persistent kernel with every item halved is faster: 69 us vs 81 us)
     const int nrb32 = (int)(m->Npad / SB_TM);
     const int ncb64 = (int)(round_up(B, SB_TN) / SB_TN);
     w.cur_nrb = nrb32;

@@ -242,7 +242,7 @@ def main():
         flop_per_launch = N_PC * N_DESIGN ** 2 * evals_per_launch
         avg_s = ms_tot / n_launch * 1e-3
         achieved = flop_per_launch / avg_s / 1e12
-        kern = "trmm_vsq_dma_kernel" if evals_per_launch > 256 else "trmm_vsq_smallb_kernel"
+        kern = "trmm_vsq_dma_kernel" if evals_per_launch > 128 else "trmm_vsq_smallb_kernel"
         roofline = {"bound": "mfma", "kernel": kern, "achieved": achieved,
                     "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": committed_traffic(split),
