@@ -131,9 +131,8 @@ struct ProposeArgs {
   int enabled = 0;
   const double *X = nullptr;      // [W][DPAD]
   const int *idx_s = nullptr;     // [n] walker of proposal i (already offset to the evaluated slice)
-  const int *idx_c = nullptr;     // complementary set members
   const double *zz = nullptr;     // [n]
-  const int *rint = nullptr;      // [n]
+  const int *partner = nullptr;   // [n] walker index of the complementary-set member drawn for proposal i
   double *factors = nullptr;      // [n] out: (d - 1) log zz
   int n = 0, d = 0;
 };

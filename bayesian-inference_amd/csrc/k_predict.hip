@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void kstar_kernel(
     double z = 1.0;
     int w = 0, j = 0;
     const bool live = b < pa.n;
-    if (live) { w = pa.idx_s[b]; j = pa.idx_c[pa.rint[b]]; z = pa.zz[b]; }
+    if (live) { w = pa.idx_s[b]; j = pa.partner[b]; z = pa.zz[b]; }
 #pragma unroll
     for (int dd = 0; dd < DPAD; ++dd) {
       double v = 0.0;

@@ -65,7 +65,7 @@ struct gpemu_sampler {
   int *idx = nullptr;          // [RING][2][W] members of each set, ascending walker index
   double *zz = nullptr;        // [RING][2][W]
   double *logu = nullptr;      // [RING][2][W]
-  int *rint = nullptr;         // [RING][2][W]
+  int *rint = nullptr;         // [RING][2][W]  partner walker of each proposal: c[randint(nc)] as a walker index
   uint64_t rng_ready_until = 0; // steps [.., rng_ready_until) of the device stream are in the ring
   double *q = nullptr;         // [qcap][DPAD]
   double *factors = nullptr;   // [W]
@@ -147,7 +147,10 @@ __global__ __launch_bounds__(1024) void rng_step_kernel(int *inds_r, int *idx_r,
       double u = u01_from(r.x, r.y);
       double t = (a - 1.0) * u + 1.0;
       zz[h * W + i] = t * t / a;
-      rint[h * W + i] = (int)(((unsigned long long)r.z * (unsigned long long)nc) >> 32);
+      // partner = member `randint(nc)` of the complementary set, stored as a walker index so that the
+      // consumers need one dependent load less (the set lists of this step are complete: barrier above)
+      const int rpos = (int)(((unsigned long long)r.z * (unsigned long long)nc) >> 32);
+      rint[h * W + i] = idx[(1 - h) * W + rpos];
       logu[h * W + i] = log(u01_from(r2.x, r2.y));
     }
   }
@@ -166,14 +169,14 @@ __global__ void build_sets_kernel(const int *inds, int *idx, int W) {
 // recomputed from the ensemble (the complementary set is unchanged during this half), so no rank
 // needs the other ranks' proposal rows; optionally records the chain row of its walkers.
 __global__ void accept_kernel(double *__restrict__ X, double *__restrict__ logp,
-                              const int *__restrict__ idx_s, const int *__restrict__ idx_c,
-                              const double *__restrict__ zz, const int *__restrict__ rint,
+                              const int *__restrict__ idx_s,
+                              const double *__restrict__ zz, const int *__restrict__ partner,
                               const double *__restrict__ newlp, const double *__restrict__ logu,
                               long long *__restrict__ naccept, int *__restrict__ flags, int ns, int d,
                               double *__restrict__ chain, double *__restrict__ lpchain) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ns) return;
-  const int w = idx_s[i], j = idx_c[rint[i]];
+  const int w = idx_s[i], j = partner[i];
   const double z = zz[i];
   const double nlp = newlp[i];
   if (nlp != nlp) atomicAdd(flags, 1);  // emcee raises on NaN log-probability
@@ -272,7 +275,7 @@ static int launch_accept(gpemu_sampler *s, int h, const double *dnewlp, int stor
     lpchain = s->lpchain + s->chain_len * s->W;
   }
   hipLaunchKernelGGL(accept_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, s->X, s->logp,
-                     s->idx + o2 + h * s->W, s->idx + o2 + (1 - h) * s->W, s->zz + o2 + h * s->W,
+                     s->idx + o2 + h * s->W, s->zz + o2 + h * s->W,
                      s->rint + o2 + h * s->W, dnewlp, s->logu + o2 + h * s->W, s->naccept, s->flags, ns,
                      (int)s->d, chain, lpchain);
   GP_HIP(hipGetLastError());
@@ -286,9 +289,8 @@ static ProposeArgs propose_args(gpemu_sampler *s, int h, int64_t lo, int64_t n) 
   pa.enabled = 1;
   pa.X = s->X;
   pa.idx_s = s->idx + o2 + h * s->W + lo;
-  pa.idx_c = s->idx + o2 + (1 - h) * s->W;
   pa.zz = s->zz + o2 + h * s->W + lo;
-  pa.rint = s->rint + o2 + h * s->W + lo;
+  pa.partner = s->rint + o2 + h * s->W + lo;
   pa.factors = s->factors + lo;
   pa.n = (int)n;
   pa.d = (int)s->d;
@@ -510,11 +512,13 @@ int gpemu_sampler_step_host_rng(gpemu_sampler *s, const int32_t *inds, const dou
   GP_ARG(n0 == s->ns[0], "inds must hold ceil(W/2) zeros");
   std::vector<int> hr(2 * W, 0);
   std::vector<double> hz(2 * W, 1.0), hu(2 * W, 0.0);
+  std::vector<int> members[2];                         // set lists in ascending walker order (as build_sets_kernel)
+  for (int64_t w = 0; w < W; ++w) members[inds[w]].push_back((int)w);
   for (int h = 0; h < 2; ++h) {
     const int64_t off = h == 0 ? 0 : s->ns[0], nc = W - s->ns[h];
     for (int64_t i = 0; i < s->ns[h]; ++i) {
       GP_ARG(rint[off + i] >= 0 && rint[off + i] < nc, "rint out of range");
-      hr[h * W + i] = (int)rint[off + i];
+      hr[h * W + i] = members[1 - h][(size_t)rint[off + i]];   // partner as a walker index
       hz[h * W + i] = zz[off + i];
       hu[h * W + i] = logu[off + i];
     }
