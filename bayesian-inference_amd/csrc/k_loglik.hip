@@ -123,21 +123,40 @@ __device__ __forceinline__ void walker_mean_sd(const double *__restrict__ mean_p
 }
 
 // writes the log-posterior of proposal b and, if enabled, finishes the stretch move for its walker
-__device__ __forceinline__ void finish_walker(double total, const double *__restrict__ Xq,
-                                              double *__restrict__ out, int64_t b, int d, int lane,
-                                              int accumulate, const AcceptArgs &aa) {
+// operands of the accept step, loaded at kernel start so that their (dependent: index -> walker state)
+// latency overlaps the partial-sum loads and the factorisation
+struct AcceptOperands {
+  int w = 0;
+  double oldlp = 0.0, factor = 0.0, logu = 0.0, xold = 0.0, xnew = 0.0;
+};
+__device__ __forceinline__ AcceptOperands load_accept_operands(const double *__restrict__ Xq, int64_t b, int lane,
+                                                               const AcceptArgs &aa) {
+  AcceptOperands ao;
+  if (!aa.enabled) return ao;
+  ao.w = aa.idx_s[b];
+  ao.oldlp = aa.logp[ao.w];
+  ao.factor = aa.factors[b];
+  ao.logu = aa.logu[b];
+  if (lane < DPAD) {
+    ao.xold = aa.X[(int64_t)ao.w * DPAD + lane];
+    ao.xnew = Xq[b * DPAD + lane];
+  }
+  return ao;
+}
+
+__device__ __forceinline__ void finish_walker(double total, double *__restrict__ out, int64_t b, int d, int lane,
+                                              int accumulate, const AcceptArgs &aa, const AcceptOperands &ao) {
   if (accumulate) total += out[b];
   if (!aa.enabled) {
     if (lane == 0) out[b] = total;
     return;
   }
-  const int w = aa.idx_s[b];
-  const double oldlp = aa.logp[w];
+  const int w = ao.w;
+  const double oldlp = ao.oldlp;
   if (total != total && lane == 0) atomicAdd(aa.flags, 1);  // emcee raises on NaN
-  const bool acc = (aa.factors[b] + total - oldlp) > aa.logu[b];
-  double xold = 0.0;
-  if (lane < DPAD) xold = aa.X[(int64_t)w * DPAD + lane];
-  if (lane < DPAD && acc) aa.X[(int64_t)w * DPAD + lane] = Xq[b * DPAD + lane];
+  const bool acc = (ao.factor + total - oldlp) > ao.logu;
+  const double xold = ao.xold;
+  if (lane < DPAD && acc) aa.X[(int64_t)w * DPAD + lane] = ao.xnew;
   if (lane == 0) {
     out[b] = total;
     if (acc) {
@@ -146,7 +165,7 @@ __device__ __forceinline__ void finish_walker(double total, const double *__rest
     }
   }
   if (aa.chain) {
-    if (lane < d) aa.chain[(int64_t)w * d + lane] = acc ? Xq[b * DPAD + lane] : xold;
+    if (lane < d) aa.chain[(int64_t)w * d + lane] = acc ? ao.xnew : xold;
     if (lane == 0) aa.lpchain[w] = acc ? total : oldlp;
   }
 }
@@ -182,6 +201,15 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
   const int64_t b = (int64_t)blockIdx.x * 4 + wave;
   if (b >= B) return;  // whole wave exits together; no workgroup barriers below
 
+  // everything that does not depend on the GP stage is requested first: the accept operands (a dependent
+  // index -> state chain) and the first observable block's constants
+  const AcceptOperands ao = load_accept_operands(Xq, b, lane, aa);
+  double gpre[KMAX];
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q) gpre[q] = (q < k && lane < k) ? G[q * k + lane] : 0.0;
+  const double gl_pre = (lane < k) ? g0[lane] : 0.0;
+  const double sc0_pre = scal[0], sc1_pre = scal[1];
+
   bool in = true;
   if (lane < d) in = (Xq[b * DPAD + lane] > lo[lane]) && (Xq[b * DPAD + lane] < hi[lane]);
   const bool inside = __all(in);
@@ -198,13 +226,14 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
       double h = 0.0;
 #pragma unroll
       for (int q = 0; q < KMAX; ++q) {
-        const double gq = (q < k && lane < k) ? Go[q * k + lane] : 0.0;
+        const double gq = (o == 0) ? gpre[q] : ((q < k && lane < k) ? Go[q * k + lane] : 0.0);
         h = fma(gq, readlane_f64(mu, q), h);
         row[q] = ((lane == q) ? 1.0 : 0.0) + sd * gq * readlane_f64(sd, q);
       }
-      const double gl = (lane < k) ? g0[(int64_t)o * k + lane] : 0.0;
+      const double gl = (o == 0) ? gl_pre : ((lane < k) ? g0[(int64_t)o * k + lane] : 0.0);
+      const double sc0 = (o == 0) ? sc0_pre : scal[2 * o], sc1 = (o == 0) ? sc1_pre : scal[2 * o + 1];
       h += gl;
-      const double quadA = sum_first_lanes<KMAX>((lane < k) ? mu * (h + gl) : 0.0) + scal[2 * o];
+      const double quadA = sum_first_lanes<KMAX>((lane < k) ? mu * (h + gl) : 0.0) + sc0;
       // right-looking Cholesky; y = L_M^-1 (sd o h) by forward substitution alongside.  One reciprocal
       // square root per pivot on the critical path; the logarithms of the pivots are taken after the
       // loop, one per lane in parallel.  Entries above the diagonal (lane < column) are never read.
@@ -224,10 +253,10 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
       const double logdiag = 0.5 * log(mypiv2);                       // lanes >= k hold pivot 1
       const double ww = sum_first_lanes<KMAX>(y * y);
       const double ldsum = sum_first_lanes<KMAX>(logdiag);
-      total += -0.5 * (quadA - ww) - 0.5 * (scal[2 * o + 1] + 2.0 * ldsum);
+      total += -0.5 * (quadA - ww) - 0.5 * (sc1 + 2.0 * ldsum);
     }
   }
-  finish_walker(total, Xq, out, b, d, lane, accumulate, aa);
+  finish_walker(total, out, b, d, lane, accumulate, aa, ao);
 }
 
 // General k (17..64): the k x k matrix of each walker lives in LDS (one wave per walker, lane = row).
@@ -304,7 +333,7 @@ __global__ __launch_bounds__(256) void loglik_lowrank_lds_kernel(
       __builtin_amdgcn_wave_barrier();
     }
   }
-  finish_walker(total, Xq, out, b, d, lane, accumulate, aa);
+  finish_walker(total, out, b, d, lane, accumulate, aa, load_accept_operands(Xq, b, lane, aa));
 }
 
 int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq, double *dout, int accumulate,
