@@ -204,7 +204,10 @@ int launch_kstar(gpemu_model *m, int64_t B, double *dXq, hipStream_t st, const P
   static const int big_rpw = getenv("GPEMU_KSTAR_RPW") ? atoi(getenv("GPEMU_KSTAR_RPW")) : 32;
   const int rows_per_wg = small ? 32 : 4 * big_rpw;
   w.cur_nchunk = (int)(m->Npad / rows_per_wg);
-  dim3 grid((unsigned)(round_up(B, TILE) / 64), (unsigned)w.cur_nchunk, (unsigned)m->k), block(256);
+  // column blocks of 64 queries: whole 128-column tiles for the triangular GEMM, except that a batch of at most
+  // 64 (always served by the small-batch kernel's 64-column items) needs only its first block
+  const int64_t ncols = (B <= 64) ? 64 : round_up(B, TILE);
+  dim3 grid((unsigned)(ncols / 64), (unsigned)w.cur_nchunk, (unsigned)m->k), block(256);
   const int pe0 = prof_mark(m, st);
   int kind = 0;
   if (m->kernel_kind == GPEMU_KERNEL_MATERN) kind = (m->nu == 0.5) ? 1 : (m->nu == 1.5 ? 2 : 3);
