@@ -95,68 +95,59 @@ def build_kernel(config) -> estimators.ARDKernel:
 
 
 def fit_emulator_group(config: "EmulationGroupConfig") -> dict[str, Any]:
-    """Standardise, PCA, fit one GP per retained PC (ref: emulation.py:53-192)."""
-    if os.path.exists(config.emulation_outputfile):
-        if config.force_retrain:
-            os.remove(config.emulation_outputfile)
-            logger.info(f'Removed {config.emulation_outputfile}')
-        else:
-            logger.info(f'Emulators already exist: {config.emulation_outputfile} (to force retrain, set force_retrain: True)')
+    """Standardise, PCA, fit one GP per retained PC (ref: emulation.py:53-192).  Returns the results dict
+    (schema in SURVEY 8b), or {} when a pickle exists and ``force_retrain`` is off."""
+    target = Path(config.emulation_outputfile)
+    if target.exists():
+        if not config.force_retrain:
+            logger.info(f'{target} exists; keeping it (force_retrain is off)')
             return {}
+        target.unlink()
+        logger.info(f'{target} deleted (force_retrain)')
 
-    logger.info('Doing PCA...')
-    data_IO = _data_IO()
-    Y = data_IO.predictions_matrix_from_h5(config.output_dir, filename=config.observables_filename,
-                                           observable_filter=config.observable_filter)
-    max_n_components = config.max_n_components_to_calculate
-    if max_n_components is not None:
-        logger.info(f"Running with max n_pc={max_n_components}")
-    scaler, pca, Y_pca = estimators.scale_and_pca(Y, n_components=max_n_components)
-    Y_pca_truncated = Y_pca[:, :config.n_pc]
-    Y_reconstructed_truncated = Y_pca_truncated.dot(pca.components_[:config.n_pc, :])
-    Y_reconstructed_truncated_unscaled = scaler.inverse_transform(Y_reconstructed_truncated)
-    logger.info(f'  Variance explained by first {config.n_pc} components: '
-                f'{np.sum(pca.explained_variance_ratio_[:config.n_pc])}')
+    io = _data_IO()
+    observables = io.predictions_matrix_from_h5(config.output_dir, filename=config.observables_filename,
+                                                observable_filter=config.observable_filter)
+    n_keep = config.n_pc
+    n_calc = config.max_n_components_to_calculate           # None: all min(N, F) components
+    logger.info('Scaling + PCA on the device' + ('' if n_calc is None else f' (first {n_calc} components)') + '...')
+    scaler, pca, scores = estimators.scale_and_pca(observables, n_components=n_calc)
+    kept_scores = scores[:, :n_keep]
+    back_projected = kept_scores @ pca.components_[:n_keep]
+    logger.info(f'  {n_keep} components explain {pca.explained_variance_ratio_[:n_keep].sum():.6f} of the variance')
 
-    design = data_IO.design_array_from_h5(config.output_dir, filename=config.observables_filename)
-    kernel = build_kernel(config)
-
-    logger.info("")
-    logger.info('Fitting GPs...')
-    logger.info(f'  The design has {design.shape[1]} parameters')
-    # the n_pc GPs and their restarts are independent optimisations: run them concurrently on the device
-    emulators = estimators.fit_gps(design, Y_pca_truncated, kernel, alpha=config.alpha,
+    design = io.design_array_from_h5(config.output_dir, filename=config.observables_filename)
+    logger.info(f'Fitting {n_keep} GPs on {design.shape[0]} design points x {design.shape[1]} parameters '
+                f'({config.n_restarts} restarts each)...')
+    # the GPs and their restarts are independent optimisations: they run concurrently on the device
+    emulators = estimators.fit_gps(design, kept_scores, build_kernel(config), alpha=config.alpha,
                                    n_restarts_optimizer=config.n_restarts, copy_X_train=False)
+    for index, gp in enumerate(emulators):
+        logger.info(f'  PC {index}: {gp.kernel_}')
 
-    logger.info("")
-    logger.info('Kernel hyperparameters:')
-    for emulator in emulators:
-        logger.info(f'  {emulator.kernel_}')
-    logger.info("")
-
-    output_dict: dict[str, Any] = {'PCA': {}}
-    output_dict['PCA']['Y'] = Y
-    output_dict['PCA']['Y_pca'] = Y_pca
-    output_dict['PCA']['Y_pca_truncated'] = Y_pca_truncated
-    output_dict['PCA']['Y_reconstructed_truncated'] = Y_reconstructed_truncated
-    output_dict['PCA']['Y_reconstructed_truncated_unscaled'] = Y_reconstructed_truncated_unscaled
-    output_dict['PCA']['pca'] = pca
-    output_dict['PCA']['scaler'] = scaler
-    output_dict['emulators'] = emulators
-    return output_dict
+    return {
+        'PCA': {
+            'Y': observables,
+            'Y_pca': scores,
+            'Y_pca_truncated': kept_scores,
+            'Y_reconstructed_truncated': back_projected,
+            'Y_reconstructed_truncated_unscaled': scaler.inverse_transform(back_projected),
+            'pca': pca,
+            'scaler': scaler,
+        },
+        'emulators': emulators,
+    }
 
 
 ####################################################################################################
 def read_emulators(config: "EmulationGroupConfig") -> dict[str, Any]:
-    with Path(config.emulation_outputfile).open("rb") as f:
-        return pickle.load(f)
+    return pickle.loads(Path(config.emulation_outputfile).read_bytes())
 
 
 def write_emulators(config: "EmulationGroupConfig", output_dict: dict[str, Any]) -> None:
-    filename = Path(config.emulation_outputfile)
-    filename.parent.mkdir(parents=True, exist_ok=True)
-    with filename.open('wb') as f:
-        pickle.dump(output_dict, f)
+    target = Path(config.emulation_outputfile)
+    target.parent.mkdir(parents=True, exist_ok=True)
+    target.write_bytes(pickle.dumps(output_dict))
 
 
 ####################################################################################################
@@ -336,106 +327,110 @@ class _Base:
         return f"[i] {self.__class__.__name__} with \n .  {body}"
 
 
+_TOP_LEVEL_KEYS = ('observable_table_dir', 'observable_config_dir', 'observables_filename')
+
+
+def _read_yaml(path):
+    with open(path, 'r') as handle:
+        return yaml.safe_load(handle)
+
+
+def _check_kernels(active):
+    """The reference's validity rules for the ``kernels`` block (ref: emulation.py:583-603)."""
+    base = [name for name in ('matern', 'rbf') if name in active]
+    assert len(base) == 1, "Must provide exactly one of 'matern', 'rbf' kernel"
+    noise = active.get('noise')
+    if noise is None:
+        return
+    assert 'type' in noise and 'args' in noise, "Noise configuration must have keys 'type' and 'args'"
+    if noise['type'] != 'white':
+        raise ValueError("Unsupported noise kernel")
+    assert set(noise['args']) == {'noise_level', 'noise_level_bounds'}, \
+        "Must provide arguments 'noise_level' and 'noise_level_bounds' for white noise kernel"
+
+
 class EmulationGroupConfig(_Base):
-    """Per-group settings read from the YAML (ref: emulation.py:551-622); same attribute names."""
+    """Settings of one emulation group from the analysis YAML (ref: emulation.py:551-622); the attribute
+    names are the reference's.  ``emulation_group_name=None`` reads an un-grouped ``emulators`` block."""
 
     def __init__(self, analysis_name='', parameterization='', analysis_config='', config_file='',
                  emulation_group_name: str | None = None):
-        self.analysis_name = analysis_name
-        self.parameterization = parameterization
-        self.analysis_config = analysis_config
-        self.config_file = config_file
-        with open(self.config_file, 'r') as stream:
-            config = yaml.safe_load(stream)
-        self.observable_table_dir = config['observable_table_dir']
-        self.observable_config_dir = config['observable_config_dir']
-        self.observables_filename = config["observables_filename"]
+        self.analysis_name, self.parameterization = analysis_name, parameterization
+        self.analysis_config, self.config_file = analysis_config, config_file
+        top = _read_yaml(config_file)
+        for key in _TOP_LEVEL_KEYS:
+            setattr(self, key, top[key])
 
-        emulators = self.analysis_config["parameters"]["emulators"]
-        emulator_configuration = emulators if emulation_group_name is None else emulators[emulation_group_name]
-        self.force_retrain = emulator_configuration['force_retrain']
-        self.n_pc = emulator_configuration['n_pc']
-        self.max_n_components_to_calculate = emulator_configuration.get("max_n_components_to_calculate", None)
+        block = analysis_config['parameters']['emulators']
+        if emulation_group_name is not None:
+            block = block[emulation_group_name]
+        self.force_retrain, self.n_pc = block['force_retrain'], block['n_pc']
+        self.max_n_components_to_calculate = block.get('max_n_components_to_calculate')
+        self.n_restarts, self.alpha = block['GPR']['n_restarts'], block['GPR']['alpha']
 
-        self.active_kernels = {kt: emulator_configuration['kernels'][kt]
-                               for kt in emulator_configuration['kernels']['active']}
-        assert sum(s in self.active_kernels for s in ("matern", "rbf")) == 1, \
-            "Must provide exactly one of 'matern', 'rbf' kernel"
-        if 'noise' in self.active_kernels:
-            noise = self.active_kernels['noise']
-            assert all(k in noise for k in ("type", "args")), "Noise configuration must have keys 'type' and 'args'"
-            if noise["type"] == "white":
-                assert set(noise["args"]) == {"noise_level", "noise_level_bounds"}, \
-                    "Must provide arguments 'noise_level' and 'noise_level_bounds' for white noise kernel"
-            else:
-                raise ValueError("Unsupported noise kernel")
+        kernels = block['kernels']
+        self.active_kernels = {name: kernels[name] for name in kernels['active']}     # order of `active` is kept
+        _check_kernels(self.active_kernels)
 
-        self.n_restarts = emulator_configuration["GPR"]['n_restarts']
-        self.alpha = emulator_configuration["GPR"]["alpha"]
-
+        wanted, unwanted = block.get('observable_list', []), block.get('observable_exclude_list', [])
         self.observable_filter = None
-        observable_list = emulator_configuration.get("observable_list", [])
-        observable_exclude_list = emulator_configuration.get("observable_exclude_list", [])
-        if observable_list or observable_exclude_list:
-            self.observable_filter = _data_IO().ObservableFilter(include_list=observable_list,
-                                                                 exclude_list=observable_exclude_list)
+        if wanted or unwanted:
+            self.observable_filter = _data_IO().ObservableFilter(include_list=wanted, exclude_list=unwanted)
 
-        self.output_dir = os.path.join(config['output_dir'], f'{analysis_name}_{parameterization}')
-        name = 'emulation.pkl' if emulation_group_name is None else f'emulation_group_{emulation_group_name}.pkl'
-        self.emulation_outputfile = os.path.join(self.output_dir, name)
+        self.output_dir = os.path.join(top['output_dir'], f'{analysis_name}_{parameterization}')
+        pickle_name = 'emulation.pkl' if emulation_group_name is None else f'emulation_group_{emulation_group_name}.pkl'
+        self.emulation_outputfile = os.path.join(self.output_dir, pickle_name)
 
 
 class EmulationConfig(_Base):
-    """All groups of one analysis (ref: emulation.py:624-709); same attribute and method names."""
+    """The emulation groups of one analysis (ref: emulation.py:624-709); attribute and method names kept."""
 
     def __init__(self, analysis_name: str, parameterization: str, config_file, analysis_config=None,
                  emulation_groups_config=None):
-        self.analysis_name = analysis_name
-        self.parameterization = parameterization
+        self.analysis_name, self.parameterization = analysis_name, parameterization
         self.config_file = Path(config_file)
-        self.analysis_config = analysis_config if analysis_config is not None else {}
-        self.emulation_groups_config = emulation_groups_config if emulation_groups_config is not None else {}
-        with self.config_file.open() as stream:
-            self.config = yaml.safe_load(stream)
-        self.observable_table_dir = self.config['observable_table_dir']
-        self.observable_config_dir = self.config['observable_config_dir']
-        self.observables_filename = self.config["observables_filename"]
-        self.output_dir = os.path.join(self.config['output_dir'], f'{self.analysis_name}_{self.parameterization}')
+        self.analysis_config = {} if analysis_config is None else analysis_config
+        self.emulation_groups_config = {} if emulation_groups_config is None else emulation_groups_config
+        self.config = _read_yaml(self.config_file)
+        for key in _TOP_LEVEL_KEYS:
+            setattr(self, key, self.config[key])
+        self.output_dir = os.path.join(self.config['output_dir'], f'{analysis_name}_{parameterization}')
         self._observable_filter = None
         self._sort_observables_in_matrix = None
 
     @classmethod
     def from_config_file(cls, analysis_name: str, parameterization: str, config_file, analysis_config):
-        c = cls(analysis_name=analysis_name, parameterization=parameterization, config_file=config_file,
-                analysis_config=analysis_config)
-        c.emulation_groups_config = {
-            k: EmulationGroupConfig(analysis_name=c.analysis_name, parameterization=c.parameterization,
-                                    analysis_config=c.analysis_config, config_file=c.config_file,
-                                    emulation_group_name=k)
-            for k in c.analysis_config["parameters"]["emulators"]
-        }
-        return c
+        self = cls(analysis_name=analysis_name, parameterization=parameterization, config_file=config_file,
+                   analysis_config=analysis_config)
+        for group in analysis_config['parameters']['emulators']:
+            self.emulation_groups_config[group] = EmulationGroupConfig(
+                analysis_name=analysis_name, parameterization=parameterization, analysis_config=analysis_config,
+                config_file=self.config_file, emulation_group_name=group)
+        return self
+
+    def _need_groups(self, what):
+        if not self.emulation_groups_config:
+            raise ValueError(f"Need to specify emulation groups to provide {what}")
 
     def read_all_emulator_groups(self):
         return {name: read_emulators(cfg) for name, cfg in self.emulation_groups_config.items()}
 
     @property
     def observable_filter(self):
+        """Union of the groups' filters plus the global exclude list (built once)."""
         if self._observable_filter is None:
-            if not self.emulation_groups_config:
-                raise ValueError("Need to specify emulation groups to provide an observable filter")
-            include_list: list[str] = []
-            exclude_list: list[str] = self.config.get("global_observable_exclude_list", [])
-            for group_config in self.emulation_groups_config.values():
-                include_list.extend(group_config.observable_filter.include_list)
-                exclude_list.extend(group_config.observable_filter.exclude_list)
-            self._observable_filter = _data_IO().ObservableFilter(include_list=include_list, exclude_list=exclude_list)
+            self._need_groups("an observable filter")
+            keep: list[str] = []
+            drop: list[str] = self.config.get('global_observable_exclude_list', [])
+            for group in self.emulation_groups_config.values():
+                keep += group.observable_filter.include_list
+                drop += group.observable_filter.exclude_list
+            self._observable_filter = _data_IO().ObservableFilter(include_list=keep, exclude_list=drop)
         return self._observable_filter
 
     @property
     def sort_observables_in_matrix(self) -> SortEmulationGroupObservables:
         if self._sort_observables_in_matrix is None:
-            if not self.emulation_groups_config:
-                raise ValueError("Need to specify emulation groups to provide an sorting for observable group observables")
+            self._need_groups("an sorting for observable group observables")
             self._sort_observables_in_matrix = SortEmulationGroupObservables.learn_mapping(self)
         return self._sort_observables_in_matrix
