@@ -43,13 +43,9 @@ def _data_IO():
 
 ####################################################################################################
 def _rank_world():
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_rank(), dist.get_world_size()
-    except Exception:
-        pass
-    return 0, 1
+    """(rank, world); joins the launcher's process group on first use (``gpemu.dist``)."""
+    from gpemu import dist as gdist
+    return gdist.rank_world()
 
 
 def fit_emulators(emulation_config: "EmulationConfig") -> None:
@@ -147,7 +143,10 @@ def read_emulators(config: "EmulationGroupConfig") -> dict[str, Any]:
 def write_emulators(config: "EmulationGroupConfig", output_dict: dict[str, Any]) -> None:
     target = Path(config.emulation_outputfile)
     target.parent.mkdir(parents=True, exist_ok=True)
-    target.write_bytes(pickle.dumps(output_dict))
+    # written under a private name and moved into place: a reader (or another rank) never sees half a pickle
+    scratch = target.with_name(f'{target.name}.{os.getpid()}.tmp')
+    scratch.write_bytes(pickle.dumps(output_dict))
+    os.replace(scratch, target)
 
 
 ####################################################################################################
@@ -160,12 +159,9 @@ def compute_emulator_cov_unexplained(emulation_config, emulation_results) -> dic
 
 
 def compute_emulator_group_cov_unexplained(emulation_group_config, emulation_group_result) -> np.ndarray:
-    """S_{>k} diag(explained_variance_{>k}) S_{>k}^T (ref: emulation.py:227-251).  A one-off F x F
-    product at setup time, kept on the host exactly as the reference writes it."""
-    pca = emulation_group_result['PCA']['pca']
-    S_unexplained = pca.components_.T[:, emulation_group_config.n_pc:]
-    D_unexplained = np.diag(pca.explained_variance_[emulation_group_config.n_pc:])
-    return S_unexplained.dot(D_unexplained.dot(S_unexplained.T))
+    """S_{>k} diag(explained_variance_{>k}) S_{>k}^T (ref: emulation.py:227-251): one F x F x (n_comp - k)
+    product on the device's f64 matrix cores (``gpemu_truncation_cov``), computed once per group."""
+    return estimators.truncation_covariance(emulation_group_result['PCA']['pca'], emulation_group_config.n_pc)
 
 
 ####################################################################################################
@@ -250,23 +246,37 @@ class SortEmulationGroupObservables:
 
 
 ####################################################################################################
-# device models are built once per results dict and reused (the reference rebuilds nothing either:
-# its sklearn objects live in the dict)
-_DEVICE_MODELS: dict[int, tuple[Any, DeviceModel, int]] = {}
+# Device models are built once per (results dict, n_pc, truncation covariance) and reused (the reference rebuilds
+# nothing either: its sklearn objects live in the dict).  The cache holds at most GPEMU_MODEL_CACHE entries
+# (default 4), least recently used first out; an evicted model is released as soon as no sampler uses it.
+_DEVICE_MODELS: "dict[tuple[int, int], tuple[Any, np.ndarray | None, DeviceModel]]" = {}
+
+
+def _model_cache_limit() -> int:
+    return max(1, int(os.environ.get("GPEMU_MODEL_CACHE", "4")))
+
+
+def release_device_models() -> None:
+    """Forget every cached device model (their HBM is freed once nothing else refers to them)."""
+    _DEVICE_MODELS.clear()
 
 
 def device_model_for(results: dict[str, Any], n_pc: int, cov_unexplained: np.ndarray | None = None) -> DeviceModel:
     """The DeviceModel (GP factors, PCA, scaler resident in HBM) of one emulation group's results dict."""
-    key = id(results)
+    key = (id(results), int(n_pc))
     hit = _DEVICE_MODELS.get(key)
-    if hit is not None and hit[0] is results and hit[2] == n_pc:
-        return hit[1]
+    if hit is not None and hit[0] is results:
+        same_cov = (hit[1] is cov_unexplained) or (
+            hit[1] is not None and cov_unexplained is not None and np.array_equal(hit[1], cov_unexplained))
+        if same_cov:
+            _DEVICE_MODELS[key] = _DEVICE_MODELS.pop(key)      # most recently used last
+            return hit[2]
     emulators = results['emulators'][:n_pc]
     pca, scaler = results['PCA']['pca'], results['PCA']['scaler']
     k0 = emulators[0].kernel_
+    given = cov_unexplained
     if cov_unexplained is None:
-        S_un = pca.components_.T[:, n_pc:]
-        cov_unexplained = S_un.dot(np.diag(pca.explained_variance_[n_pc:]).dot(S_un.T))
+        cov_unexplained = estimators.truncation_covariance(pca, n_pc)
     dm = DeviceModel(
         X_train=emulators[0].X_train_,
         ls=np.stack([e.kernel_.length_scale for e in emulators]),
@@ -277,7 +287,10 @@ def device_model_for(results: dict[str, Any], n_pc: int, cov_unexplained: np.nda
         const=np.array([e.kernel_.constant_value for e in emulators]) if k0.has_const else None,
         noise=np.array([e.kernel_.noise_level for e in emulators]) if k0.has_noise else None,
         cov_unexplained=cov_unexplained)
-    _DEVICE_MODELS[key] = (results, dm, n_pc)
+    _DEVICE_MODELS.pop(key, None)
+    _DEVICE_MODELS[key] = (results, given, dm)
+    while len(_DEVICE_MODELS) > _model_cache_limit():
+        _DEVICE_MODELS.pop(next(iter(_DEVICE_MODELS)))
     return dm
 
 

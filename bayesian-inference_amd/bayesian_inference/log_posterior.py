@@ -43,6 +43,8 @@ def initialize_pool_variables(local_min, local_max, local_emulation_config, loca
     emulator_cov_unexplained = local_emulator_cov_unexplained
     _state["models"] = None
     _state["n_div"] = None
+    # the previous run's device models (k N^2 doubles each) are not needed any more
+    emulation.release_device_models()
 
 
 def _group_layouts():

@@ -19,6 +19,7 @@ import numpy as np
 import yaml
 
 from bayesian_inference import emulation, log_posterior
+from gpemu import dist as gdist
 from gpemu.sampler import EnsembleSampler
 
 logger = logging.getLogger(__name__)
@@ -32,13 +33,9 @@ def _data_IO():
 
 
 def _rank_world():
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_rank(), dist.get_world_size()
-    except Exception:
-        pass
-    return 0, 1
+    """(rank, world); joins the launcher's process group on first use (the reference's steering script
+    initialises none)."""
+    return gdist.rank_world()
 
 
 def _rank():
@@ -58,17 +55,7 @@ def closure_owner(closure_index, world):
 
 def _same_on_all_ranks(arr):
     """Rank 0's copy of ``arr`` on every rank (identity without torch.distributed)."""
-    try:
-        import torch
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            where = "cuda" if dist.get_backend() == "nccl" else "cpu"
-            buf = torch.from_numpy(np.ascontiguousarray(arr)).to(where)
-            dist.broadcast(buf, src=0)
-            return buf.cpu().numpy()
-    except ImportError:
-        pass
-    return arr
+    return gdist.rank0_array(arr)
 
 
 def _best_distinct(sampler, count):

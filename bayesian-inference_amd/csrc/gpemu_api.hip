@@ -4,6 +4,7 @@
 #include <cstdarg>
 
 #include "internal.h"
+#include "gemm.h"
 #include "linalg_dev.h"
 
 namespace gpemu {
@@ -487,6 +488,64 @@ int gpemu_logpost(gpemu_model *m, int64_t B, const double *X, double *out, int m
     if (e != hipSuccess) { set_error("logpost: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
   }
   hipFree(dX); hipFree(dout);
+  return rc;
+}
+
+// ---- truncation covariance -----------------------------------------------------------------------
+}  // extern "C"
+namespace gpemu {
+// rows n_pc.. of the components, zero padded to [Kp][Fp]: A plain, Bm scaled by the row's explained variance
+__global__ void trunc_pack_kernel(const double *__restrict__ comp, const double *__restrict__ ev, double *__restrict__ A,
+                                  double *__restrict__ Bm, int F, int Fp, int K, int Kp, int n_pc) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)Kp * Fp) return;
+  const int r = (int)(idx / Fp), f = (int)(idx - (int64_t)r * Fp);
+  double v = 0.0, lam = 0.0;
+  if (r < K && f < F) { v = comp[(int64_t)(n_pc + r) * F + f]; lam = ev[n_pc + r]; }
+  A[idx] = v;
+  Bm[idx] = lam * v;
+}
+}  // namespace gpemu
+extern "C" {
+
+int gpemu_truncation_cov(int device, int64_t n_comp, int64_t F, int64_t n_pc, const double *components,
+                         const double *explained_variance, double *cov_out) {
+  GP_ARG(components && explained_variance && cov_out, "null pointer");
+  GP_ARG(n_comp > 0 && F > 0 && n_pc >= 0 && n_pc <= n_comp, "n_comp, F, n_pc");
+  GP_TRY(check_device(device));
+  GP_HIP(hipSetDevice(device));
+  const int64_t K = n_comp - n_pc;
+  if (K == 0) {
+    memset(cov_out, 0, sizeof(double) * (size_t)(F * F));
+    return GPEMU_OK;
+  }
+  const int64_t Fp = round_up(F, 64), Kp = round_up(K, 32);
+  double *dcomp = nullptr, *dev_ = nullptr, *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  hipStream_t st = nullptr;   // a one-off setup product: the null stream
+  int rc = dev_alloc(&dcomp, n_comp * F);
+  if (rc == GPEMU_OK) rc = dev_alloc(&dev_, n_comp);
+  if (rc == GPEMU_OK) rc = dev_alloc(&dA, Kp * Fp);
+  if (rc == GPEMU_OK) rc = dev_alloc(&dB, Kp * Fp);
+  if (rc == GPEMU_OK) rc = dev_alloc(&dC, Fp * Fp);
+  if (rc == GPEMU_OK) rc = upload(dcomp, components, n_comp * F, st);
+  if (rc == GPEMU_OK) rc = upload(dev_, explained_variance, n_comp, st);
+  if (rc == GPEMU_OK) {
+    const int64_t n = Kp * Fp;
+    hipLaunchKernelGGL(trunc_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dcomp, dev_, dA, dB,
+                       (int)F, (int)Fp, (int)K, (int)Kp, (int)n_pc);
+    GemmArgs g;                       // C[f][g] = sum_r A[r][f] * (lambda_r A[r][g]): both operands k-major
+    g.A = dA; g.B = dB; g.C = dC;
+    g.lda = Fp; g.ldb = Fp; g.ldc = Fp;
+    g.M = (int)Fp; g.N = (int)Fp; g.K = (int)Kp;
+    rc = launch_gemm(g, true, true, 1, st);
+  }
+  if (rc == GPEMU_OK) {
+    hipError_t e = hipMemcpy2DAsync(cov_out, sizeof(double) * F, dC, sizeof(double) * Fp, sizeof(double) * F, (size_t)F,
+                                    hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { set_error("truncation_cov: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
+  }
+  hipFree(dcomp); hipFree(dev_); hipFree(dA); hipFree(dB); hipFree(dC);
   return rc;
 }
 

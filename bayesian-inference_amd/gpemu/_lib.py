@@ -59,6 +59,7 @@ _SIGNATURES = {
                                       C.c_int, C.c_int, C.c_double, C.c_void_p]),
     "gpemu_cholesky": (C.c_int, [C.c_int, c_i64, C.c_void_p]),
     "gpemu_pca_fit": (C.c_int, [C.c_int, c_i64, c_i64, C.c_void_p, c_i64] + [C.c_void_p] * 10),
+    "gpemu_truncation_cov": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpemu_sampler_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, c_i64,
                                        C.c_double, C.c_uint64]),
     "gpemu_sampler_destroy": (C.c_int, [C.c_void_p]),

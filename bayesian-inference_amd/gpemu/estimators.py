@@ -72,6 +72,12 @@ def scale_and_pca(Y, n_components=None, device=None):
     return scaler, pca, out["Y_pca"]
 
 
+def truncation_covariance(pca, n_pc, device=None):
+    """Covariance carried by the discarded components, ``S_{>k} diag(var_{>k}) S_{>k}^T``
+    (ref: emulation.py:227-251), as one device GEMM."""
+    return _fit.truncation_cov(pca.components_, pca.explained_variance_, n_pc, device=device)
+
+
 # ------------------------------------------------------------------------------------------------
 class ARDKernel:
     """base (+ ConstantKernel) (+ WhiteKernel) in the order the reference builds it

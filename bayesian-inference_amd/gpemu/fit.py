@@ -109,3 +109,15 @@ def pca_fit(Y, n_components=None, device=None):
                                    ptr(out["Y_pca"]), ptr(out["flip_argmax"]), ptr(ns)))
     out["n_sweeps"] = int(ns[0])
     return out
+
+
+def truncation_cov(components, explained_variance, n_pc, device=None):
+    """S_{>k} diag(explained_variance_{>k}) S_{>k}^T (F x F) on the device (ref: emulation.py:227-251)."""
+    _lib.require_device()
+    device = _lib.resolve_device(device)
+    components = as_f64(components)
+    nc, F = components.shape
+    ev = as_f64(explained_variance, (nc,))
+    out = np.empty((F, F))
+    check(_lib.lib().gpemu_truncation_cov(int(device), nc, F, int(n_pc), ptr(components), ptr(ev), ptr(out)))
+    return out

@@ -463,6 +463,11 @@ class EnsembleSampler:
     def _ensure(self):
         if self._impl is not None:
             return
+        if self.world_size > 1:
+            # a sharded chain needs the same random stream on every rank (the ranks only exchange
+            # log-probabilities): rank 0's seed wins, whether it was given or drawn from numpy's global state
+            from . import dist as gdist
+            self._seed = gdist.rank0_int(self._seed)
         hook = getattr(self.log_prob_fn, "_gpemu_device_models", None)
         if hook is not None:
             self._impl = DeviceSampler(hook(), self.nwalkers, a=self.a, seed=self._seed)

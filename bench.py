@@ -54,8 +54,7 @@ def build_workload(device=0):
         Ls.append(L)
         alphas.append(alpha)
     fit.close()
-    S_un = pca.components_.T[:, N_PC:]
-    cun = S_un.dot(np.diag(pca.explained_variance_[N_PC:]).dot(S_un.T))
+    cun = estimators.truncation_covariance(pca, N_PC, device=device)
     return dict(prob=prob, ls=np.tile(ls, (N_PC, 1)), noise=np.full(N_PC, noise), alpha=np.stack(alphas),
                 L=np.stack(Ls), components=pca.components_[:N_PC], mean=scaler.mean_, scale=scaler.scale_,
                 cun=cun)

@@ -152,6 +152,15 @@ int gpemu_pca_fit(int device, int64_t N, int64_t F, const double *Y, int64_t n_c
                   double *components, double *explained_variance, double *explained_variance_ratio,
                   double *Y_pca, int64_t *flip_argmax, int64_t *n_sweeps);
 
+/* ---- truncation covariance ----------------------------------------------------------------------
+ * Replaces ref: emulation.py:227-251 (compute_emulator_group_cov_unexplained):
+ *   cov_out[F*F] = S_{>k} diag(explained_variance_{>k}) S_{>k}^T,  S = components^T,
+ * components[n_comp*F] = pca.components_, explained_variance[n_comp], k = n_pc: one F x F x (n_comp - n_pc)
+ * product on the f64 matrix cores.  The reference divides it by the batch size at use (emulation.py:531-532);
+ * that stays with the callers (n_div). */
+int gpemu_truncation_cov(int device, int64_t n_comp, int64_t F, int64_t n_pc, const double *components,
+                         const double *explained_variance, double *cov_out);
+
 /* ---- stretch-move ensemble sampler ------------------------------------------------------------
  * Replaces ref: mcmc.py:77-107, 187-204: emcee.EnsembleSampler(n_walkers, ndim, log_posterior,
  * pool=Pool()) with its default StretchMove(a=2) and the pool.map over walkers.  The ensemble,

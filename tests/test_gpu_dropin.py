@@ -138,7 +138,7 @@ def test_fit_emulator_group_end_to_end(tmp_path):
     assert emulation.fit_emulator_group(cfg) == {}
 
 
-def test_run_mcmc_end_to_end(tmp_path):
+def test_run_mcmc_end_to_end(tmp_path, monkeypatch):
     from bayesian_inference import emulation, mcmc
     g = GU.load("g1_rbf_noise")
     written = {}
@@ -149,8 +149,9 @@ def test_run_mcmc_end_to_end(tmp_path):
     np.random.seed(1)
     emulation.fit_emulators(ec)
     # single group: the merged matrix is the group matrix
-    emulation.EmulationConfig.sort_observables_in_matrix = property(lambda self: DU.TrivialSort("main"))
-    emulation.EmulationConfig.observable_filter = property(lambda self: None)
+    monkeypatch.setattr(emulation.EmulationConfig, "sort_observables_in_matrix",
+                        property(lambda self: DU.TrivialSort("main")))
+    monkeypatch.setattr(emulation.EmulationConfig, "observable_filter", property(lambda self: None))
     cfg = mcmc.MCMCConfig("test_analysis", "exponential", analysis, path)
     mcmc.run_mcmc(cfg)
     out = written[cfg.mcmc_outputfile]

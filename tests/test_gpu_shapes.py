@@ -198,47 +198,3 @@ def test_pca_shape_sweep(N, F):
     Ys = (Y - mean) / scale
     rec = out["Y_pca"] @ out["components"] + out["pca_mean"]
     assert np.max(np.abs(rec - Ys)) < 1e-10 * max(1.0, np.max(np.abs(Ys)))
-
-
-def test_stress_size_n5000_f2000():
-    """BASELINE configs[4] shape (N_design = 5000, N_obs = 2000): the device fit-side factorisation feeds a
-    model whose predictive mean / variance and log-posterior (both forms) match the oracle."""
-    from gpemu import synthetic
-    from gpemu.fit import DeviceFit
-    from gpemu.model import DeviceModel
-    N, F, k = 5000, 2000, 3
-    prob = synthetic.make_problem(N, F, seed=3)
-    mean, scale, _ = O.scaler_fit(prob["Y"])
-    pca = O.pca_fit((prob["Y"] - mean) / scale, n_components=k + 5)       # a few components past k for the truncation term
-    spec = O.KernelSpec(kind=O.RBF, nu=np.inf, has_const=False, has_noise=True)
-    theta = np.log(np.r_[(prob["hi"] - prob["lo"]) * 0.5, 0.05])
-    # factors from the DEVICE fit path (blocked Cholesky at N = 5000) ...
-    fit = DeviceFit(prob["design"], kernel_kind=0, has_noise=True, jitter=1e-10)
-    Ls, alphas = [], []
-    for i in range(k):
-        L, a, _ = fit.factor(pca["Y_pca"][:, i], theta)
-        Ls.append(L)
-        alphas.append(a)
-    fit.close()
-    # ... checked against the oracle's factorisation for one PC
-    gp0 = O.gp_fit_at_theta(prob["design"], pca["Y_pca"][:, 0], theta, spec, 1e-10)
-    assert np.max(np.abs(Ls[0] - gp0.L)) < 1e-9 * np.max(np.abs(gp0.L))
-    assert np.max(np.abs(alphas[0] - gp0.alpha)) < 1e-6 * np.max(np.abs(gp0.alpha))
-    gps = [gp0] + [O.GP(ls=gp0.ls, const=gp0.const, noise=gp0.noise, L=Ls[i], alpha=alphas[i]) for i in range(1, k)]
-    model = O.GroupModel(X_train=prob["design"], spec=spec, gps=gps, components=pca["components"],
-                         explained_variance=pca["explained_variance"], scaler_mean=mean, scaler_scale=scale, n_pc=k)
-    cu = O.cov_unexplained(model)
-    dm = DeviceModel(X_train=prob["design"], ls=np.stack([g.ls for g in gps]), alpha=np.stack(alphas), L=np.stack(Ls),
-                     components=pca["components"][:k], scaler_mean=mean, scaler_scale=scale, kernel_kind=0,
-                     noise=np.array([g.noise for g in gps]), cov_unexplained=cu)
-    X = synthetic.make_walkers(700, seed=4)
-    m, v = dm.gp_predict(X)
-    mo, vo = O.gp_predict_all(X[:3], model)
-    assert np.max(np.abs(m[:3] - mo)) < TOL * np.max(np.abs(mo)) and np.max(np.abs(v[:3] - vo)) < TOL
-    dm.likelihood_setup(prob["y_exp"], prob["y_err"], prob["lo"], prob["hi"], 1.0)
-    lp = dm.logpost(X)
-    ref = np.array([O.log_posterior(X[i], {"g": model}, prob["lo"], prob["hi"], prob["y_exp"], prob["y_err"])[0]
-                    for i in range(2)])
-    np.testing.assert_allclose(lp[:2], ref, rtol=TOL)
-    np.testing.assert_allclose(dm.logpost(X[:2], mode=1), ref, rtol=TOL)
-    dm.close()

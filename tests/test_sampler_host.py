@@ -202,3 +202,40 @@ def test_closure_tests_run_as_replicas_gloo_world2(tmp_path, monkeypatch):
     assert sorted(np.r_[s0, s1]) == [0, 1, 2, 3, 4] and list(s0) == [1, 3] and list(s1) == [0, 2, 4]
     assert np.load(tmp_path / "chain_0.npy").shape == (5, 12, 2)
     assert np.load(tmp_path / "chain_1.npy").shape == (8, 12, 2)
+
+
+# ---- seed=None on a sharded chain: rank 0's draw is used everywhere; the group is joined from the env --------
+def _unseeded_worker(rank, world, port, out_dir):
+    # what torch.distributed.run exports; nothing here calls init_process_group: the drop-in joins by itself
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), GPEMU_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from bayesian_inference import mcmc
+    from gpemu.sampler import EnsembleSampler
+    assert not dist.is_initialized()
+    assert mcmc._rank_world() == (rank, world)            # joins the launcher's group on first use
+    assert dist.is_initialized() and dist.get_backend() == "gloo"
+    np.random.seed(1000 + rank)                           # the ranks' global numpy states differ (as under torchrun)
+    f = _gauss_logp(np.array([0.2, -0.1, 0.4]), np.diag([1.0, 0.5, 2.0]))
+    es = EnsembleSampler(14, 3, f, vectorize=True)        # seed=None
+    assert es.world_size == world
+    es.run_mcmc(np.random.default_rng(5).normal(size=(14, 3)), 12)
+    np.save(os.path.join(out_dir, f"chain_{rank}.npy"), es.get_chain())
+    np.save(os.path.join(out_dir, f"seed_{rank}.npy"), np.array([es._seed]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unseeded_sharded_sampler_uses_rank0_seed_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    from gpemu.sampler import EnsembleSampler
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_unseeded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    c0, c1 = np.load(tmp_path / "chain_0.npy"), np.load(tmp_path / "chain_1.npy")
+    s0, s1 = int(np.load(tmp_path / "seed_0.npy")[0]), int(np.load(tmp_path / "seed_1.npy")[0])
+    assert s0 == s1
+    np.testing.assert_array_equal(c0, c1)
+    f = _gauss_logp(np.array([0.2, -0.1, 0.4]), np.diag([1.0, 0.5, 2.0]))
+    es = EnsembleSampler(14, 3, f, vectorize=True, seed=s0, sharded=False)
+    es.run_mcmc(np.random.default_rng(5).normal(size=(14, 3)), 12)
+    np.testing.assert_array_equal(es.get_chain(), c0)     # the single-process chain for that seed
