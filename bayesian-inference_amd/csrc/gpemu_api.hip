@@ -291,6 +291,7 @@ int gpemu_model_destroy(gpemu_model *m) {
   hipFree(m->cunexpl); hipFree(m->yexp); hipFree(m->yerr); hipFree(m->lo); hipFree(m->hi);
   hipFree(m->G); hipFree(m->g0); hipFree(m->scal); hipFree(m->exact_scratch);
   hipFree(m->blk_start); hipFree(m->blk_of); hipFree(m->sched_items); hipFree(m->sched_cnt);
+  hipFree(m->sm_items); hipFree(m->sm_cnt);
   free_workspace(m->ws);
   for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
   if (m->stream) hipStreamDestroy(m->stream);

@@ -64,6 +64,10 @@ struct gpemu_model {
   int *sched_cnt = nullptr;    // [sched_workers]
   int sched_ncb = -1, sched_max_items = 0, sched_workers = 0;
   int64_t vsq_nrb = 0;         // row blocks of partial ||W k_*||^2 the triangular GEMM writes
+  // schedule of the small-batch triangular GEMM (k_trmm_small.hip) for the current number of 32-column blocks
+  void *sm_items = nullptr;
+  int *sm_cnt = nullptr;
+  int sm_ncb = -1, sm_max_items = 0, sm_workers = 0;
   int kernel_kind = 0;
   double nu = 0;
   int has_const = 0, has_noise = 0;
@@ -143,6 +147,7 @@ int ensure_workspace(gpemu_model *m, int64_t B);
 // dXq_padded is read, or -- with pa->enabled -- written (rows [0, round_up(B, 128))) by the kernel
 int launch_kstar(gpemu_model *m, int64_t B, double *dXq_padded, hipStream_t st, const ProposeArgs *pa = nullptr);
 int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st);
+int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st);   // B <= 128; GPEMU_ERR_UNSUPPORTED if the shape does not fit
 int launch_reduce_mean_var(gpemu_model *m, int64_t B, double *dmean, double *dvar, hipStream_t st);
 int launch_pad_queries(gpemu_model *m, int64_t B, const double *dX, hipStream_t st);
 int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq_padded, double *dout,

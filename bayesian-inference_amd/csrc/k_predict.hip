@@ -952,7 +952,12 @@ static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &
 int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
   Workspace &w = m->ws;
   static const int smallb_max = getenv("GPEMU_SMALLB_MAX") ? atoi(getenv("GPEMU_SMALLB_MAX")) : 128;
-  if (B <= smallb_max) {   // small batch: 32 x 64 items with the K range split inside the workgroup (at 129..256
+  static const bool old_smallb = getenv("GPEMU_TRMM_OLD_SMALLB") != nullptr;
+  if (B <= smallb_max && !old_smallb) {   // small batch: persistent 32 x 32 items, LDS-direct loads (k_trmm_small.hip)
+    const int rc = launch_trmm_vsq_small(m, B, st);
+    if (rc != GPEMU_ERR_UNSUPPORTED) return rc;
+  }
+  if (B <= smallb_max) {   // general small-batch form: 32 x 64 items with the K range split inside the workgroup (at 129..256
                            // rows the persistent kernel with every item halved is faster: 69 us vs 81 us)
     const int nrb32 = (int)(m->Npad / SB_TM);
     const int ncb64 = (int)(round_up(B, SB_TN) / SB_TN);

@@ -1,0 +1,305 @@
+// Triangular GEMM with fused column sum-of-squares for SMALL batches (B <= 128 columns per launch: one rank's
+// share of the proposing half on a 4- or 8-GPU run, ref: mcmc.py:77-85 replaced by walker sharding).
+//
+//   V[i][b] = sum_{j<=i} Wt[p][j][i] * KS[p][j][b],   out[b][p][rb] = sum_{i in 32-row block rb} V[i][b]^2
+//
+// With 64 columns and 10 PCs a rank has 0.64 GFLOP per launch: 2.5 MFLOP per CU, less than ONE 64 x 128 item of
+// the large-batch kernel.  What bounds a small batch is therefore (a) the longest item -- an item's time is its
+// FLOPs over one CU's rate whatever its shape -- and (b) the operand traffic, which grows as the tile shrinks.
+// Tile 32 rows x 32 columns: the longest item (K = 1024) is 2.1 MFLOP = 6.8 us of one CU at peak, W is read once
+// per 32-column block (second read from the XCD's L2, see the schedule) and K_*^T once per 32-row block.
+//
+// One 512-thread workgroup per CU, persistent over an LPT list of (PC, row block, column block) items.  The eight
+// waves split K, not the tile: wave w owns k-rows 4 w .. 4 w + 3 of every 32-deep k-tile and accumulates the whole
+// 32 x 32 tile (2 x 2 f64 MFMA tiles: four independent accumulator chains).  So no operand is shared between waves
+// and NOTHING goes through LDS in the k loop: a wave loads its MFMA fragments straight from L2 into registers --
+// one global_load_dwordx4 per operand and k-step, lane (q, lk) fetching W[k0 + lk][i0 + 2 q .. 2 q + 1]: the two
+// adjacent values feed the two row tiles, which therefore hold the even and the odd rows (the row order inside a
+// block is irrelevant to a column sum of squares), likewise the even / odd columns -- with a register ring four
+// k-tiles deep (eight gave the same time: the loop is not latency bound), no barrier, no LDS bandwidth.  (History, C3 at B = 64: LDS-staged 32 x 64 items 31 us; persistent
+// 32 x 32 items with LDS-direct loads 24.5 us -- the LDS-DMA path fills at most ~28 B/clk per CU, the whole budget
+// of this tile shape; this form: see DESIGN.md.)  The eight K-slices are summed through LDS in the item epilogue in
+// a fixed order, so results are deterministic.
+#include <algorithm>
+
+#include "internal.h"
+
+namespace gpemu {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int ST_M = 32, ST_N = 32, ST_K = 32;
+constexpr int ST_MAX_ITEMS = 64;
+
+struct SmallItem {
+  int p, rb, col0, pad;
+};
+
+// dbg: compile-time ablation switch (2: no operand loads, i.e. the bare MFMA stream); 0 in production.
+// ST_RING: k-tiles in flight per wave (two 16-byte loads each)
+template <int dbg, int ST_RING>
+__global__ __launch_bounds__(512, 2) void trmm_vsq_small_kernel(
+    const double *__restrict__ Wt, const double *__restrict__ KS, double *__restrict__ out,
+    const SmallItem *__restrict__ sched, const int *__restrict__ sched_cnt, int max_items, int64_t Npad,
+    int64_t Bcap, int k, int nrb, unsigned long long *__restrict__ stamps) {
+  __shared__ __attribute__((aligned(16))) double scratch[4 * 4 * 64 * 4];   // K-slice partial tiles, 32 KiB
+  __shared__ SmallItem s_items[ST_MAX_ITEMS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane & 15, lk = lane >> 4;
+
+  if (stamps && tid == 0) stamps[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long clk0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+  const int nitems = __builtin_amdgcn_readfirstlane(sched_cnt[blockIdx.x]);
+  if (tid < nitems) s_items[tid] = sched[(int64_t)blockIdx.x * max_items + tid];
+  __syncthreads();
+  if (nitems == 0) return;
+  // item fields as wave-uniform scalars: every branch on them is a scalar branch
+  auto item_p = [&](int i) { return __builtin_amdgcn_readfirstlane(s_items[i].p); };
+  auto item_rb = [&](int i) { return __builtin_amdgcn_readfirstlane(s_items[i].rb); };
+  auto item_col0 = [&](int i) { return __builtin_amdgcn_readfirstlane(s_items[i].col0); };
+  if (stamps && tid == 0) stamps[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime();
+
+  // ---- load cursor: ST_RING k-tiles ahead of the compute cursor, across item boundaries ----
+  const int64_t laneA = (int64_t)(4 * wave + lk) * Npad + 2 * q;     // this lane's k-row and row pair in a k-tile
+  const int64_t laneB = (int64_t)(4 * wave + lk) * Bcap + 2 * q;
+  const int64_t astep = (int64_t)ST_K * Npad, bstep = (int64_t)ST_K * Bcap;
+  int l_item = 0, l_t = 0, l_nt = 1;
+  const double *l_pa = Wt, *l_pb = KS;
+  auto l_open = [&]() {
+    const int ip = item_p(l_item), irb = item_rb(l_item), ic0 = item_col0(l_item);
+    l_nt = irb + 1;                                 // k-tiles of 32: rows j <= i0 + 31
+    l_pa = Wt + (int64_t)ip * Npad * Npad + (int64_t)irb * ST_M + laneA;
+    l_pb = KS + (int64_t)ip * Npad * Bcap + ic0 + laneB;
+    l_t = 0;
+  };
+  auto issue = [&](d2 &ra, d2 &rb) {
+    if (!(dbg & 2)) {
+      ra = *reinterpret_cast<const d2 *>(l_pa);
+      rb = *reinterpret_cast<const d2 *>(l_pb);
+    }
+    if (l_item < nitems) {
+      if (++l_t == l_nt) {
+        if (++l_item < nitems) l_open();            // else: stay on the last k-tile (harmless re-read)
+      } else {
+        l_pa += astep;
+        l_pb += bstep;
+      }
+    }
+  };
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  d2 ra[ST_RING], rb[ST_RING];
+#pragma unroll
+  for (int u = 0; u < ST_RING; ++u) ra[u] = rb[u] = d2{0.0, 0.0};
+  l_open();
+#pragma unroll
+  for (int u = 0; u < ST_RING; ++u) issue(ra[u], rb[u]);
+  if (stamps && tid == 0) stamps[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime();
+
+  // two accumulator sets, taken in turn by successive k-tiles: eight independent MFMA chains per wave
+  d4 acc[2][2], acc2[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = acc2[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+  int c_item = 0, c_t = 0;
+  int cur_p = item_p(0), cur_rb = item_rb(0), cur_col0 = item_col0(0);
+  int c_nt = cur_rb + 1;
+
+  for (;;) {
+    bool done = false;
+#pragma unroll
+    for (int u = 0; u < ST_RING; ++u) {
+      const d2 av = ra[u], bv = rb[u];
+      issue(ra[u], rb[u]);                          // the slot's next occupant: k-tile + ST_RING
+      if (!(dbg & 1)) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y) {
+            if (u & 1) acc2[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc2[x][y], 0, 0, 0);
+            else acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
+          }
+      }
+      if (++c_t == c_nt) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y) {
+            acc[x][y] = acc[x][y] + acc2[x][y];
+            acc2[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+          }
+        // Item finished: sum the eight K-slices (fixed order: deterministic) and reduce V^2 over the 32 rows.
+        // Slot of a value: [wave][tile x + 2 y][lane][reg]  (8 KiB per wave).  Tile (x, y), lane (lr, lk'), register r
+        // is row i0 + 2 (lk' + 4 r) + x, column col0 + 2 lr + y.
+        lds_barrier();                              // the previous item's scratch reads are over
+        if (wave >= 4) {
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+              *reinterpret_cast<d4 *>(&scratch[(((wave - 4) * 4 + x + 2 * y) * 64 + lane) * 4]) = acc[x][y];
+        }
+        lds_barrier();
+        if (wave < 4) {
+#pragma unroll
+          for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+              d4 *slot = reinterpret_cast<d4 *>(&scratch[((wave * 4 + x + 2 * y) * 64 + lane) * 4]);
+              *slot = acc[x][y] + *slot;            // slices w and w + 4
+            }
+        }
+        lds_barrier();
+        {
+          // all 512 threads: wave w takes columns 4 w .. 4 w + 3, lane = (16 row groups) x (4 columns); a row group
+          // is (row tile x, accumulator lane group lk', register pair h)
+          const int col = 4 * wave + (lane & 3), g = lane >> 2;
+          const int x = g >> 3, lkp = (g >> 1) & 3, h = g & 1;
+          const int y = col & 1, lrp = col >> 1;
+          const int off = ((x + 2 * y) * 64 + lkp * 16 + lrp) * 4 + 2 * h;
+          d2 v = *reinterpret_cast<const d2 *>(&scratch[off]);
+#pragma unroll
+          for (int w2 = 1; w2 < 4; ++w2) v = v + *reinterpret_cast<const d2 *>(&scratch[w2 * 1024 + off]);
+          double sq = fma(v[0], v[0], v[1] * v[1]);
+          sq += __shfl_xor(sq, 4);
+          sq += __shfl_xor(sq, 8);
+          sq += __shfl_xor(sq, 16);
+          sq += __shfl_xor(sq, 32);
+          if (lane < 4) out[(((int64_t)cur_col0 + col) * k + cur_p) * nrb + cur_rb] = sq;
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+          for (int y = 0; y < 2; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+        if (stamps && tid == 0 && c_item < 12) stamps[blockIdx.x * 16 + 3 + c_item] = __builtin_amdgcn_s_memrealtime();
+        if (++c_item == nitems) { done = true; break; }
+        cur_p = item_p(c_item); cur_rb = item_rb(c_item); cur_col0 = item_col0(c_item);
+        c_nt = cur_rb + 1;
+        c_t = 0;
+      }
+    }
+    if (done) break;
+  }
+  if (stamps && tid == 0) stamps[blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime() - clk0;
+}
+
+// host side: LPT schedule, XCD-aware.  Workgroups are dispatched round-robin over the 8 XCDs (worker w on XCD
+// w % 8, each with its own 4 MiB L2).  The items of one (PC, column block) group read the same K_*^T block and
+// the column blocks of one (PC, row block) the same W strip, so whole groups are dealt to XCDs in (PC, column
+// block) order -- adjacent column blocks of a PC land on the same XCD, equally long, and start together -- and
+// the groups left over when the count is not a multiple of 8 are spread over every XCD.
+static void build_small_schedule(const gpemu_model *m, int ncb, std::vector<SmallItem> &flat, std::vector<int> &cnt,
+                                 int &max_items, int &nworkers) {
+  const int nrb = (int)(m->Npad / ST_M), k = (int)m->k;
+  struct It { double cost; SmallItem it; int group; };
+  std::vector<It> items;
+  const double ov = 1.5;             // per-item epilogue, in k-tiles of 32
+  for (int rb = 0; rb < nrb; ++rb) {
+    const double nt = (double)(rb + 1);
+    for (int p = 0; p < k; ++p)
+      for (int cb = 0; cb < ncb; ++cb) items.push_back({nt + ov, SmallItem{p, rb, cb * ST_N, 0}, p * ncb + cb});
+  }
+  std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.cost > b.cost; });
+  nworkers = m->num_cu < (int)items.size() ? m->num_cu : (int)items.size();
+  std::vector<std::vector<SmallItem>> per(nworkers);
+  std::vector<double> load(nworkers, 0.0);
+  const int nxcd = 8, ngroups = k * ncb;
+  static const bool xcd_aware = getenv("GPEMU_TRMM_NO_XCD") == nullptr;
+  const bool use_xcd = xcd_aware && nworkers == m->num_cu && nworkers % nxcd == 0 && ngroups >= nxcd;
+  const int whole = use_xcd ? (ngroups / nxcd) * nxcd : 0;     // groups [0, whole) live on one XCD each
+  const int gper = use_xcd ? ngroups / nxcd : 1;
+  for (const It &x : items) {
+    int best;
+    if (x.group < whole) {
+      const int xcd = x.group / gper;
+      best = xcd;
+      for (int w = xcd; w < nworkers; w += nxcd)
+        if (load[w] < load[best]) best = w;
+    } else {
+      best = 0;
+      for (int w = 1; w < nworkers; ++w)
+        if (load[w] < load[best]) best = w;
+    }
+    per[best].push_back(x.it);
+    load[best] += x.cost;
+  }
+  max_items = 1;
+  for (auto &v : per) max_items = v.size() > (size_t)max_items ? (int)v.size() : max_items;
+  flat.assign((size_t)nworkers * max_items, SmallItem{0, 0, 0, 0});
+  cnt.assign(nworkers, 0);
+  for (int w = 0; w < nworkers; ++w) {
+    cnt[w] = (int)per[w].size();
+    for (size_t i = 0; i < per[w].size(); ++i) flat[(size_t)w * max_items + i] = per[w][i];
+  }
+}
+
+// returns GPEMU_ERR_UNSUPPORTED (without setting an error) when the shape needs more items per worker than the
+// kernel holds; the caller then uses the general small-batch kernel
+int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st) {
+  Workspace &w = m->ws;
+  const int nrb = (int)(m->Npad / ST_M);
+  const int ncb = (int)(round_up(B, ST_N) / ST_N);
+  if (m->sm_ncb != ncb) {
+    std::vector<SmallItem> flat;
+    std::vector<int> cnt;
+    int max_items = 0, nworkers = 0;
+    build_small_schedule(m, ncb, flat, cnt, max_items, nworkers);
+    if (max_items > ST_MAX_ITEMS) return GPEMU_ERR_UNSUPPORTED;
+    GP_HIP(hipStreamSynchronize(st));
+    (void)hipFree(m->sm_items);
+    (void)hipFree(m->sm_cnt);
+    m->sm_items = nullptr; m->sm_cnt = nullptr; m->sm_ncb = -1;
+    GP_HIP(hipMalloc(&m->sm_items, sizeof(SmallItem) * flat.size()));
+    GP_HIP(hipMalloc((void **)&m->sm_cnt, sizeof(int) * cnt.size()));
+    GP_HIP(hipMemcpy(m->sm_items, flat.data(), sizeof(SmallItem) * flat.size(), hipMemcpyHostToDevice));
+    GP_HIP(hipMemcpy(m->sm_cnt, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice));
+    m->sm_ncb = ncb; m->sm_max_items = max_items; m->sm_workers = nworkers;
+  }
+  w.cur_nrb = nrb;
+  static const int dbg = getenv("GPEMU_SMALL_DBG") ? atoi(getenv("GPEMU_SMALL_DBG")) : 0;   // ablation switches
+  static const char *stamp_path = getenv("GPEMU_SMALL_STAMPS");                             // per-worker time stamps
+  static unsigned long long *dstamps = nullptr;
+  static int stamp_calls = 0;
+  if (stamp_path && !dstamps) {
+    GP_HIP(hipMalloc((void **)&dstamps, sizeof(unsigned long long) * 16 * 1024));
+    GP_HIP(hipMemset(dstamps, 0, sizeof(unsigned long long) * 16 * 1024));
+  }
+  const int pe0 = prof_mark(m, st);
+#define GP_LAUNCH_SMALL(D)                                                                                          \
+  hipLaunchKernelGGL((trmm_vsq_small_kernel<D, 4>), dim3((unsigned)m->sm_workers), dim3(512), 0, st, m->Wt, w.KS, w.vsq_part, \
+                     (const SmallItem *)m->sm_items, m->sm_cnt, m->sm_max_items, m->Npad, w.Bcap, (int)m->k, nrb, dstamps)
+  switch (dbg) {
+    case 2: GP_LAUNCH_SMALL(2); break;
+    default: GP_LAUNCH_SMALL(0); break;
+  }
+#undef GP_LAUNCH_SMALL
+  GP_HIP(hipGetLastError());
+  prof_pair(m, 0, pe0, prof_mark(m, st));
+  if (stamp_path && ++stamp_calls == 500) {
+    GP_HIP(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h(16 * 1024);
+    GP_HIP(hipMemcpy(h.data(), dstamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    std::vector<int> cnt(m->sm_workers);
+    GP_HIP(hipMemcpy(cnt.data(), m->sm_cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost));
+    FILE *f = fopen(stamp_path, "w");
+    if (f) {
+      unsigned long long t0 = ~0ull;
+      for (int wk = 0; wk < m->sm_workers; ++wk) t0 = std::min(t0, h[wk * 16]);
+      for (int wk = 0; wk < m->sm_workers; ++wk) {
+        fprintf(f, "%d %d", wk, cnt[wk]);
+        for (int i = 0; i < 3 + std::min(cnt[wk], 12); ++i) fprintf(f, " %.2f", (double)(h[wk * 16 + i] - t0) / 100.0);
+        fprintf(f, " cycles %llu", h[wk * 16 + 15]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
+  return GPEMU_OK;
+}
+
+}  // namespace gpemu
