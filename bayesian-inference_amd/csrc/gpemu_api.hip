@@ -41,7 +41,7 @@ static int upload(double *dst, const double *src, int64_t n, hipStream_t st) {
 }
 
 static void free_workspace(Workspace &w) {
-  hipFree(w.Xq); hipFree(w.KS); hipFree(w.mean_part); hipFree(w.vsq_part);
+  hipFree(w.Xq); hipFree(w.KS); hipFree(w.mean_part); hipFree(w.mean_part2); hipFree(w.vsq_part);
   hipFree(w.mean); hipFree(w.var); hipFree(w.logp);
   w = Workspace();
 }
@@ -56,6 +56,7 @@ int ensure_workspace(gpemu_model *m, int64_t B) {
   GP_TRY(dev_alloc(&w.Xq, need * DPAD));
   GP_TRY(dev_alloc(&w.KS, k * m->Npad * need));
   GP_TRY(dev_alloc(&w.mean_part, k * (m->Npad / 32) * need));   // sized for the 32-row small-batch form
+  GP_TRY(dev_alloc(&w.mean_part2, k * (m->Npad / 32) * need));
   GP_TRY(dev_alloc(&w.vsq_part, k * (m->Npad / 32) * need));   // sized for the 32-row small-batch form
   GP_TRY(dev_alloc(&w.mean, need * k));
   GP_TRY(dev_alloc(&w.var, need * k));

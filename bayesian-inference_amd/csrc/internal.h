@@ -44,6 +44,7 @@ struct Workspace {
   double *Xq = nullptr;        // [Bcap][DPAD]   query points (padded with 0)
   double *KS = nullptr;        // [k][Npad][Bcap] cross-kernel K_*^T per PC
   double *mean_part = nullptr; // [Bcap][k][nchunk] partial K_* . alpha per 128- (or 32-) row chunk
+  double *mean_part2 = nullptr; // second copy: the fused sampler run reads one half-step's while the next is written
   double *vsq_part = nullptr;  // [Bcap][k][nrb]    partial ||W k_*||^2 per 64- (or 32-) row block
   double *mean = nullptr;      // [Bcap][k]
   double *var = nullptr;       // [Bcap][k]

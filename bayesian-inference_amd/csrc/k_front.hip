@@ -1,0 +1,639 @@
+// Fused stretch-move run: TWO launches per half-step instead of four plus a collective.
+//
+// Replaces, for a single emulation group with k <= 16 PCs, the per-half-step chain
+//     kstar (+proposal) -> triangular GEMM -> likelihood -> [all-gather] -> accept
+// of k_sampler.hip (ref: mcmc.py:77-107 -> emcee RedBlueMove / StretchMove, the pool.map over walkers) by
+//     front kernel  ->  triangular GEMM
+// where ONE front launch does, for the half-step BEFORE the one it opens:
+//     (A) the low-rank log-likelihood of this rank's share of that half's proposals (a few workgroups, first);
+//     (B) the exchange: each new log-probability is stored -- one 8-byte system-scope store per value and rank --
+//         straight into every rank's gather buffer (peer memory over xGMI; the own buffer on one GPU).  A slot holds a
+//         NaN with a reserved payload until its value arrives, so the value is its own flag: no fence, no counter;
+//     (C) the accept / reject, recomputed by whoever needs a walker's position (the workgroups of the next half's
+//         cross-kernel evaluation, for the two walkers of each of their proposals) from the previous half's draws;
+//         a few extra workgroups write the accepted ensemble, the counters and the chain row into the OTHER half of
+//         the double-buffered state;
+// and then, for the half-step it opens, the stretch proposal and the cross-kernel K_*^T with its partial means
+// (exactly kstar_kernel's arithmetic).  Every rank draws the same randomness (Philox, k_sampler.hip) and applies the
+// same decisions, so the chain equals the single-GPU chain bit for bit.
+#include <algorithm>
+
+#include "internal.h"
+#include "loglik_dev.h"
+#include "predict_dev.h"
+#include "sampler_internal.h"
+
+namespace gpemu {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+struct FrontArgs {
+  // GP model: cross-kernel of the half being opened
+  const double *Xs, *inv_ls, *constv, *alpha;
+  double *KS, *mean_part_next;
+  int64_t N, Npad, Bcap;
+  int has_const, kind, k, d, W;
+  int nchunk, ncolblk;                 // cross-kernel workgroups: (column block, row chunk, PC), nkstar of them
+  int nkstar, nks;                     // nks = max(nkstar, likelihood workgroups): the state workgroups follow
+  // the half being opened: this rank's share of its proposals (pointers already offset to the share)
+  int have_next, next_cnt;
+  const int *idx_next, *partner_next;
+  const double *zz_next;
+  double *Xq_next;
+  // the half before: likelihood of this rank's share, exchange, accept
+  int have_prev, hp, prev_n, prev_lo, prev_cnt, n_llwg;
+  const int *inds_prev, *pos_prev, *partner_prev;   // [W], [W], [prev_n]
+  const double *zz_prev, *fac_prev, *logu_prev;     // [prev_n]
+  const double *Xq_prev, *mean_part_prev, *vsq_part, *kdiag, *G, *g0, *scal, *lo, *hi;
+  int nchunk_prev, nrb_prev, nblk;
+  const double *gath;                  // this rank's gather slot of that half: [prev_n]
+  double *const *peers;                // every rank's gather buffer
+  int world;
+  int64_t slot_off;                    // offset of that half's slot inside a gather buffer
+  // ensemble state (double buffered) and bookkeeping
+  const double *Xcur, *lpcur;
+  double *Xnext, *lpnext;
+  long long *naccept;
+  int *flags;                          // [0] NaN log-probabilities, [1] exchange time-outs
+  double *chain_row, *lp_row;          // row of the step the accept completes, or null
+  double *reset;                       // gather entries handed back to "not arrived"
+  int reset_lo, reset_cnt;
+  unsigned long long *stamps;          // diagnostic: per-workgroup time stamps (GPEMU_FRONT_STAMPS), else null
+};
+
+constexpr int GATHER_SPIN_LIMIT = 1 << 21;   // polls before an exchange is declared lost (seconds)
+
+__device__ __forceinline__ double gather_wait(const double *entry, int *flags) {
+  const unsigned long long *p = reinterpret_cast<const unsigned long long *>(entry);
+  unsigned long long bits;
+  int spins = 0;
+  for (;;) {
+    bits = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (bits != GATHER_EMPTY) break;
+    if (++spins > GATHER_SPIN_LIMIT) {        // every wave reaches this exit: the grid always drains
+      atomicAdd(flags + 1, 1);
+      bits = 0x7FF8000000000000ull;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return __longlong_as_double((long long)bits);
+}
+
+// Position (and log-probability) of walker x AFTER the previous half's accept / reject (emcee moves/red_blue.py):
+// unchanged unless x proposed in that half and its proposal was accepted.
+__device__ __forceinline__ void state_after_prev(const FrontArgs &fa, int x, double (&px)[DPAD], double &lp, bool &acc,
+                                                 double &nlp, bool &in_prev) {
+  in_prev = fa.have_prev && fa.inds_prev[x] == fa.hp;
+  double z = 1.0;
+  int pj = x;
+  acc = false;
+  nlp = 0.0;
+  const double oldlp = fa.lpcur[x];
+  if (in_prev) {
+    const int i = fa.pos_prev[x];
+    pj = fa.partner_prev[i];
+    z = fa.zz_prev[i];
+    const double fc = fa.fac_prev[i], lu = fa.logu_prev[i];
+    nlp = gather_wait(fa.gath + i, fa.flags);
+    acc = (fc + nlp - oldlp) > lu;
+  }
+#pragma unroll
+  for (int dd = 0; dd < DPAD; ++dd) {
+    const double sw = fa.Xcur[(int64_t)x * DPAD + dd];
+    double v = sw;
+    if (acc && dd < fa.d) {
+      const double cj = fa.Xcur[(int64_t)pj * DPAD + dd];
+      v = cj - (cj - sw) * z;                 // emcee moves/stretch.py get_proposal
+    }
+    px[dd] = v;
+  }
+  lp = acc ? nlp : oldlp;
+}
+
+template <int KMAX>
+__device__ __forceinline__ double front_loglik(const FrontArgs &fa, int64_t b, int lane) {
+  double gpre[KMAX];
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q) gpre[q] = (q < fa.k && lane < fa.k) ? fa.G[q * fa.k + lane] : 0.0;
+  const double gl_pre = (lane < fa.k) ? fa.g0[lane] : 0.0;
+  const double sc0_pre = fa.scal[0], sc1_pre = fa.scal[1];
+  bool in = true;
+  if (lane < fa.d) in = (fa.Xq_prev[b * DPAD + lane] > fa.lo[lane]) && (fa.Xq_prev[b * DPAD + lane] < fa.hi[lane]);
+  const bool inside = __all(in);
+  double mu, sd;
+  walker_mean_sd<16>(fa.mean_part_prev, fa.vsq_part, fa.kdiag, nullptr, nullptr, b, fa.Bcap, fa.k, fa.nchunk_prev,
+                     fa.nrb_prev, lane, mu, sd);
+  return walker_loglik_lowrank<KMAX>(inside, mu, sd, gpre, gl_pre, sc0_pre, sc1_pre, fa.G, fa.g0, fa.scal, fa.k,
+                                     fa.nblk, lane);
+}
+
+// rows of K_*^T for this wave's RPW training rows and the workgroup's 64 query columns (kstar_kernel's loop)
+template <int KIND, int RPW>
+__device__ __forceinline__ double front_kstar_rows(const double (&xq)[DPAD], const double *xs, const double *al,
+                                                   const double *s_tab, double c, int64_t jbase, int64_t N,
+                                                   double *ks, int64_t Bcap) {
+  double macc = 0.0;
+#pragma unroll 4
+  for (int jj = 0; jj < RPW; ++jj) {
+    double r2 = 0.0;
+#pragma unroll
+    for (int dd = 0; dd < DPAD; ++dd) {
+      double df = xq[dd] - xs[jj * DPAD + dd];
+      r2 = fma(df, df, r2);
+    }
+    double v = base_kernel_fast<KIND>(r2, s_tab) + c;
+    if (jbase + jj >= N) v = 0.0;
+    ks[(int64_t)jj * Bcap] = v;
+    macc = fma(al[jj], v, macc);
+  }
+  return macc;
+}
+
+template <int RPW>
+__global__ __launch_bounds__(256) void front_kernel(FrontArgs fa) {
+  __shared__ double s_tab[32];
+  __shared__ __attribute__((aligned(16))) double s_xs[4 * RPW * DPAD];
+  __shared__ double s_al[4 * RPW];
+  __shared__ double s_eff[2][64][DPAD];
+  __shared__ double red[4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = blockIdx.x;
+  if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+
+  if (g >= fa.nks) {
+    // ---- state workgroups: the ensemble after the previous half, counters, chain row, gather hand-back ----
+    const int x = (g - fa.nks) * 256 + threadIdx.x;
+    if (x < fa.W) {
+      double px[DPAD], lp, nlp;
+      bool acc, in_prev;
+      state_after_prev(fa, x, px, lp, acc, nlp, in_prev);
+#pragma unroll
+      for (int dd = 0; dd < DPAD; ++dd) fa.Xnext[(int64_t)x * DPAD + dd] = px[dd];
+      fa.lpnext[x] = lp;
+      if (in_prev && nlp != nlp) atomicAdd(fa.flags, 1);       // emcee raises on a NaN log-probability
+      if (acc) fa.naccept[x] += 1;
+      if (fa.chain_row) {
+        for (int dd = 0; dd < fa.d; ++dd) fa.chain_row[(int64_t)x * fa.d + dd] = px[dd];
+        fa.lp_row[x] = lp;
+      }
+    }
+    if (x < fa.reset_cnt)
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(fa.reset + fa.reset_lo + x), GATHER_EMPTY,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    return;
+  }
+
+  // ---- cross-kernel workgroups ----
+  const int cb = g % fa.ncolblk;
+  const int rest = g / fa.ncolblk;
+  const int chunk = rest % fa.nchunk;
+  const int p = rest / fa.nchunk;
+  const int64_t b = (int64_t)cb * 64 + lane;
+  const int64_t jb0 = (int64_t)chunk * (4 * RPW);
+
+  // the workgroup's training rows: requested first, their latency overlaps everything below
+  constexpr int NPAIR = 4 * RPW * DPAD / 2;
+  constexpr int PER_T = (NPAIR + 255) / 256;
+  d2 stage[PER_T];
+  double al_stage = 0.0;
+  const bool does_kstar = fa.have_next && g < fa.nkstar;
+  if (does_kstar) {
+    const d2 *xsrc = reinterpret_cast<const d2 *>(fa.Xs + ((int64_t)p * fa.Npad + jb0) * DPAD);
+#pragma unroll
+    for (int t = 0; t < PER_T; ++t) {
+      const int idx = threadIdx.x + 256 * t;
+      stage[t] = (idx < NPAIR) ? xsrc[idx] : d2{0.0, 0.0};
+    }
+    if (threadIdx.x < 4 * RPW) al_stage = fa.alpha[(int64_t)p * fa.Npad + jb0 + threadIdx.x];
+  }
+
+  // (A) + (B): likelihood of the previous half's proposals of this rank (first workgroups), stored to every rank
+  if (fa.have_prev && g < fa.n_llwg) {
+    const int i = g * 4 + wave;
+    if (i < fa.prev_cnt) {
+      double total;
+      if (fa.k <= 4) total = front_loglik<4>(fa, i, lane);
+      else if (fa.k <= 8) total = front_loglik<8>(fa, i, lane);
+      else if (fa.k <= 12) total = front_loglik<12>(fa, i, lane);
+      else total = front_loglik<16>(fa, i, lane);
+      if (lane < fa.world)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(fa.peers[lane] + fa.slot_off + fa.prev_lo + i),
+                           (unsigned long long)__double_as_longlong(total), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+  if (!does_kstar) return;
+
+  // (C) the two walkers of this column's proposal, as they stand after the previous half; wave 0: the proposing
+  // walker, wave 1: its partner of the complementary set
+  const bool live = b < fa.next_cnt;
+  if (wave < 2) {
+    double px[DPAD];
+#pragma unroll
+    for (int dd = 0; dd < DPAD; ++dd) px[dd] = 0.0;
+    if (live) {
+      const int x = (wave == 0) ? fa.idx_next[b] : fa.partner_next[b];
+      double lp, nlp;
+      bool acc, in_prev;
+      state_after_prev(fa, x, px, lp, acc, nlp, in_prev);
+    }
+#pragma unroll
+    for (int dd = 0; dd < DPAD; ++dd) s_eff[wave][lane][dd] = px[dd];
+  }
+  if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x < 32) s_tab[threadIdx.x] = c_exp2_32[threadIdx.x];
+#pragma unroll
+  for (int t = 0; t < PER_T; ++t) {
+    const int idx = threadIdx.x + 256 * t;
+    if (idx < NPAIR) reinterpret_cast<d2 *>(s_xs)[idx] = stage[t];
+  }
+  if (threadIdx.x < 4 * RPW) s_al[threadIdx.x] = al_stage;
+  __syncthreads();
+  if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+
+  // stretch proposal q = c - (c - s) z  (emcee moves/stretch.py), stored once per column
+  double xq[DPAD];
+  {
+    const double z = live ? fa.zz_next[b] : 1.0;
+#pragma unroll
+    for (int dd = 0; dd < DPAD; ++dd) {
+      double v = 0.0;
+      if (live && dd < fa.d) {
+        const double cj = s_eff[1][lane][dd], sw = s_eff[0][lane][dd];
+        v = cj - (cj - sw) * z;
+      }
+      xq[dd] = v;
+    }
+    if (chunk == 0 && p == 0 && wave == 0) {
+#pragma unroll
+      for (int dd = 0; dd < DPAD; ++dd) fa.Xq_next[b * DPAD + dd] = xq[dd];
+    }
+#pragma unroll
+    for (int dd = 0; dd < DPAD; ++dd) xq[dd] = xq[dd] * fa.inv_ls[p * DPAD + dd];
+  }
+  const double c = fa.has_const ? fa.constv[p] : 0.0;
+
+  const int64_t jbase = jb0 + wave * RPW;
+  const double *xs = s_xs + wave * RPW * DPAD;
+  const double *al = s_al + wave * RPW;
+  double *ks = fa.KS + ((int64_t)p * fa.Npad + jbase) * fa.Bcap + b;
+  double macc;
+  switch (fa.kind) {
+    case 0: macc = front_kstar_rows<0, RPW>(xq, xs, al, s_tab, c, jbase, fa.N, ks, fa.Bcap); break;
+    case 1: macc = front_kstar_rows<1, RPW>(xq, xs, al, s_tab, c, jbase, fa.N, ks, fa.Bcap); break;
+    case 2: macc = front_kstar_rows<2, RPW>(xq, xs, al, s_tab, c, jbase, fa.N, ks, fa.Bcap); break;
+    default: macc = front_kstar_rows<3, RPW>(xq, xs, al, s_tab, c, jbase, fa.N, ks, fa.Bcap); break;
+  }
+  red[wave][lane] = macc;
+  __syncthreads();
+  if (wave == 0) {
+    const double sum = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    fa.mean_part_next[(b * fa.k + p) * fa.nchunk + chunk] = sum;
+  }
+  if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+}
+
+__global__ void gather_fill_kernel(double *p, int64_t n, unsigned long long bits) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) reinterpret_cast<unsigned long long *>(p)[i] = bits;
+}
+
+// ---- host side --------------------------------------------------------------------------------------------
+static int ensure_gather(gpemu_sampler *s) {
+  if (s->gather) return GPEMU_OK;
+  const size_t bytes = sizeof(double) * GATHER_SLOTS * (size_t)s->ns[0];
+  // uncached device memory: the values are written by other workgroups / other GPUs and polled here
+  hipError_t e = hipExtMallocWithFlags((void **)&s->gather, bytes, hipDeviceMallocUncached);
+  s->gather_uncached = (e == hipSuccess);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    GP_HIP(hipMalloc((void **)&s->gather, bytes));
+  }
+  const int64_t n = GATHER_SLOTS * s->ns[0];
+  hipLaunchKernelGGL(gather_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->gather, n,
+                     GATHER_EMPTY);
+  GP_HIP(hipStreamSynchronize(s->stream));
+  return GPEMU_OK;
+}
+
+static int set_local_peer(gpemu_sampler *s) {
+  if (s->peers && s->peer_world == 1) return GPEMU_OK;
+  GP_HIP(hipStreamSynchronize(s->stream));
+  for (void *q : s->peer_opened) (void)hipIpcCloseMemHandle(q);
+  s->peer_opened.clear();
+  (void)hipFree(s->peers);
+  s->peers = nullptr;
+  GP_HIP(hipMalloc((void **)&s->peers, sizeof(double *)));
+  GP_HIP(hipMemcpy(s->peers, &s->gather, sizeof(double *), hipMemcpyHostToDevice));
+  s->peer_world = 1;
+  s->peer_rank = 0;
+  return GPEMU_OK;
+}
+
+void front_release(gpemu_sampler *s) {
+  for (void *q : s->peer_opened) (void)hipIpcCloseMemHandle(q);
+  s->peer_opened.clear();
+  (void)hipFree(s->peers);
+  (void)hipFree(s->gather);
+  s->peers = nullptr;
+  s->gather = nullptr;
+  s->peer_world = 0;
+}
+
+bool front_eligible(const gpemu_sampler *s) {
+  static const bool off = getenv("GPEMU_NO_FUSED") != nullptr;
+  if (off || s->groups.size() != 1) return false;
+  const gpemu_model *m = s->groups[0];
+  if (m->k > 16 || s->W > 2048) return false;       // every workgroup of a launch must be resident (they wait on each other)
+  return true;
+}
+
+struct Pending {                    // the half whose likelihood / accept is still to be done
+  bool have = false;
+  int h = 0;
+  size_t slot = 0;                  // randomness ring slot of its step
+  int64_t lo = 0, cnt = 0;
+  int nchunk = 0, nrb = 0;
+  int parity = 0;                   // which q2 / mean_part buffer its proposals and partial means are in
+};
+
+static void share_of(const gpemu_sampler *s, int h, int world, int rank, int64_t &lo, int64_t &cnt) {
+  const int64_t share = (s->ns[h] + world - 1) / world;        // == sampler.shard_bounds()
+  lo = std::min<int64_t>((int64_t)rank * share, s->ns[h]);
+  cnt = std::min<int64_t>(share, s->ns[h] - lo);
+}
+
+static int launch_front(gpemu_sampler *s, const Pending &pv, bool have_next, int h, int64_t lo, int64_t cnt,
+                        int world, bool emulate, int store_row, Pending &out) {
+  gpemu_model *m = s->groups[0];
+  Workspace &w = m->ws;
+  hipStream_t st = s->stream;
+  const int64_t W = s->W;
+  FrontArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  const int parity = (int)(s->front_count & 1);
+  fa.Xs = m->Xs; fa.inv_ls = m->inv_ls; fa.constv = m->constv; fa.alpha = m->alpha;
+  fa.KS = w.KS;
+  fa.mean_part_next = parity ? w.mean_part2 : w.mean_part;
+  fa.N = m->N; fa.Npad = m->Npad; fa.Bcap = w.Bcap;
+  fa.has_const = m->has_const; fa.k = (int)m->k; fa.d = (int)s->d; fa.W = (int)W;
+  fa.kind = 0;
+  if (m->kernel_kind == GPEMU_KERNEL_MATERN) fa.kind = (m->nu == 0.5) ? 1 : (m->nu == 1.5 ? 2 : 3);
+  const bool small = cnt <= 256;
+  const int rows_per_wg = small ? 32 : 128;
+  fa.nchunk = (int)(m->Npad / rows_per_wg);
+  const int64_t ncols = (cnt <= 64) ? 64 : round_up(cnt, TILE);
+  fa.ncolblk = (int)(ncols / 64);
+  fa.have_next = have_next ? 1 : 0;
+  if (have_next) {
+    const size_t o2 = s->step_counter % RNG_RING * 2 * W;
+    fa.next_cnt = (int)cnt;
+    fa.idx_next = s->idx + o2 + h * W + lo;
+    fa.partner_next = s->rint + o2 + h * W + lo;
+    fa.zz_next = s->zz + o2 + h * W + lo;
+    fa.Xq_next = s->q2 + (size_t)parity * s->qcap * DPAD;
+  }
+  fa.have_prev = pv.have ? 1 : 0;
+  if (pv.have) {
+    const size_t o2 = pv.slot * 2 * W;
+    fa.hp = pv.h;
+    fa.prev_n = (int)s->ns[pv.h];
+    fa.prev_lo = (int)pv.lo; fa.prev_cnt = (int)pv.cnt;
+    fa.n_llwg = (int)((pv.cnt + 3) / 4);
+    fa.inds_prev = s->inds + pv.slot * W;
+    fa.pos_prev = s->pos + pv.slot * W;
+    fa.partner_prev = s->rint + o2 + pv.h * W;
+    fa.zz_prev = s->zz + o2 + pv.h * W;
+    fa.fac_prev = s->fac + o2 + pv.h * W;
+    fa.logu_prev = s->logu + o2 + pv.h * W;
+    fa.Xq_prev = s->q2 + (size_t)pv.parity * s->qcap * DPAD;
+    fa.mean_part_prev = pv.parity ? w.mean_part2 : w.mean_part;
+    fa.vsq_part = w.vsq_part; fa.kdiag = m->kdiag; fa.G = m->G; fa.g0 = m->g0; fa.scal = m->scal;
+    fa.lo = m->lo; fa.hi = m->hi;
+    fa.nchunk_prev = pv.nchunk; fa.nrb_prev = pv.nrb; fa.nblk = (int)m->nblk;
+    // the previous half's values live in slot (front_count - 1) % GATHER_SLOTS
+    const int slot = (int)((s->front_count + GATHER_SLOTS - 1) % GATHER_SLOTS);
+    fa.slot_off = (int64_t)slot * s->ns[0];
+    fa.gath = s->gather + fa.slot_off;
+    fa.peers = s->peers;
+    fa.world = emulate ? 1 : world;
+  }
+  fa.nkstar = have_next ? fa.ncolblk * fa.nchunk * fa.k : 0;
+  fa.nks = std::max(fa.nkstar, fa.n_llwg);
+  fa.Xcur = s->Xbuf + (size_t)s->cur * W * DPAD;
+  fa.lpcur = s->lpbuf + (size_t)s->cur * W;
+  fa.Xnext = s->Xbuf + (size_t)(s->cur ^ 1) * W * DPAD;
+  fa.lpnext = s->lpbuf + (size_t)(s->cur ^ 1) * W;
+  fa.naccept = s->naccept; fa.flags = s->flags;
+  if (store_row >= 0) {
+    fa.chain_row = s->chain + (size_t)store_row * W * s->d;
+    fa.lp_row = s->lpchain + (size_t)store_row * W;
+  }
+  // hand back the slot the launch after next will receive into: the whole slot, or -- when one GPU stands in for
+  // rank 0 of a larger job -- only the share somebody writes (the rest stays -inf: rejected)
+  {
+    const int rslot = (int)((s->front_count + 1) % GATHER_SLOTS);
+    fa.reset = s->gather + (int64_t)rslot * s->ns[0];
+    fa.reset_lo = 0;
+    fa.reset_cnt = (int)s->ns[0];
+    if (emulate) {
+      int64_t l0, c0, l1, c1;
+      share_of(s, 0, world, 0, l0, c0);
+      share_of(s, 1, world, 0, l1, c1);
+      fa.reset_cnt = (int)std::max(c0, c1);
+    }
+  }
+  const int nstate = (int)((std::max<int64_t>(W, fa.reset_cnt) + 255) / 256);
+  const dim3 grid((unsigned)(fa.nks + nstate)), block(256);
+  static const char *stamp_path = getenv("GPEMU_FRONT_STAMPS");
+  static unsigned long long *dstamps = nullptr;
+  static int stamp_calls = 0;
+  if (stamp_path && !dstamps) {
+    GP_HIP(hipMalloc((void **)&dstamps, sizeof(unsigned long long) * 8 * 4096));
+    GP_HIP(hipMemset(dstamps, 0, sizeof(unsigned long long) * 8 * 4096));
+  }
+  fa.stamps = (stamp_path && grid.x <= 4096) ? dstamps : nullptr;
+  const int pe0 = prof_mark(m, st);
+  if (small) hipLaunchKernelGGL((front_kernel<8>), grid, block, 0, st, fa);
+  else hipLaunchKernelGGL((front_kernel<32>), grid, block, 0, st, fa);
+  GP_HIP(hipGetLastError());
+  prof_pair(m, 1, pe0, prof_mark(m, st));
+  if (fa.stamps && ++stamp_calls == 400) {
+    GP_HIP(hipStreamSynchronize(st));
+    std::vector<unsigned long long> hst(8 * (size_t)grid.x);
+    GP_HIP(hipMemcpy(hst.data(), dstamps, sizeof(unsigned long long) * hst.size(), hipMemcpyDeviceToHost));
+    if (FILE *f = fopen(stamp_path, "w")) {
+      unsigned long long t0 = ~0ull;
+      for (unsigned wg = 0; wg < grid.x; ++wg) t0 = std::min(t0, hst[wg * 8]);
+      fprintf(f, "# nks %d nkstar %d n_llwg %d grid %u: wg start afterA afterwait aftersync end (us)\n", fa.nks, fa.nkstar,
+              fa.n_llwg, grid.x);
+      for (unsigned wg = 0; wg < grid.x; ++wg) {
+        fprintf(f, "%u", wg);
+        for (int i = 0; i < 5; ++i) fprintf(f, " %.2f", hst[wg * 8 + i] >= t0 ? (double)(hst[wg * 8 + i] - t0) / 100.0 : -1.0);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
+  // bookkeeping
+  s->cur ^= 1;
+  s->X = s->Xbuf + (size_t)s->cur * W * DPAD;
+  s->logp = s->lpbuf + (size_t)s->cur * W;
+  out = Pending();
+  if (have_next) {
+    out.have = true; out.h = h; out.slot = s->step_counter % RNG_RING;
+    out.lo = lo; out.cnt = cnt; out.nchunk = fa.nchunk; out.parity = parity;
+    w.cur_nchunk = fa.nchunk;
+  }
+  s->front_count += 1;
+  return GPEMU_OK;
+}
+
+int front_run(gpemu_sampler *s, int64_t steps, int store_chain, int world, int rank, bool emulate) {
+  gpemu_model *m = s->groups[0];
+  hipStream_t st = s->stream;
+  if (!m->lik_ready) { set_error("gpemu_likelihood_setup has not been called"); return GPEMU_ERR_STATE; }
+  int rc = ensure_gather(s);
+  if (rc != GPEMU_OK) return rc;
+  if (world == 1 || emulate) {
+    rc = set_local_peer(s);
+    if (rc != GPEMU_OK) return rc;
+  } else if (!s->peers || s->peer_world != world || s->peer_rank != rank) {
+    set_error("fused sharded run: the ranks' gather buffers have not been exchanged (gpemu_sampler_peer_import)");
+    return GPEMU_ERR_STATE;
+  }
+  int64_t lo[2], cnt[2];
+  for (int h = 0; h < 2; ++h) share_of(s, h, world, emulate ? 0 : rank, lo[h], cnt[h]);
+  rc = ensure_workspace(m, std::max<int64_t>(std::max(cnt[0], cnt[1]), 1));
+  if (rc != GPEMU_OK) return rc;
+  if (emulate) {
+    // proposals nobody evaluates carry -inf (rejected); the share that IS evaluated starts as "not arrived"
+    const int64_t n = GATHER_SLOTS * s->ns[0];
+    hipLaunchKernelGGL(gather_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->gather, n,
+                       0xFFF0000000000000ull);
+    for (int sl = 0; sl < GATHER_SLOTS; ++sl)
+      hipLaunchKernelGGL(gather_fill_kernel, dim3((unsigned)((std::max(cnt[0], cnt[1]) + 255) / 256)), dim3(256), 0, st,
+                         s->gather + (int64_t)sl * s->ns[0], std::max(cnt[0], cnt[1]), GATHER_EMPTY);
+  }
+  if (store_chain) {
+    rc = sampler_ensure_chain(s, s->chain_len + steps);
+    if (rc != GPEMU_OK) return rc;
+  }
+  Pending pend;
+  int64_t rec = s->chain_len;       // next chain row to be written
+  for (int64_t it = 0; it < steps; ++it) {
+    rc = sampler_launch_rng(s, st, steps - it);
+    if (rc != GPEMU_OK) return rc;
+    for (int h = 0; h < 2; ++h) {
+      // the accept of half 1 of the previous step completes that step: its chain row is written now
+      const int row = (pend.have && pend.h == 1 && store_chain) ? (int)(rec++) : -1;
+      Pending next;
+      if (cnt[h] > 0) {
+        rc = launch_front(s, pend, true, h, lo[h], cnt[h], world, emulate, row, next);
+        if (rc != GPEMU_OK) return rc;
+        rc = launch_trmm_vsq(m, cnt[h], st);
+        if (rc != GPEMU_OK) return rc;
+        next.nrb = m->ws.cur_nrb;
+      } else {
+        // this rank has no proposal in this half (more ranks than proposals): likelihood / accept only
+        rc = launch_front(s, pend, false, h, 0, 0, world, emulate, row, next);
+        if (rc != GPEMU_OK) return rc;
+        next.have = true; next.h = h; next.slot = s->step_counter % RNG_RING; next.lo = lo[h]; next.cnt = 0;
+      }
+      pend = next;
+    }
+    s->step_counter += 1;
+  }
+  if (pend.have) {                 // the last half's likelihood, exchange and accept
+    const int row = (pend.h == 1 && store_chain) ? (int)(rec++) : -1;
+    Pending none;
+    rc = launch_front(s, pend, false, 0, 0, 0, world, emulate, row, none);
+    if (rc != GPEMU_OK) return rc;
+  }
+  if (store_chain) s->chain_len += steps;
+  s->iterations += steps;
+  if (emulate) {                   // leave the buffer as a real run expects it
+    const int64_t n = GATHER_SLOTS * s->ns[0];
+    hipLaunchKernelGGL(gather_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->gather, n,
+                       GATHER_EMPTY);
+  }
+  rc = sampler_check_nan(s);
+  if (rc != GPEMU_OK) return rc;
+  int lost = 0;
+  GP_HIP(hipMemcpy(&lost, s->flags + 1, sizeof(int), hipMemcpyDeviceToHost));
+  if (lost) {
+    (void)hipMemset(s->flags + 1, 0, sizeof(int));
+    set_error("fused run: %d log-probability exchanges timed out (a rank did not deliver its share)", lost);
+    return GPEMU_ERR_STATE;
+  }
+  return GPEMU_OK;
+}
+
+}  // namespace gpemu
+
+using namespace gpemu;
+
+extern "C" {
+
+int gpemu_sampler_peer_export(gpemu_sampler *s, char *handle_out64) {
+  GP_ARG(s && handle_out64, "null pointer");
+  GP_HIP(hipSetDevice(s->device));
+  int rc = ensure_gather(s);
+  if (rc != GPEMU_OK) return rc;
+  hipIpcMemHandle_t h;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+  GP_HIP(hipIpcGetMemHandle(&h, s->gather));
+  memcpy(handle_out64, &h, 64);
+  return GPEMU_OK;
+}
+
+int gpemu_sampler_peer_import(gpemu_sampler *s, int world, int rank, const char *handles) {
+  GP_ARG(s && handles && world >= 1 && world <= 64 && rank >= 0 && rank < world, "world / rank / handles");
+  GP_HIP(hipSetDevice(s->device));
+  int rc = ensure_gather(s);
+  if (rc != GPEMU_OK) return rc;
+  GP_HIP(hipStreamSynchronize(s->stream));
+  for (void *q : s->peer_opened) (void)hipIpcCloseMemHandle(q);
+  s->peer_opened.clear();
+  (void)hipFree(s->peers);
+  s->peers = nullptr;
+  s->peer_world = 0;
+  std::vector<double *> ptrs((size_t)world, nullptr);
+  for (int r = 0; r < world; ++r) {
+    if (r == rank) { ptrs[r] = s->gather; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handles + (size_t)r * 64, 64);
+    void *q = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      set_error("hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+      for (void *o : s->peer_opened) (void)hipIpcCloseMemHandle(o);
+      s->peer_opened.clear();
+      return GPEMU_ERR_HIP;
+    }
+    s->peer_opened.push_back(q);
+    ptrs[r] = (double *)q;
+  }
+  GP_HIP(hipMalloc((void **)&s->peers, sizeof(double *) * world));
+  GP_HIP(hipMemcpy(s->peers, ptrs.data(), sizeof(double *) * world, hipMemcpyHostToDevice));
+  s->peer_world = world;
+  s->peer_rank = rank;
+  return GPEMU_OK;
+}
+
+int gpemu_sampler_run_peer(gpemu_sampler *s, int64_t steps, int store_chain) {
+  GP_ARG(s && steps >= 0, "sampler / steps");
+  GP_HIP(hipSetDevice(s->device));
+  if (!front_eligible(s)) {
+    set_error("the fused run needs one emulation group with at most 16 PCs and at most 2048 walkers");
+    return GPEMU_ERR_UNSUPPORTED;
+  }
+  if (s->peer_world < 1) { set_error("gpemu_sampler_peer_import has not been called"); return GPEMU_ERR_STATE; }
+  return front_run(s, steps, store_chain, s->peer_world, s->peer_rank, false);
+}
+
+}  // extern "C"

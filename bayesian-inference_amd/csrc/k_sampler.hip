@@ -13,6 +13,7 @@
 // identical on every rank so no communication is needed for it) or supplied by the host in emcee's
 // draw order (gpemu_sampler_step_host_rng) to replay a numpy RandomState stream.
 #include "internal.h"
+#include "sampler_internal.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -47,40 +48,11 @@ __host__ __device__ static inline double u01_from(uint32_t hi, uint32_t lo) {
 
 }  // namespace gpemu
 
-struct gpemu_sampler {
-  int device = 0;
-  std::vector<gpemu_model *> groups;
-  int64_t W = 0, d = 0;
-  int64_t ns[2] = {0, 0};      // set sizes: ceil(W/2), floor(W/2)
-  int64_t qcap = 0;            // rows of q (>= ns[0] rounded up to 128, + 128)
-  double a = 2.0;
-  uint64_t seed = 0;
-  uint64_t step_counter = 0;   // RNG counter, never reset
-  int64_t iterations = 0;      // steps since the last reset
-  hipStream_t stream = nullptr;
-  double *X = nullptr;         // [W][DPAD]
-  double *logp = nullptr;      // [W]
-  // per-step randomness, ring of RNG_RING steps (slot = step_counter % RNG_RING)
-  int *inds = nullptr;         // [RING][W] split of each walker
-  int *idx = nullptr;          // [RING][2][W] members of each set, ascending walker index
-  double *zz = nullptr;        // [RING][2][W]
-  double *logu = nullptr;      // [RING][2][W]
-  int *rint = nullptr;         // [RING][2][W]  partner walker of each proposal: c[randint(nc)] as a walker index
-  uint64_t rng_ready_until = 0; // steps [.., rng_ready_until) of the device stream are in the ring
-  double *q = nullptr;         // [qcap][DPAD]
-  double *factors = nullptr;   // [W]
-  double *newlp = nullptr;     // [qcap]
-  long long *naccept = nullptr;  // [W]
-  int *flags = nullptr;        // [1] count of NaN log-probabilities seen
-  double *chain = nullptr;     // [chain_cap][W][d]
-  double *lpchain = nullptr;   // [chain_cap][W]
-  int64_t chain_cap = 0, chain_len = 0;
-  // multi-GPU: this rank's slice / the gathered log-probabilities of each half ([per] / [per*world])
-  double *gmine[2] = {nullptr, nullptr};
-  double *gfull[2] = {nullptr, nullptr};
-  int64_t gper[2] = {0, 0};
-  int gworld = 0;
-};
+#define GP_TRY0(expr)           \
+  do {                          \
+    int rc0__ = (expr);         \
+    if (rc0__ != GPEMU_OK) return rc0__; \
+  } while (0)
 
 namespace gpemu {
 
@@ -88,12 +60,11 @@ namespace gpemu {
 // One workgroup per step (grid = steps generated ahead): random balanced split (rank of W random
 // keys by counting), set member lists (ballot prefix sums), and the step's zz / rint / log u draws
 // for both halves.  Step s writes slot s % RNG_RING of the ring buffers.
-constexpr int RNG_RING = 16;
 
 __global__ __launch_bounds__(1024) void rng_step_kernel(int *inds_r, int *idx_r, double *zz_r,
-                                                        double *logu_r, int *rint_r, int W, int n0,
-                                                        int n1, double a, uint32_t k0, uint32_t k1,
-                                                        unsigned long long step0) {
+                                                        double *logu_r, int *rint_r, double *fac_r, int *pos_r,
+                                                        int W, int n0, int n1, int d, double a, uint32_t k0,
+                                                        uint32_t k1, unsigned long long step0) {
   extern __shared__ unsigned long long keys[];  // [W]
   __shared__ int wcnt[2][16];
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -106,6 +77,8 @@ __global__ __launch_bounds__(1024) void rng_step_kernel(int *inds_r, int *idx_r,
   double *zz = zz_r + (size_t)slot * 2 * W;
   double *logu = logu_r + (size_t)slot * 2 * W;
   int *rint = rint_r + (size_t)slot * 2 * W;
+  double *fac = fac_r + (size_t)slot * 2 * W;
+  int *pos = pos_r + (size_t)slot * W;
 
   for (int w = tid; w < W; w += nthr) {
     u32x4 r = philox4x32_10(u32x4{(uint32_t)w, 0u, step_lo, step_hi}, k0, k1);
@@ -134,8 +107,8 @@ __global__ __launch_bounds__(1024) void rng_step_kernel(int *inds_r, int *idx_r,
       if (v < wave) { off0 += wcnt[0][v]; off1 += wcnt[1][v]; }
       tot0 += wcnt[0][v]; tot1 += wcnt[1][v];
     }
-    if (sp == 0) idx[off0 + __popcll(b0 & lt)] = w;
-    if (sp == 1) idx[W + off1 + __popcll(b1 & lt)] = w;
+    if (sp == 0) { const int i = off0 + __popcll(b0 & lt); idx[i] = w; pos[w] = i; }
+    if (sp == 1) { const int i = off1 + __popcll(b1 & lt); idx[W + i] = w; pos[w] = i; }
     base0 += tot0; base1 += tot1;
     __syncthreads();
   }
@@ -146,7 +119,9 @@ __global__ __launch_bounds__(1024) void rng_step_kernel(int *inds_r, int *idx_r,
       u32x4 r2 = philox4x32_10(u32x4{(uint32_t)i, (uint32_t)(3 + h), step_lo, step_hi}, k0, k1);
       double u = u01_from(r.x, r.y);
       double t = (a - 1.0) * u + 1.0;
-      zz[h * W + i] = t * t / a;
+      const double z = t * t / a;
+      zz[h * W + i] = z;
+      fac[h * W + i] = (d - 1.0) * log(z);     // emcee moves/stretch.py: factors = (ndim - 1) * log(zz)
       // partner = member `randint(nc)` of the complementary set, stored as a walker index so that the
       // consumers need one dependent load less (the set lists of this step are complete: barrier above)
       const int rpos = (int)(((unsigned long long)r.z * (unsigned long long)nc) >> 32);
@@ -248,19 +223,33 @@ static int ensure_chain(gpemu_sampler *s, int64_t need) {
   return GPEMU_OK;
 }
 
-// make sure the randomness of step s->step_counter is in the ring; generates up to `ahead` steps
-// (bounded by the ring) in one launch.  Stream order keeps earlier steps' reads before the refill.
-static int launch_rng(gpemu_sampler *s, hipStream_t st, int64_t ahead = 1) {
-  if (s->step_counter < s->rng_ready_until) return GPEMU_OK;
-  int64_t n = ahead < 1 ? 1 : (ahead > RNG_RING ? RNG_RING : ahead);
+static int launch_rng_batch(gpemu_sampler *s, hipStream_t st, uint64_t first, int64_t n) {
   size_t shm = sizeof(unsigned long long) * s->W;
   hipLaunchKernelGGL(rng_step_kernel, dim3((unsigned)n), dim3(1024), shm, st, s->inds, s->idx, s->zz,
-                     s->logu, s->rint, (int)s->W, (int)s->ns[0], (int)s->ns[1], s->a, (uint32_t)s->seed,
-                     (uint32_t)(s->seed >> 32), (unsigned long long)s->step_counter);
+                     s->logu, s->rint, s->fac, s->pos, (int)s->W, (int)s->ns[0], (int)s->ns[1], (int)s->d, s->a,
+                     (uint32_t)s->seed, (uint32_t)(s->seed >> 32), (unsigned long long)first);
   GP_HIP(hipGetLastError());
-  s->rng_ready_until = s->step_counter + (uint64_t)n;
   return GPEMU_OK;
 }
+
+// Make sure the randomness of step s->step_counter is in the ring.  A batch is at most RNG_BATCH steps and never
+// crosses a multiple of RNG_BATCH, so it fills one half of the ring and leaves the other half (the previous steps'
+// draws, still read by the fused run) untouched.  Generated in the chain's own stream: producing the next batch on
+// a side stream while the current one is consumed was tried and LOST (C3: 0.262 -> 0.265 ms per step on one GPU,
+// 0.187 -> 0.214 at two emulated ranks) -- the generator's workgroups land on CUs that each hold one persistent
+// triangular-GEMM worker and turn those workers into stragglers.
+static int launch_rng(gpemu_sampler *s, hipStream_t st, int64_t ahead = 1) {
+  const uint64_t step = s->step_counter;
+  if (step < s->rng_ready_until) return GPEMU_OK;
+  const int64_t to_edge = RNG_BATCH - (int64_t)(step % RNG_BATCH);
+  const int64_t n = ahead < 1 ? 1 : (ahead > to_edge ? to_edge : ahead);
+  GP_TRY0(launch_rng_batch(s, st, step, n));
+  s->rng_ready_until = step + (uint64_t)n;
+  return GPEMU_OK;
+}
+
+int sampler_launch_rng(gpemu_sampler *s, hipStream_t st, int64_t ahead) { return launch_rng(s, st, ahead); }
+int sampler_ensure_chain(gpemu_sampler *s, int64_t need) { return ensure_chain(s, need); }
 
 static inline size_t rslot(const gpemu_sampler *s) { return (size_t)(s->step_counter % RNG_RING); }
 
@@ -366,22 +355,29 @@ int gpemu_sampler_create(gpemu_sampler **out, gpemu_model *const *groups, int n_
   s->stream = groups[0]->stream;
   hipError_t e = hipSuccess;
   auto A = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 8); };
-  A((void **)&s->X, sizeof(double) * W * DPAD);
-  A((void **)&s->logp, sizeof(double) * W);
+  A((void **)&s->Xbuf, sizeof(double) * 2 * W * DPAD);
+  A((void **)&s->lpbuf, sizeof(double) * 2 * W);
   A((void **)&s->inds, sizeof(int) * W * RNG_RING);
   A((void **)&s->idx, sizeof(int) * 2 * W * RNG_RING);
   A((void **)&s->zz, sizeof(double) * 2 * W * RNG_RING);
   A((void **)&s->logu, sizeof(double) * 2 * W * RNG_RING);
   A((void **)&s->rint, sizeof(int) * 2 * W * RNG_RING);
+  A((void **)&s->fac, sizeof(double) * 2 * W * RNG_RING);
+  A((void **)&s->pos, sizeof(int) * W * RNG_RING);
+  A((void **)&s->q2, sizeof(double) * 2 * s->qcap * DPAD);
   A((void **)&s->q, sizeof(double) * s->qcap * DPAD);
   A((void **)&s->factors, sizeof(double) * W);
   A((void **)&s->newlp, sizeof(double) * s->qcap);
   A((void **)&s->naccept, sizeof(long long) * W);
-  A((void **)&s->flags, sizeof(int));
+  A((void **)&s->flags, sizeof(int) * 2);
+  if (e == hipSuccess) { s->X = s->Xbuf; s->logp = s->lpbuf; s->cur = 0; }
+
   if (e == hipSuccess) e = hipMemsetAsync(s->q, 0, sizeof(double) * s->qcap * DPAD, s->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(s->q2, 0, sizeof(double) * 2 * s->qcap * DPAD, s->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(s->lpbuf, 0, sizeof(double) * 2 * W, s->stream);
   if (e == hipSuccess) e = hipMemsetAsync(s->naccept, 0, sizeof(long long) * W, s->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(s->flags, 0, sizeof(int), s->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(s->X, 0, sizeof(double) * W * DPAD, s->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(s->flags, 0, sizeof(int) * 2, s->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(s->Xbuf, 0, sizeof(double) * 2 * W * DPAD, s->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
   if (e != hipSuccess) {
     set_error("sampler_create: %s", hipGetErrorString(e));
@@ -396,7 +392,9 @@ int gpemu_sampler_destroy(gpemu_sampler *s) {
   if (!s) return GPEMU_OK;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  (void)hipFree(s->X); (void)hipFree(s->logp); (void)hipFree(s->inds); (void)hipFree(s->idx);
+  front_release(s);
+  (void)hipFree(s->Xbuf); (void)hipFree(s->lpbuf); (void)hipFree(s->inds); (void)hipFree(s->idx);
+  (void)hipFree(s->fac); (void)hipFree(s->pos); (void)hipFree(s->q2);
   (void)hipFree(s->zz); (void)hipFree(s->logu); (void)hipFree(s->rint); (void)hipFree(s->q);
   (void)hipFree(s->factors); (void)hipFree(s->newlp); (void)hipFree(s->naccept); (void)hipFree(s->flags);
   (void)hipFree(s->chain); (void)hipFree(s->lpchain);
@@ -489,6 +487,11 @@ int gpemu_sampler_run(gpemu_sampler *s, int64_t steps, int store_chain) {
   GP_ARG(s && steps >= 0, "sampler / steps");
   GP_HIP(hipSetDevice(s->device));
   hipStream_t st = s->stream;
+  // On one GPU the three-launch half-step below is the faster form (0.262 vs 0.265 ms per step at C3: the fused
+  // front kernel runs its likelihood and cross-kernel phases back to back); GPEMU_FUSED_SINGLE=1 takes the
+  // two-launch form of the sharded run instead (same chain).
+  static const bool fused_single = getenv("GPEMU_FUSED_SINGLE") != nullptr;
+  if (fused_single && front_eligible(s)) return front_run(s, steps, store_chain, 1, 0, false);
   if (store_chain) GP_TRY(ensure_chain(s, s->chain_len + steps));
   for (int64_t it = 0; it < steps; ++it) {
     GP_TRY(launch_rng(s, st, steps - it));
@@ -574,7 +577,7 @@ int gpemu_sampler_reserve_chain(gpemu_sampler *s, int64_t additional_steps) {
 int gpemu_sampler_begin_step(gpemu_sampler *s) {
   GP_ARG(s, "sampler");
   GP_HIP(hipSetDevice(s->device));
-  return launch_rng(s, s->stream, RNG_RING);
+  return launch_rng(s, s->stream, RNG_BATCH);
 }
 
 int gpemu_sampler_half_propose_eval(gpemu_sampler *s, int half, int64_t lo, int64_t hi,
@@ -733,6 +736,7 @@ int gpemu_sampler_run_sharded(gpemu_sampler *s, gpemu_comm *c, int64_t steps, in
   GP_HIP(hipSetDevice(s->device));
   hipStream_t st = s->stream;
   const int world = c->world;
+  if (emulate_world > 0 && front_eligible(s)) return front_run(s, steps, store_chain, emulate_world, 0, true);
   const int split = emulate_world > 0 ? emulate_world : world;
   int64_t lo[2], hi[2];
   for (int h = 0; h < 2; ++h) {
@@ -769,3 +773,7 @@ int gpemu_sampler_run_sharded(gpemu_sampler *s, gpemu_comm *c, int64_t steps, in
 }
 
 }  // extern "C"
+
+namespace gpemu {
+int sampler_check_nan(gpemu_sampler *s) { return check_nan(s); }
+}  // namespace gpemu

@@ -84,6 +84,9 @@ _SIGNATURES = {
     "gpemu_comm_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gpemu_comm_all_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p]),
     "gpemu_sampler_run_sharded": (C.c_int, [C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int]),
+    "gpemu_sampler_peer_export": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gpemu_sampler_peer_import": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "gpemu_sampler_run_peer": (C.c_int, [C.c_void_p, c_i64, C.c_int]),
     "gpemu_philox4x32": (C.c_int, [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]),
 }
 

@@ -227,15 +227,46 @@ class DeviceSampler:
         self.__dict__.setdefault("_comms", {})[key] = None
         return None
 
+    def _peer_ready(self, group):
+        """Exchange the ranks' gather-buffer IPC handles (once per sampler and group) so that every rank can
+        store its log-probabilities straight into the others' memory.  True on every rank, or False on every
+        rank (the ranks vote), e.g. when the model is outside the fused run's limits or IPC is unavailable."""
+        import torch
+        import torch.distributed as dist
+        key = id(group) if group is not None else 0
+        cache = self.__dict__.setdefault("_peer_ok", {})
+        if key in cache:
+            return cache[key]
+        L = _lib.lib()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        where = torch.device("cuda", self.device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        mine = (C.c_char * 64)()
+        ok = 1
+        if L.gpemu_sampler_peer_export(self._h, C.cast(mine, C.c_void_p)) != 0:
+            ok = 0
+        t = torch.tensor(list(mine.raw), dtype=torch.uint8, device=where)
+        everyone = torch.zeros(64 * world, dtype=torch.uint8, device=where)
+        dist.all_gather_into_tensor(everyone, t, group=group)
+        if ok:
+            raw = bytes(everyone.cpu().tolist())
+            buf = C.create_string_buffer(raw, 64 * world)
+            if L.gpemu_sampler_peer_import(self._h, int(world), int(rank), C.cast(buf, C.c_void_p)) != 0:
+                ok = 0
+        vote = torch.tensor([ok], dtype=torch.int32, device=where)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=group)
+        cache[key] = bool(int(vote.item()))
+        return cache[key]
+
     def run_sharded(self, steps, store=True, group=None, force=False, emulate_world=None, transport=None):
         """Same chain as ``run`` (every rank draws identical randomness); rank r evaluates its
-        block of each half's proposals and the log-probabilities are all-gathered.
+        block of each half's proposals and the log-probabilities are exchanged.
 
-        Backend "nccl" (RCCL over xGMI), transport "rccl" (default): the whole loop runs inside the
-        library on its own RCCL communicator (``gpemu_sampler_run_sharded``), no host work per step.
-        transport "torch" (or env GPEMU_SHARDED_TRANSPORT=torch): per-phase calls with torch.distributed's
-        all-gather on a shared stream.  Any other backend (gloo, for tests): the 8-byte-per-walker payload
-        is staged through the host.
+        transport "peer" (default where it applies: one emulation group, <= 16 PCs, <= 2048 walkers): two
+        launches per half-step, every new log-probability stored straight into all ranks' memory (xGMI peer
+        stores, no collective): ``gpemu_sampler_run_peer``.  transport "rccl" (backend "nccl"): the loop runs
+        inside the library on its own RCCL communicator with one all-gather per half-step
+        (``gpemu_sampler_run_sharded``).  transport "torch": per-phase calls with torch.distributed's all-gather
+        (staged through the host on non-nccl backends).  GPEMU_SHARDED_TRANSPORT overrides the default.
         """
         import torch
         import torch.distributed as dist
@@ -245,7 +276,17 @@ class DeviceSampler:
         L = _lib.lib()
         dev = torch.device("cuda", self.device)
         on_device = dist.get_backend(group) == "nccl"
-        transport = transport or os.environ.get("GPEMU_SHARDED_TRANSPORT", "rccl")
+        transport = transport or os.environ.get("GPEMU_SHARDED_TRANSPORT", "peer")
+        if transport == "peer" and not emulate_world:
+            if world > 1 and self._peer_ready(group):
+                rc = L.gpemu_sampler_run_peer(self._h, int(steps), int(bool(store)))
+                if rc == 1:
+                    raise ValueError("Probability function returned NaN")
+                check(rc)
+                return None
+            transport = "rccl"
+        elif transport == "peer":
+            transport = "rccl"          # the emulation switch lives in gpemu_sampler_run_sharded
         if on_device and transport == "rccl":
             comm = self._rccl_comm_agreed(group)
             if comm is None:

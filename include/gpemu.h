@@ -222,6 +222,18 @@ int gpemu_comm_all_gather(gpemu_comm *c, const double *dsend, double *drecv, int
 int gpemu_sampler_run_sharded(gpemu_sampler *s, gpemu_comm *c, int64_t steps, int store_chain,
                               int emulate_world);
 
+/* ---- sharded run without a collective: peer stores over xGMI ---------------------------------------------
+ * Every rank owns a small "gather" buffer; after evaluating its share of a half's proposals a rank stores each new
+ * log-probability (8 bytes) straight into every rank's buffer.  Setup: each rank exports a 64-byte IPC handle of its
+ * buffer (gpemu_sampler_peer_export), the ranks exchange the handles by any means (torch.distributed all_gather),
+ * and each imports all of them (handles[world*64], its own entry is ignored).  gpemu_sampler_run_peer then runs
+ * `steps` stretch-move steps with TWO launches per half-step and no RCCL call; same chain as gpemu_sampler_run on
+ * every rank.  Needs one emulation group with <= 16 PCs and <= 2048 walkers (else GPEMU_ERR_UNSUPPORTED: use
+ * gpemu_sampler_run_sharded).  Replaces ref: mcmc.py:77-85 (the pool.map over walkers). */
+int gpemu_sampler_peer_export(gpemu_sampler *s, char *handle_out64);
+int gpemu_sampler_peer_import(gpemu_sampler *s, int world, int rank, const char *handles);
+int gpemu_sampler_run_peer(gpemu_sampler *s, int64_t steps, int store_chain);
+
 /* Philox4x32-10 block function (host copy of the device generator; for tests) */
 int gpemu_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                      uint32_t *out4);

@@ -130,7 +130,7 @@ def test_c3_sampler_bookkeeping_and_statistics():
 
 
 # ---- sharded device sampler: 2 ranks on the one GPU, log-probabilities exchanged over gloo ----------
-def _sharded_worker(rank, world, port, out_dir):
+def _sharded_worker(rank, world, port, out_dir, transport):
     import os
     import sys
     import torch.distributed as dist
@@ -145,7 +145,10 @@ def _sharded_worker(rank, world, port, out_dir):
     W = 26     # halves of 13: ragged shards
     ds = DeviceSampler([dm], W, seed=99)
     ds.set_state(synthetic.make_walkers(W, seed=3, lo=g["lo"], hi=g["hi"]))
-    ds.run_sharded(9)
+    ds.run_sharded(4, transport=transport)     # two calls: the exchange slots carry over
+    ds.run_sharded(5, transport=transport)
+    if transport == "peer":
+        assert ds._peer_ok and all(ds._peer_ok.values()), "the peer transport was not taken"
     chain, lps = ds.get_chain()
     np.save(os.path.join(out_dir, f"chain_{rank}.npy"), chain)
     np.save(os.path.join(out_dir, f"lp_{rank}.npy"), lps)
@@ -157,13 +160,17 @@ def _sharded_worker(rank, world, port, out_dir):
     dm.close()
 
 
-def test_sharded_device_sampler_two_ranks_equals_single(tmp_path):
+@pytest.mark.parametrize("transport", ["peer", "torch"])
+def test_sharded_device_sampler_two_ranks_equals_single(tmp_path, transport):
+    """Two ranks (two processes on the one GPU, rendezvous over gloo) shard the proposals; "peer": the fused run,
+    each rank storing its log-probabilities into the other's gather buffer through an IPC mapping; "torch": the
+    per-phase API with the values staged through the host."""
     import os
     import torch.multiprocessing as mp
     from gpemu import synthetic
     from gpemu.sampler import DeviceSampler
-    port = 29600 + (os.getpid() % 2000)
-    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 29600 + (os.getpid() % 2000) + (7 if transport == "peer" else 0)
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path), transport), nprocs=2, join=True)
     c0, c1 = np.load(tmp_path / "chain_0.npy"), np.load(tmp_path / "chain_1.npy")
     np.testing.assert_array_equal(c0, c1)                       # every rank holds the same ensemble
     np.testing.assert_array_equal(np.load(tmp_path / "lp_0.npy"), np.load(tmp_path / "lp_1.npy"))
@@ -230,3 +237,43 @@ def test_sharded_path_over_rccl_world1(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_rccl_worker, args=(29700 + (os.getpid() % 2000), str(tmp_path)), nprocs=1, join=True)
     assert np.load(tmp_path / "ok.npy").all()
+
+
+def test_fused_run_world1_equals_three_launch_run():
+    """gpemu_sampler_run_peer with a one-rank "world" (the two-launch half-step: likelihood + exchange + accept +
+    proposal + cross-kernel in one kernel) against gpemu_sampler_run (three launches per half-step): same chain, bit
+    for bit, over several calls and an odd ensemble size."""
+    import ctypes as C
+    from gpemu import _lib, synthetic
+    from gpemu.sampler import DeviceSampler
+    g, model, dm, _ = _setup()
+    L = _lib.lib()
+    for W in (24, 33, 130, 1025):
+        X0 = synthetic.make_walkers(W, seed=3, lo=g["lo"], hi=g["hi"])
+        a = DeviceSampler([dm], W, seed=7)
+        a.set_state(X0)
+        a.run(11)
+        b = DeviceSampler([dm], W, seed=7)
+        b.set_state(X0)
+        h = (C.c_char * 64)()
+        _lib.check(L.gpemu_sampler_peer_export(b._h, C.cast(h, C.c_void_p)))
+        _lib.check(L.gpemu_sampler_peer_import(b._h, 1, 0, C.cast(h, C.c_void_p)))
+        for n in (1, 4, 6):                       # 11 steps in three calls, crossing no / one RNG batch edge
+            _lib.check(L.gpemu_sampler_run_peer(b._h, n, 1))
+        ca, la = a.get_chain()
+        cb, lb = b.get_chain()
+        np.testing.assert_array_equal(ca, cb)
+        np.testing.assert_array_equal(la, lb)
+        np.testing.assert_array_equal(a.counts()[0], b.counts()[0])
+        np.testing.assert_array_equal(a.get_state()[0], b.get_state()[0])
+        a.close(); b.close()
+    # 40 steps in one call (randomness generated in batches of 16) against one step per call
+    W = 64
+    X0 = synthetic.make_walkers(W, seed=5, lo=g["lo"], hi=g["hi"])
+    a = DeviceSampler([dm], W, seed=11); a.set_state(X0); a.run(40)
+    b = DeviceSampler([dm], W, seed=11); b.set_state(X0)
+    for _ in range(40):
+        b.run(1)
+    np.testing.assert_array_equal(a.get_chain()[0], b.get_chain()[0])
+    a.close(); b.close()
+    dm.close()
