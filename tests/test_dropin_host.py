@@ -161,3 +161,53 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+
+
+# ---- learn_mapping against the reference's own run on its fixture (golden G6) ------------------------------
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/bayesian_inference/data_IO.py"),
+                    reason="needs the reference's data_IO (build container only)")
+def test_learn_mapping_matches_the_reference_on_its_fixture(monkeypatch):
+    """SortEmulationGroupObservables.learn_mapping (ref: emulation.py:289-344) through the UNTOUCHED reference
+    data_IO -- imported without silx thanks to gpemu.h5io's stand-in, reading the reference's observables.h5 with
+    the built-in HDF5 reader -- for a two-group split, against the reference's own result (tests/golden/
+    make_learn_mapping_golden.py)."""
+    import importlib.util
+    import sys
+    import bayesian_inference
+    from bayesian_inference import emulation
+    HERE = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("bayesian_inference.data_IO",
+                                                  "/root/reference/src/bayesian_inference/data_IO.py")
+    ref_io = importlib.util.module_from_spec(spec)
+    monkeypatch.setitem(sys.modules, "bayesian_inference.data_IO", ref_io)
+    monkeypatch.setattr(bayesian_inference, "data_IO", ref_io, raising=False)
+    spec.loader.exec_module(ref_io)
+    g = dict(np.load(os.path.join(HERE, "golden", "g6_learn_mapping.npz")))
+
+    class GroupCfg:
+        def __init__(self, include):
+            self.observable_filter = ref_io.ObservableFilter(include_list=include.split(";"), exclude_list=[])
+
+    class EmuCfg:
+        output_dir = "/root/reference/tests/test_data"
+        emulation_groups_config = {str(n): GroupCfg(str(i)) for n, i in zip(g["group_names"], g["include"])}
+
+    m = emulation.SortEmulationGroupObservables.learn_mapping(EmuCfg())
+    assert list(m.emulation_group_to_observable_matrix) == [str(k) for k in g["observables"]]      # sorted order
+    assert tuple(m.shape) == tuple(int(v) for v in g["shape"])
+    for i, key in enumerate(g["observables"]):
+        grp, so, sg = m.emulation_group_to_observable_matrix[str(key)]
+        assert grp == str(g["group"][i])
+        assert (so.start, so.stop) == (int(g["out_start"][i]), int(g["out_stop"][i]))
+        assert (sg.start, sg.stop) == (int(g["grp_start"][i]), int(g["grp_stop"][i]))
+    # the layout handed to the device likelihood: this group's columns in the merged order, observable block starts
+    for name in m_groups(g):
+        cols, starts = m.group_layout(name)
+        sel = [i for i in range(len(g["group"])) if str(g["group"][i]) == name]
+        want = np.concatenate([np.arange(g["out_start"][i], g["out_stop"][i]) for i in sel])
+        np.testing.assert_array_equal(np.sort(cols), np.sort(want))
+        assert starts[0] == 0 and starts[-1] == len(want) and len(starts) == len(sel) + 1
+
+
+def m_groups(g):
+    return [str(n) for n in g["group_names"]]

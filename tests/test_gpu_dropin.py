@@ -166,3 +166,11 @@ def test_run_mcmc_end_to_end(tmp_path, monkeypatch):
     np.testing.assert_allclose(lp, out["log_prob"][-1][:5], rtol=1e-10)
     sampler = pickle.load(open(cfg.sampler_outputfile, "rb"))
     np.testing.assert_array_equal(sampler.get_chain(), out["chain"])
+    # mcmc.h5 on disk (silx layout, written without silx): what plot_mcmc.py:44-58 reads back
+    from gpemu import h5io
+    back = h5io.read_dict_from_h5(cfg.mcmc_output_dir, cfg.mcmc_outputfilename)
+    assert set(back) == {"chain", "acceptance_fraction", "log_prob", "autocorrelation_time"}
+    np.testing.assert_array_equal(back["chain"], out["chain"])
+    np.testing.assert_array_equal(back["log_prob"], out["log_prob"])
+    np.testing.assert_array_equal(back["acceptance_fraction"], out["acceptance_fraction"])
+    assert back["autocorrelation_time"] == {}             # None -> empty group, as silx writes it

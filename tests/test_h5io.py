@@ -1,0 +1,90 @@
+"""gpemu.h5io: the silx-free HDF5 writer / reader behind mcmc.h5 and observables.h5 (ref: data_IO.py:217-257,
+mcmc.py:111-125, plot_mcmc.py:44-58).  The writer's output is checked against the HDF5 library itself by
+tests/golden/h5_crosscheck.py (run with the interpreter that has h5py); here: the committed fixtures."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import h5_crosscheck as X  # noqa: E402
+
+REF_H5 = "/root/reference/tests/test_data/observables.h5"
+
+
+@pytest.fixture(autouse=True)
+def _native(monkeypatch):
+    monkeypatch.setenv("GPEMU_NO_H5PY", "1")        # the built-in writer / reader even where h5py exists
+
+
+def test_native_round_trip(tmp_path):
+    from gpemu import h5io
+    h5io.write_dict_to_h5(X.tree(), str(tmp_path / "sub"), "mcmc.h5")
+    got = h5io.read_dict_from_h5(str(tmp_path / "sub"), "mcmc.h5")
+    X.compare(got, X.tree())
+    assert got["autocorrelation_time"] == {}                       # None -> empty group -> {} (silx semantics)
+    assert got["extras"]["label"] == "pt_ch_alice" and got["extras"]["scalar"] == 3.25
+    np.testing.assert_array_equal(h5io.h5todict(str(tmp_path / "sub" / "mcmc.h5"), "/experimental_pseudodata")["y"],
+                                  X.tree()["experimental_pseudodata"]["y"])
+    # the file is rewritten, not appended to
+    h5io.dicttoh5({"only": np.arange(3.0)}, str(tmp_path / "sub" / "mcmc.h5"), update_mode="modify")
+    assert list(h5io.h5todict(str(tmp_path / "sub" / "mcmc.h5"))) == ["only"]
+
+
+def test_writer_output_is_the_committed_fixture(tmp_path):
+    """h5_native_writer.h5 is the file h5py / h5dump were run on (tests/golden/h5_crosscheck.py): the writer still
+    produces exactly those bytes."""
+    from gpemu import h5io
+    h5io.dicttoh5(X.tree(), str(tmp_path / "t.h5"))
+    assert (tmp_path / "t.h5").read_bytes() == open(X.NATIVE, "rb").read()
+
+
+def test_reader_on_a_library_written_file():
+    """h5_h5py_writer.h5 was written by h5py 3.3.0 (HDF5 1.10): old-style groups, one with 21 members spread over
+    several symbol-table nodes, contiguous datasets, a fixed-length string, a zero-size dataset."""
+    from gpemu import h5io
+    X.compare(h5io.h5todict(X.LIBRARY), X.tree())
+
+
+def test_unsupported_files_raise(tmp_path):
+    from gpemu import h5io
+    p = tmp_path / "bad.h5"
+    p.write_bytes(b"not hdf5 at all" * 10)
+    with pytest.raises(ValueError):
+        h5io.h5todict(str(p))
+    with pytest.raises(ValueError):
+        h5io.dicttoh5({"a/b": np.zeros(2)}, str(tmp_path / "x.h5"))
+    with pytest.raises(TypeError):
+        h5io.dicttoh5({"a": np.array([object()])}, str(tmp_path / "x.h5"))
+
+
+def test_silx_shim_serves_the_two_names():
+    from gpemu import h5io
+    import bayesian_inference  # noqa: F401  (installs the shim when silx is missing)
+    from silx.io.dictdump import dicttoh5, h5todict
+    try:
+        import silx
+        real = getattr(silx, "__file__", None) is not None
+    except ImportError:
+        real = False
+    if not real:
+        assert dicttoh5 is h5io.dicttoh5 and h5todict is h5io.h5todict
+
+
+@pytest.mark.skipif(not os.path.exists(REF_H5), reason="the reference's fixture is only in the build container")
+def test_reader_on_the_reference_fixture():
+    """The reference's own test fixture (written through silx / h5py) read by the built-in reader equals what h5py
+    read from it (tests/golden/observables_fixture.npz, produced by dump_observables_h5.py under h5py)."""
+    from gpemu import h5io
+    obs = h5io.h5todict(REF_H5)
+    fx = dict(np.load(os.path.join(HERE, "golden", "observables_fixture.npz")))
+    assert set(obs) == {"Data", "Design", "Design_validation", "Prediction", "Prediction_validation"}
+    np.testing.assert_array_equal(obs["Design"], fx["design"])
+    labels = sorted(obs["Prediction"])
+    assert labels == list(fx["labels"])
+    Y = np.concatenate([obs["Prediction"][k]["y"].T for k in labels], axis=1)
+    np.testing.assert_array_equal(Y, fx["Y"])
+    np.testing.assert_array_equal(np.concatenate([obs["Data"][k]["y"] for k in labels]), fx["y"])
+    np.testing.assert_array_equal(np.concatenate([obs["Data"][k]["y_err"] for k in labels]), fx["y_err"])
