@@ -14,6 +14,10 @@ struct GemmArgs {
   int M = 0, N = 0, K = 0;
   double alpha = 1.0, beta = 0.0;
   int lower_only = 0;  // skip 64 x 64 tiles strictly above the diagonal
+  // triangular operands: restrict the K range of a tile to where the operands can be non-zero
+  int k_from_m = 0;    // op(A)[m][k] = 0 for k < m  (A upper triangular in (m, k)): start at the tile's first row
+  int k_from_n = 0;    // op(B)[k][n] = 0 for k < n  (B lower triangular in (k, n)): start at the tile's first column
+  int k_to_m = 0;      // op(A)[m][k] = 0 for k > m  (A lower triangular in (m, k)): stop after the tile's last row
 };
 
 // C = alpha op(A) op(B) + beta C; a_kmajor: A stored [k][m] else [m][k]; b_kmajor: B stored [k][n]

@@ -270,6 +270,7 @@ int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double
       g.B = W + p0 * Np + p0; g.ldb = Np; g.strideB = 2 * b * Np + 2 * b;
       g.C = T + (p0 + b) * Np + p0; g.ldc = Np; g.strideC = 2 * b * Np + 2 * b;
       g.M = (int)b2; g.N = (int)b; g.K = (int)b;
+      g.k_from_n = 1;                                          // W11 is lower triangular: W11[k][n] = 0 for k < n
       int rc = launch_gemm(g, false, true, batch, st);
       if (rc != GPEMU_OK) return rc;
       // W21 = -W22 . T21  (b2 x b) = (b2 x b2) (b2 x b)
@@ -278,6 +279,7 @@ int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double
       h.B = T + (p0 + b) * Np + p0; h.ldb = Np; h.strideB = 2 * b * Np + 2 * b;
       h.C = W + (p0 + b) * Np + p0; h.ldc = Np; h.strideC = 2 * b * Np + 2 * b;
       h.M = (int)b2; h.N = (int)b; h.K = (int)b2; h.alpha = -1.0;
+      h.k_to_m = 1;                                            // W22 is lower triangular: W22[m][k] = 0 for k > m
       return launch_gemm(h, false, true, batch, st);
     };
     if (nfull > 0) {
@@ -373,11 +375,16 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(const double *__restrict_
   __shared__ double red[NTH_MAX][4];
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;
+  if ((int)(blockIdx.x * blockDim.x) > j) {            // wholly above the diagonal: nothing to add
+    if (threadIdx.x < NTH_MAX) gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NTH_MAX + threadIdx.x] = 0.0;
+    return;
+  }
   double acc[NTH_MAX];
 #pragma unroll
   for (int t = 0; t < NTH_MAX; ++t) acc[t] = 0.0;
-  if (l < N) {
-    const double wgt = alpha[j] * alpha[l] - Kinv[(int64_t)j * ld + l];
+  // the summand is symmetric in (j, l): the lower triangle counts twice, Kinv is only read (and only valid) there
+  if (l <= j) {
+    const double wgt = (l < j ? 2.0 : 1.0) * (alpha[j] * alpha[l] - Kinv[(int64_t)j * ld + l]);
     double D[DPAD], r2 = 0.0;
 #pragma unroll
     for (int dd = 0; dd < DPAD; ++dd) {
@@ -416,21 +423,31 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(const double *__restrict_
   }
 }
 
-__global__ __launch_bounds__(1024) void grad_reduce_kernel(const double *__restrict__ gpart, int nparts,
-                                                           double *__restrict__ grad, int nth) {
-  __shared__ double part[16];
+// two-stage deterministic sum of the partial gradients: GR_BLOCKS workgroups each sum a contiguous slice ...
+constexpr int GR_BLOCKS = 128;
+__global__ __launch_bounds__(256) void grad_reduce_stage1_kernel(const double *__restrict__ gpart, int nparts,
+                                                                 double *__restrict__ stage, int nth) {
+  __shared__ double part[4];
+  const int per = (nparts + GR_BLOCKS - 1) / GR_BLOCKS;
+  const int i0 = blockIdx.x * per, i1 = (i0 + per < nparts) ? i0 + per : nparts;
   for (int t = 0; t < nth; ++t) {
     double s = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += gpart[(int64_t)i * NTH_MAX + t];
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) s += gpart[(int64_t)i * NTH_MAX + t];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      double tot = 0.0;
-      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += part[w];
-      grad[t] = tot;
-    }
+    if (threadIdx.x == 0) stage[blockIdx.x * NTH_MAX + t] = (part[0] + part[1]) + (part[2] + part[3]);
+  }
+}
+
+// ... and one workgroup sums the GR_BLOCKS slices
+__global__ __launch_bounds__(64) void grad_reduce_kernel(const double *__restrict__ stage, double *__restrict__ grad, int nth) {
+  for (int t = 0; t < nth; ++t) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < GR_BLOCKS; i += 64) s += stage[i * NTH_MAX + t];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (threadIdx.x == 0) grad[t] = s;
   }
 }
 
@@ -491,7 +508,7 @@ struct gpemu_fit {
   hipStream_t stream = nullptr;
   double *X = nullptr, *hp = nullptr, *K = nullptr, *Dinv = nullptr, *W = nullptr,
          *T = nullptr, *Kinv = nullptr, *y = nullptr, *v = nullptr, *alpha = nullptr, *gpart = nullptr,
-         *scal = nullptr, *grad = nullptr;
+         *scal = nullptr, *grad = nullptr, *gstage = nullptr;
   int *info = nullptr;
   int n_gparts = 0;
 };
@@ -541,14 +558,17 @@ static int fit_eval(gpemu_fit *f, const double *y, const double *theta, int64_t 
   hipLaunchKernelGGL(lml_terms_kernel, dim3(1), dim3(1024), 0, st, f->y, f->alpha, f->K, Np, (int)N, f->scal);
   GP_HIP(hipGetLastError());
   if (want_grad) {
-    GemmArgs g;  // K^-1 = W^T W
-    g.A = f->W; g.lda = Np; g.B = f->W; g.ldb = Np; g.C = f->Kinv; g.ldc = Np;
-    g.M = (int)Np; g.N = (int)Np; g.K = (int)Np;
+    GemmArgs g;  // K^-1 = W^T W: symmetric, so only the tiles on and below the diagonal; W is lower triangular, so
+    g.A = f->W; g.lda = Np; g.B = f->W; g.ldb = Np; g.C = f->Kinv; g.ldc = Np;   // (W^T W)[a][b] = sum_{i >= max(a, b)}:
+    g.M = (int)Np; g.N = (int)Np; g.K = (int)Np;                                  // N^3/3 FLOP instead of 2 N^3
+    g.lower_only = 1; g.k_from_m = 1;
     GP_TRY(launch_gemm(g, true, true, 1, st));
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)N);
     hipLaunchKernelGGL(lml_grad_kernel, grid, dim3(256), 0, st, f->X, f->hp, f->alpha, f->Kinv, Np, f->gpart, (int)N,
                        (int)d, f->kind, f->has_const, f->has_noise);
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3(1), dim3(1024), 0, st, f->gpart, (int)(grid.x * grid.y), f->grad, nth);
+    hipLaunchKernelGGL(grad_reduce_stage1_kernel, dim3(GR_BLOCKS), dim3(256), 0, st, f->gpart, (int)(grid.x * grid.y),
+                       f->gstage, nth);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(1), dim3(64), 0, st, f->gstage, f->grad, nth);
     GP_HIP(hipGetLastError());
   }
   double hs[2];
@@ -596,6 +616,7 @@ int gpemu_fit_create(gpemu_fit **out, int device, int64_t N, int64_t d, const do
   A(&f->X, Np * DPAD); A(&f->hp, DPAD + 2); A(&f->K, Np * Np); A(&f->Dinv, Np * NB);
   A(&f->W, Np * Np); A(&f->T, Np * Np); A(&f->Kinv, Np * Np); A(&f->y, Np); A(&f->v, Np); A(&f->alpha, Np);
   A(&f->gpart, (int64_t)f->n_gparts * NTH_MAX); A(&f->scal, 4); A(&f->grad, NTH_MAX);
+  A(&f->gstage, (int64_t)GR_BLOCKS * NTH_MAX);
   if (e == hipSuccess) e = hipMalloc((void **)&f->info, sizeof(int));
   std::vector<double> hX((size_t)(Np * DPAD), 0.0);
   for (int64_t i = 0; i < N; ++i)
@@ -614,7 +635,8 @@ int gpemu_fit_destroy(gpemu_fit *f) {
   if (!f) return GPEMU_OK;
   (void)hipSetDevice(f->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
-  double *ptrs[] = {f->X, f->hp, f->K, f->Dinv, f->W, f->T, f->Kinv, f->y, f->v, f->alpha, f->gpart, f->scal, f->grad};
+  double *ptrs[] = {f->X, f->hp, f->K, f->Dinv, f->W, f->T, f->Kinv, f->y, f->v, f->alpha, f->gpart, f->scal, f->grad,
+                    f->gstage};
   for (double *p : ptrs) (void)hipFree(p);
   (void)hipFree(f->info);
   if (f->stream) (void)hipStreamDestroy(f->stream);

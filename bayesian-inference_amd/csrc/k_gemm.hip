@@ -68,14 +68,18 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
 
-  const int nk = g.K / GK;
-  if (nk > 0) {
-    gload(0);
+  // K range of this tile (whole k-tiles): triangular operands contribute nothing outside it
+  int kt0 = 0, nk = g.K / GK;
+  if (g.k_from_m) kt0 = m0 / GK;
+  if (g.k_from_n && n0 / GK > kt0) kt0 = n0 / GK;
+  if (g.k_to_m && (m0 + GT) / GK < nk) nk = (m0 + GT) / GK;
+  if (nk > kt0) {
+    gload(kt0);
     sstore(0);
   }
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int buf = (kt - kt0) & 1;
     if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
     for (int ks = 0; ks < GK / 4; ++ks) {
