@@ -345,6 +345,9 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
                 per_gp[i].append(opt)
             list(pool.map(finish, range(k_gp), per_gp))
     finally:
+        n_eval = sum(h.n_evaluations for h in handles)
         for h in handles:
             h.close()
+    for g in gprs:
+        g.n_lml_evaluations_ = n_eval          # of the whole group fit (all GPs and restarts)
     return gprs

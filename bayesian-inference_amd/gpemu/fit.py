@@ -31,6 +31,7 @@ class DeviceFit:
                                           float(nu) if np.isfinite(nu) else 0.0, int(has_const), int(has_noise),
                                           float(jitter)))
         self._h = h
+        self.n_evaluations = 0          # log-marginal-likelihood evaluations run through this handle
 
     def close(self):
         if getattr(self, "_h", None):
@@ -53,6 +54,7 @@ class DeviceFit:
         theta = as_f64(theta, (self.n_theta,))
         val = C.c_double()
         grad = np.empty(self.n_theta) if eval_gradient else None
+        self.n_evaluations += 1
         self._check(_lib.lib().gpemu_fit_lml(self._h, ptr(y), ptr(theta), self.n_theta, C.byref(val), ptr(grad)))
         return (val.value, grad) if eval_gradient else val.value
 

@@ -89,6 +89,62 @@ def measure_predict(dm, n_samples=1024, reps=5):
                          "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0}}
 
 
+def measure_fit_c5(device=0):
+    """BASELINE configs[4] ("C5": N_design = 5000, N_obs = 2000): the fit side on the device -- StandardScaler + PCA of the
+    5000 x 2000 matrix and one log-marginal-likelihood evaluation at N = 5000 (kernel matrix, blocked Cholesky with MFMA
+    SYRK trailing updates, blocked triangular inverse, alpha; with gradient: K^-1 = W^T W on the lower triangle + the
+    contraction), timed against the fp64 MFMA peak.  Algorithmic FLOPs: N^3/3 (Cholesky) + N^3/3 (inverse of the factor)
+    [+ N^3/3 (K^-1, symmetric, from the triangular W)], SURVEY.md 8d."""
+    from gpemu import estimators, synthetic
+    from gpemu.fit import DeviceFit
+    N, F = 5000, 2000
+    prob = synthetic.make_problem(N, F, seed=3)
+    t0 = time.perf_counter()
+    scaler, pca, Y_pca = estimators.scale_and_pca(prob["Y"], device=device)
+    t_pca = time.perf_counter() - t0
+    theta = np.log(np.r_[(prob["hi"] - prob["lo"]) * 0.5, 0.05])
+    fit = DeviceFit(prob["design"], kernel_kind=0, has_noise=True, jitter=1e-10, device=device)
+    y = Y_pca[:, 0]
+    out = {"workload": "C5: N_design=5000 x N_obs=2000", "pca_5000x2000_ms": t_pca * 1e3}
+    for grad in (False, True):
+        fit.lml(y, theta, eval_gradient=grad)
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fit.lml(y, theta, eval_gradient=grad)
+        dt = (time.perf_counter() - t0) / reps
+        flop = N ** 3 / 3 * (3 if grad else 2)
+        key = "lml_grad" if grad else "lml"
+        out[key + "_ms"] = dt * 1e3
+        out[key + "_roofline"] = {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": flop / dt / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                                  "algorithmic_gflop": flop / 1e9}
+    fit.close()
+    return out
+
+
+def measure_fit_c3(device=0, n_restarts=50):
+    """The whole C3 emulator fit as the shipped configuration runs it (ref: emulation.py:169-172 with
+    config/jet_substructure.yaml:80, n_restarts: 50): 10 GPs x 51 L-BFGS-B maximisations of the log-marginal
+    likelihood at N = 1000, the optimisers on host threads, every evaluation on the device."""
+    from gpemu import estimators, synthetic
+    prob = synthetic.make_problem(N_DESIGN, N_OBS, seed=0)
+    t0 = time.perf_counter()
+    scaler, pca, Y_pca = estimators.scale_and_pca(prob["Y"], device=device)
+    t_pca = time.perf_counter() - t0
+    ls0 = prob["hi"] - prob["lo"]
+    kern = estimators.ARDKernel(estimators.RBF_KIND, length_scale=ls0, length_scale_bounds=np.outer(ls0, (0.01, 100.0)),
+                                noise_level=0.1, noise_level_bounds=(1e-3, 10.0))
+    np.random.seed(2026)
+    t0 = time.perf_counter()
+    gps = estimators.fit_gps(prob["design"], Y_pca[:, :N_PC], kern, alpha=1e-10, n_restarts_optimizer=n_restarts,
+                             device=device)
+    dt = time.perf_counter() - t0
+    return {"workload": f"C3 fit: 10 GPs x (1 + {n_restarts}) L-BFGS-B runs at N_design=1000", "seconds": dt,
+            "pca_1000x500_ms": t_pca * 1e3, "lml_evaluations": int(getattr(gps[0], "n_lml_evaluations_", 0)),
+            "mean_lml": float(np.mean([g.log_marginal_likelihood_value_ for g in gps]))}
+
+
 def committed_traffic(world):
     """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_e_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied).
@@ -160,6 +216,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fit", action="store_true", help="skip the fit-side legs (fit_c5, fit_c3)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: time ONE rank's share of an N-GPU step on this GPU (world-1 RCCL gather); "
                          "the printed value is NOT a throughput claim")
@@ -255,6 +312,15 @@ def main():
         except Exception as e:
             predict = {"value": None, "error": repr(e)}
 
+    fit_c5 = fit_c3 = None
+    if rank == 0 and world == 1 and not args.no_fit and not args.emulate_world:
+        try:
+            fit_c5 = measure_fit_c5(dev_index)
+            fit_c3 = measure_fit_c3(dev_index)
+        except Exception as e:
+            fit_c5 = fit_c5 or {"error": repr(e)}
+            fit_c3 = fit_c3 or {"error": repr(e)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -273,7 +339,7 @@ def main():
                           "n_walkers": N_WALKERS, "evals_per_step": N_WALKERS,
                           "parallelism": f"walkers sharded over {world} GPU(s)"},
                "acceptance_fraction_mean": float((nacc / max(iters, 1)).mean()),
-               "roofline": roofline, "cpu_baseline": cpu, "gp_predict": predict}
+               "roofline": roofline, "cpu_baseline": cpu, "gp_predict": predict, "fit_c5": fit_c5, "fit_c3": fit_c3}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()          # rank 0 also measured metric 2 / printed; tear down together
