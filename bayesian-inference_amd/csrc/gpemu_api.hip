@@ -18,7 +18,8 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
-int launch_lik_setup(gpemu_model *m, double *dA, double *dPT, double *dZ, int *dinfo, hipStream_t st);
+int launch_lik_setup(gpemu_model *m, const std::vector<int> &hstart, double *dA, double *dPT, double *dZ, int *dinfo,
+                     hipStream_t st);
 int launch_predict_full(gpemu_model *m, int64_t B, double n_div, double *dcv, double *dcov, hipStream_t st);
 int launch_loglik_exact(gpemu_model *m, int64_t B, const double *dXq, double *dout, hipStream_t st);
 
@@ -290,7 +291,8 @@ int gpemu_model_destroy(gpemu_model *m) {
   hipFree(m->Xs); hipFree(m->inv_ls); hipFree(m->ls); hipFree(m->constv); hipFree(m->kdiag);
   hipFree(m->alpha); hipFree(m->Wt); hipFree(m->comp); hipFree(m->smean); hipFree(m->sscale);
   hipFree(m->cunexpl); hipFree(m->yexp); hipFree(m->yerr); hipFree(m->lo); hipFree(m->hi);
-  hipFree(m->G); hipFree(m->g0); hipFree(m->scal); hipFree(m->exact_scratch);
+  for (const gpemu_model::LikEntry &en : m->lik_cache) { hipFree(en.G); hipFree(en.g0); hipFree(en.scal); }
+  hipFree(m->exact_scratch);
   hipFree(m->blk_start); hipFree(m->blk_of); hipFree(m->sched_items); hipFree(m->sched_cnt);
   hipFree(m->sm_items); hipFree(m->sm_cnt);
   free_workspace(m->ws);
@@ -408,20 +410,52 @@ int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_
   const int64_t nblk = (int64_t)hstart.size() - 1;
   for (int64_t o = 0; o < nblk; ++o)
     for (int f = hstart[o]; f < hstart[o + 1]; ++f) hof[f] = (int)o;
+  // same data as the cached constants belong to?  then an n_div seen before is a pointer swap
+  std::vector<double> key;
+  key.insert(key.end(), y_exp, y_exp + F);
+  key.insert(key.end(), y_err, y_err + F);
+  key.insert(key.end(), lo, lo + m->d);
+  key.insert(key.end(), hi, hi + m->d);
+  for (int v : hstart) key.push_back((double)v);
+  const bool same_data = m->lik_ready && key.size() == m->lik_host.size() &&
+                         memcmp(key.data(), m->lik_host.data(), sizeof(double) * key.size()) == 0;
+  if (same_data) {
+    for (const gpemu_model::LikEntry &en : m->lik_cache)
+      if (en.n_div == n_div) {
+        GP_HIP(hipStreamSynchronize(st));
+        m->G = en.G; m->g0 = en.g0; m->scal = en.scal; m->n_div = n_div;
+        return GPEMU_OK;
+      }
+  } else {
+    GP_HIP(hipStreamSynchronize(st));
+    for (const gpemu_model::LikEntry &en : m->lik_cache) { (void)hipFree(en.G); (void)hipFree(en.g0); (void)hipFree(en.scal); }
+    m->lik_cache.clear();
+    m->G = m->g0 = m->scal = nullptr;
+  }
+  if (m->lik_cache.size() >= 64) {           // bounded: drop the oldest entry
+    GP_HIP(hipStreamSynchronize(st));
+    const gpemu_model::LikEntry en = m->lik_cache.front();
+    (void)hipFree(en.G); (void)hipFree(en.g0); (void)hipFree(en.scal);
+    m->lik_cache.erase(m->lik_cache.begin());
+  }
   GP_HIP(hipStreamSynchronize(st));
   if (!m->yexp) {
     GP_TRY(dev_alloc(&m->yexp, F)); GP_TRY(dev_alloc(&m->yerr, F));
     GP_TRY(dev_alloc(&m->lo, DPAD)); GP_TRY(dev_alloc(&m->hi, DPAD));
     GP_TRY(dev_alloc(&m->blk_of, F));
   }
-  (void)hipFree(m->G); (void)hipFree(m->g0); (void)hipFree(m->scal); (void)hipFree(m->blk_start);
-  m->G = m->g0 = m->scal = nullptr; m->blk_start = nullptr;
-  GP_TRY(dev_alloc(&m->G, nblk * k * k)); GP_TRY(dev_alloc(&m->g0, nblk * k));
-  GP_TRY(dev_alloc(&m->scal, 2 * nblk)); GP_TRY(dev_alloc(&m->blk_start, nblk + 1));
+  (void)hipFree(m->blk_start);
+  m->blk_start = nullptr;
+  gpemu_model::LikEntry en{n_div, nullptr, nullptr, nullptr};
+  GP_TRY(dev_alloc(&en.G, nblk * k * k)); GP_TRY(dev_alloc(&en.g0, nblk * k));
+  GP_TRY(dev_alloc(&en.scal, 2 * nblk)); GP_TRY(dev_alloc(&m->blk_start, nblk + 1));
+  m->G = en.G; m->g0 = en.g0; m->scal = en.scal;
+  m->lik_cache.push_back(en);
   m->nblk = nblk;
   GP_HIP(hipMemcpyAsync(m->blk_start, hstart.data(), sizeof(int) * (nblk + 1), hipMemcpyHostToDevice, st));
   GP_HIP(hipMemcpyAsync(m->blk_of, hof.data(), sizeof(int) * F, hipMemcpyHostToDevice, st));
   m->lik_ready = false;
+  m->lik_host.clear();
   m->n_div = n_div;
   double hlo[DPAD], hhi[DPAD];
   for (int i = 0; i < DPAD; ++i) { hlo[i] = i < m->d ? lo[i] : -INFINITY; hhi[i] = i < m->d ? hi[i] : INFINITY; }
@@ -435,7 +469,8 @@ int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_
   if (rc == GPEMU_OK) rc = dev_alloc(&dZ, F * (k + 1));
   if (rc == GPEMU_OK) rc = dev_alloc(&dinfo, nblk);
   std::vector<int> info((size_t)nblk, 0);
-  if (rc == GPEMU_OK) rc = launch_lik_setup(m, dA, dPT, dZ, dinfo, st);
+  if (rc == GPEMU_OK && hipMemsetAsync(dinfo, 0, sizeof(int) * nblk, st) != hipSuccess) rc = GPEMU_ERR_HIP;
+  if (rc == GPEMU_OK) rc = launch_lik_setup(m, hstart, dA, dPT, dZ, dinfo, st);
   if (rc == GPEMU_OK) {
     hipError_t e = hipMemcpyAsync(info.data(), dinfo, sizeof(int) * nblk, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -451,6 +486,7 @@ int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_
     }
   }
   m->lik_ready = true;
+  m->lik_host = key;
   return GPEMU_OK;
 }
 

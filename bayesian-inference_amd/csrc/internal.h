@@ -92,6 +92,12 @@ struct gpemu_model {
   // likelihood state (gpemu_likelihood_setup)
   bool lik_ready = false;
   double n_div = 1.0;
+  // the constants (G, g0, scal) depend on the data AND on n_div (the reference divides the truncation covariance by
+  // the number of in-bounds rows of each call): one entry per n_div seen with the current data, so that a batch
+  // size that comes back costs nothing.  G / g0 / scal below point into the current entry.
+  struct LikEntry { double n_div; double *G, *g0, *scal; };
+  std::vector<LikEntry> lik_cache;
+  std::vector<double> lik_host;        // y_exp | y_err | lo | hi | block starts the cache belongs to
   double *yexp = nullptr, *yerr = nullptr, *lo = nullptr, *hi = nullptr;  // [F],[F],[DPAD],[DPAD]
   int64_t nblk = 1;            // observable blocks of the (block-diagonal) covariance
   int *blk_start = nullptr;    // [nblk+1] first feature of each block
@@ -155,7 +161,10 @@ int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq_padded, d
                           int accumulate, hipStream_t st, const AcceptArgs *aa = nullptr);
 int logpost_padded(gpemu_model *m, int64_t B, double *dXq, double *dout, int accumulate,
                    hipStream_t st, const AcceptArgs *aa = nullptr, const ProposeArgs *pa = nullptr);
-// fit-side building blocks (k_fit.hip)
+// fit-side building blocks (k_fit.hip): in-place blocked Cholesky of an Np x Np matrix (Np multiple of 64) with the
+// inverted diagonal blocks in Dinv [Np/64][64][64], and W = L^-1 from it (T: Np x Np scratch)
+int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hipStream_t st);
+int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double *W, double *T, hipStream_t st);
 int device_invert_factor_to_Wt(const double *dL, int64_t N, double *Wt, int64_t Npad, double *A, double *Dinv,
                                double *W, double *T, hipStream_t st);
 // profiling helpers: record an event on `st` and return its pool index (-1 when profiling is off)

@@ -14,6 +14,8 @@
 // covariance (ref: emulation.py:370-388, SortEmulationGroupObservables.convert + nd_block_diag), so
 // Sigma is block diagonal over the observables of the group and the likelihood is a sum over
 // blocks o, each of the form above with its own (G_o, g0_o, q0_o, logdet A_o) and the same m, var.
+#include <algorithm>
+
 #include "internal.h"
 #include "linalg_dev.h"
 #include "loglik_dev.h"
@@ -37,10 +39,11 @@ __global__ void build_A_kernel(const double *__restrict__ cun, const double *__r
 __global__ __launch_bounds__(CHOL_THREADS) void lik_setup_kernel(
     double *A, double *PT, double *Z /*[F][k+1]*/, const double *__restrict__ comp,
     const double *__restrict__ s, const double *__restrict__ smean, const double *__restrict__ yexp,
-    const int *__restrict__ blk_start, double *G, double *g0, double *scal, int F, int k, int *info) {
+    const int *__restrict__ blk_start, double *G, double *g0, double *scal, int F, int k, int *info, int max_nf) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int o = blockIdx.x;
   const int f0 = blk_start[o], nf = blk_start[o + 1] - f0;
+  if (nf > max_nf) return;       // large blocks go through the blocked path (launch_lik_setup)
   const int k1 = k + 1;
   double *Ao = A + (int64_t)f0 * F + f0;
   double *Zo = Z + (int64_t)f0 * k1;
@@ -65,16 +68,102 @@ __global__ __launch_bounds__(CHOL_THREADS) void lik_setup_kernel(
   if (tid == 0) scal[2 * o + 1] = 2.0 * ld;
 }
 
-int launch_lik_setup(gpemu_model *m, double *dA, double *dPT, double *dZ, int *dinfo, hipStream_t st) {
-  const int F = (int)m->F;
+// ---- large observable blocks: blocked MFMA Cholesky + triangular inverse instead of one workgroup ------------
+constexpr int LIK_BLOCKED_MIN = 256;   // blocks up to this many features stay with the single-workgroup kernel
+
+// Ab[Np][Np] = A_o (lower triangle) padded with the identity
+__global__ void lik_pad_block_kernel(const double *__restrict__ A, int ld, int nf, double *__restrict__ Ab, int Np) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c >= Np) return;
+  double v = 0.0;
+  if (r < nf && c <= r) v = A[(int64_t)r * ld + c];
+  else if (r >= nf && c == r) v = 1.0;
+  Ab[(int64_t)r * Np + c] = v;
+}
+
+// Z[i][c] = sum_{j <= i} W[i][j] R[j][c],  R = [U_o | r0_o]  (nf x (k+1)); one wave per row i, lanes over j
+__global__ __launch_bounds__(256) void lik_z_kernel(const double *__restrict__ W, int Np, int nf, int f0, int F, int k,
+                                                    const double *__restrict__ comp, const double *__restrict__ s,
+                                                    const double *__restrict__ smean, const double *__restrict__ yexp,
+                                                    double *__restrict__ Z) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= nf) return;
+  const int k1 = k + 1;
+  for (int c = 0; c < k1; ++c) {
+    double acc = 0.0;
+    for (int j = lane; j <= i; j += 64) {
+      const int f = f0 + j;
+      const double r = (c < k) ? s[f] * comp[(int64_t)c * F + f] : (smean[f] - yexp[f]);
+      acc = fma(W[(int64_t)i * Np + j], r, acc);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) Z[(int64_t)(f0 + i) * k1 + c] = acc;
+  }
+}
+
+// G_o = Zu^T Zu, g0_o = Zu^T zr, q0_o = zr^T zr, logdet A_o = 2 sum log diag C: one workgroup
+__global__ __launch_bounds__(1024) void lik_gram_kernel(const double *__restrict__ Z, const double *__restrict__ Lb, int Np,
+                                                        int nf, int f0, int k, int o, double *G, double *g0, double *scal) {
+  const int tid = threadIdx.x, k1 = k + 1;
+  const double *Zo = Z + (int64_t)f0 * k1;
+  for (int idx = tid; idx < k1 * k1; idx += 1024) {
+    const int p = idx / k1, q = idx - p * k1;
+    double acc = 0.0;
+    for (int f = 0; f < nf; ++f) acc = fma(Zo[(int64_t)f * k1 + p], Zo[(int64_t)f * k1 + q], acc);
+    if (p < k && q < k) G[((int64_t)o * k + p) * k + q] = acc;
+    else if (p < k && q == k) g0[(int64_t)o * k + p] = acc;
+    else if (p == k && q == k) scal[2 * o] = acc;
+  }
+  double ld = 0.0;
+  for (int f = tid; f < nf; f += 1024) ld += log(Lb[(int64_t)f * Np + f]);
+  ld = wg_sum(ld);
+  if (tid == 0) scal[2 * o + 1] = 2.0 * ld;
+}
+
+// hstart: the observable block boundaries (host copy).  Small blocks: one workgroup each (lik_setup_kernel, all of
+// them in one launch, larger ones skipped); blocks of more than LIK_BLOCKED_MIN features: blocked Cholesky with MFMA
+// trailing updates, W = C^-1 by the blocked triangular inverse, Z = W [U | r0].
+int launch_lik_setup(gpemu_model *m, const std::vector<int> &hstart, double *dA, double *dPT, double *dZ, int *dinfo,
+                     hipStream_t st) {
+  const int F = (int)m->F, k = (int)m->k;
   int64_t n = (int64_t)F * F;
   hipLaunchKernelGGL(build_A_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->cunexpl,
                      m->sscale, m->yerr, dA, F, 1.0 / m->n_div);
   hipLaunchKernelGGL(lik_setup_kernel, dim3((unsigned)m->nblk), dim3(CHOL_THREADS), 0, st, dA, dPT, dZ,
                      m->comp, m->sscale, m->smean, m->yexp, m->blk_start, m->G, m->g0, m->scal, F,
-                     (int)m->k, dinfo);
+                     k, dinfo, LIK_BLOCKED_MIN);
   GP_HIP(hipGetLastError());
-  return GPEMU_OK;
+  int64_t maxnp = 0;
+  for (size_t o = 0; o + 1 < hstart.size(); ++o) {
+    const int nf = hstart[o + 1] - hstart[o];
+    if (nf > LIK_BLOCKED_MIN) maxnp = std::max<int64_t>(maxnp, round_up(nf, 64));
+  }
+  if (maxnp == 0) return GPEMU_OK;
+  double *Ab = nullptr, *Dinv = nullptr, *W = nullptr, *T = nullptr;
+  hipError_t e = hipMalloc((void **)&Ab, sizeof(double) * maxnp * maxnp);
+  if (e == hipSuccess) e = hipMalloc((void **)&Dinv, sizeof(double) * maxnp * 64);
+  if (e == hipSuccess) e = hipMalloc((void **)&W, sizeof(double) * maxnp * maxnp);
+  if (e == hipSuccess) e = hipMalloc((void **)&T, sizeof(double) * maxnp * maxnp);
+  int rc = GPEMU_OK;
+  if (e != hipSuccess) { set_error("likelihood_setup: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
+  for (size_t o = 0; o + 1 < hstart.size() && rc == GPEMU_OK; ++o) {
+    const int f0 = hstart[o], nf = hstart[o + 1] - f0;
+    if (nf <= LIK_BLOCKED_MIN) continue;
+    const int Np = (int)round_up(nf, 64);
+    hipLaunchKernelGGL(lik_pad_block_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)Np), dim3(256), 0, st,
+                       dA + (int64_t)f0 * F + f0, F, nf, Ab, Np);
+    rc = device_cholesky_blocked(Ab, Np, Dinv, dinfo + o, st);
+    if (rc == GPEMU_OK) rc = device_trtri_blocked(Ab, Np, Dinv, W, T, st);
+    if (rc != GPEMU_OK) break;
+    hipLaunchKernelGGL(lik_z_kernel, dim3((unsigned)((nf + 3) / 4)), dim3(256), 0, st, W, Np, nf, f0, F, k, m->comp,
+                       m->sscale, m->smean, m->yexp, dZ);
+    hipLaunchKernelGGL(lik_gram_kernel, dim3(1), dim3(1024), 0, st, dZ, Ab, Np, nf, f0, k, (int)o, m->G, m->g0, m->scal);
+    if (hipGetLastError() != hipSuccess) { set_error("likelihood_setup: launch failed"); rc = GPEMU_ERR_HIP; }
+  }
+  if (rc == GPEMU_OK && hipStreamSynchronize(st) != hipSuccess) { set_error("likelihood_setup: sync failed"); rc = GPEMU_ERR_HIP; }
+  (void)hipFree(Ab); (void)hipFree(Dinv); (void)hipFree(W); (void)hipFree(T);
+  return rc;
 }
 
 // k <= KMAX <= 16.  The k x k matrix M = I + D^1/2 G D^1/2 is padded to KMAX x KMAX with the identity, so

@@ -277,3 +277,38 @@ def test_fused_run_world1_equals_three_launch_run():
     np.testing.assert_array_equal(a.get_chain()[0], b.get_chain()[0])
     a.close(); b.close()
     dm.close()
+
+
+def test_device_sampler_posterior_moments_vs_host_stretch_move():
+    """Statistical check of the device sampler beyond step equality: the posterior of the G1 emulator sampled (a) by
+    the device sampler (Philox randomness, fused kernels) and (b) by the host stretch move -- an independent
+    implementation on numpy's RandomState in emcee's draw order -- fed the device log-posterior as a black box.
+    Means agree to a fraction of the posterior width, variances to 25 %, acceptance fractions alike."""
+    from gpemu import synthetic
+    from gpemu.sampler import DeviceSampler, HostEnsemble
+    g, model, dm, _ = _setup()
+    W, burn, steps = 64, 600, 5000
+    X0 = synthetic.make_walkers(W, seed=21, lo=g["lo"], hi=g["hi"])
+    ds = DeviceSampler([dm], W, seed=2024)
+    ds.set_state(X0)
+    ds.run(burn, store=False)
+    ds.run(steps)
+    cd, _ = ds.get_chain()
+    nacc, it, _ = ds.counts()
+    he = HostEnsemble(W, dm.d, lambda q: dm.logpost(np.ascontiguousarray(q)), seed=77)
+    he.set_state(X0)
+    he.run(burn, store=False)
+    he.run(steps)
+    ch = np.stack(he.chain)
+    fd, fh = cd.reshape(-1, dm.d), ch.reshape(-1, dm.d)
+    sd = fh.std(axis=0)
+    assert np.all(np.abs(fd.mean(axis=0) - fh.mean(axis=0)) < 0.1 * sd), (fd.mean(0), fh.mean(0), sd)
+    assert np.all(np.abs(fd.std(axis=0) / sd - 1.0) < 0.25)
+    # two-sample comparison of the marginal quantiles (10 %, 50 %, 90 %)
+    qd, qh = np.quantile(fd, [0.1, 0.5, 0.9], axis=0), np.quantile(fh, [0.1, 0.5, 0.9], axis=0)
+    assert np.all(np.abs(qd - qh) < 0.15 * sd)
+    af_d = (nacc / it).mean()
+    af_h = (he.naccepted / he.iterations).mean()
+    assert abs(af_d - af_h) < 0.05 and 0.1 < af_d < 0.9
+    ds.close()
+    dm.close()
