@@ -391,8 +391,16 @@ int gpemu_gp_predict(gpemu_model *m, int64_t B, const double *X, double *mean_ou
 int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_err,
                            const double *lo, const double *hi, double n_div, int64_t n_blocks,
                            const int64_t *block_start) {
+  return gpemu_likelihood_setup_chains(m, 1, y_exp, y_err, lo, hi, n_div, n_blocks, block_start);
+}
+
+int gpemu_likelihood_setup_chains(gpemu_model *m, int n_chains, const double *y_exp, const double *y_err,
+                                  const double *lo, const double *hi, double n_div, int64_t n_blocks,
+                                  const int64_t *block_start) {
   GP_ARG(m && y_exp && y_err && lo && hi, "null pointer");
   GP_ARG(n_div >= 1.0, "n_div must be >= 1");
+  GP_ARG(n_chains >= 1 && n_chains <= 4096, "n_chains must be in [1, 4096]");
+  const int64_t NC = n_chains;
   GP_HIP(hipSetDevice(m->device));
   hipStream_t st = m->stream;
   const int64_t F = m->F, k = m->k;
@@ -412,7 +420,8 @@ int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_
     for (int f = hstart[o]; f < hstart[o + 1]; ++f) hof[f] = (int)o;
   // same data as the cached constants belong to?  then an n_div seen before is a pointer swap
   std::vector<double> key;
-  key.insert(key.end(), y_exp, y_exp + F);
+  key.push_back((double)NC);
+  key.insert(key.end(), y_exp, y_exp + NC * F);
   key.insert(key.end(), y_err, y_err + F);
   key.insert(key.end(), lo, lo + m->d);
   key.insert(key.end(), hi, hi + m->d);
@@ -439,16 +448,20 @@ int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_
     m->lik_cache.erase(m->lik_cache.begin());
   }
   GP_HIP(hipStreamSynchronize(st));
-  if (!m->yexp) {
-    GP_TRY(dev_alloc(&m->yexp, F)); GP_TRY(dev_alloc(&m->yerr, F));
+  if (!m->yerr) {
+    GP_TRY(dev_alloc(&m->yerr, F));
     GP_TRY(dev_alloc(&m->lo, DPAD)); GP_TRY(dev_alloc(&m->hi, DPAD));
     GP_TRY(dev_alloc(&m->blk_of, F));
   }
+  (void)hipFree(m->yexp);
+  m->yexp = nullptr;
+  GP_TRY(dev_alloc(&m->yexp, NC * F));
+  m->lik_chains = n_chains;
   (void)hipFree(m->blk_start);
   m->blk_start = nullptr;
   gpemu_model::LikEntry en{n_div, nullptr, nullptr, nullptr};
-  GP_TRY(dev_alloc(&en.G, nblk * k * k)); GP_TRY(dev_alloc(&en.g0, nblk * k));
-  GP_TRY(dev_alloc(&en.scal, 2 * nblk)); GP_TRY(dev_alloc(&m->blk_start, nblk + 1));
+  GP_TRY(dev_alloc(&en.G, nblk * k * k)); GP_TRY(dev_alloc(&en.g0, NC * nblk * k));
+  GP_TRY(dev_alloc(&en.scal, NC * 2 * nblk)); GP_TRY(dev_alloc(&m->blk_start, nblk + 1));
   m->G = en.G; m->g0 = en.g0; m->scal = en.scal;
   m->lik_cache.push_back(en);
   m->nblk = nblk;
@@ -459,14 +472,14 @@ int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_
   m->n_div = n_div;
   double hlo[DPAD], hhi[DPAD];
   for (int i = 0; i < DPAD; ++i) { hlo[i] = i < m->d ? lo[i] : -INFINITY; hhi[i] = i < m->d ? hi[i] : INFINITY; }
-  GP_TRY(upload(m->yexp, y_exp, F, st)); GP_TRY(upload(m->yerr, y_err, F, st));
+  GP_TRY(upload(m->yexp, y_exp, NC * F, st)); GP_TRY(upload(m->yerr, y_err, F, st));
   GP_TRY(upload(m->lo, hlo, DPAD, st)); GP_TRY(upload(m->hi, hhi, DPAD, st));
   GP_HIP(hipStreamSynchronize(st));  // hlo/hhi are stack buffers
   double *dA = nullptr, *dPT = nullptr, *dZ = nullptr;
   int *dinfo = nullptr;
   int rc = dev_alloc(&dA, F * F);
   if (rc == GPEMU_OK) rc = dev_alloc(&dPT, nblk * chol_scratch_size(F));
-  if (rc == GPEMU_OK) rc = dev_alloc(&dZ, F * (k + 1));
+  if (rc == GPEMU_OK) rc = dev_alloc(&dZ, F * (k + NC));
   if (rc == GPEMU_OK) rc = dev_alloc(&dinfo, nblk);
   std::vector<int> info((size_t)nblk, 0);
   if (rc == GPEMU_OK && hipMemsetAsync(dinfo, 0, sizeof(int) * nblk, st) != hipSuccess) rc = GPEMU_ERR_HIP;

@@ -92,6 +92,8 @@ struct gpemu_model {
   // likelihood state (gpemu_likelihood_setup)
   bool lik_ready = false;
   double n_div = 1.0;
+  int lik_chains = 1;          // data vectors the likelihood was set up for (one per chain of a multi-chain sampler)
+  int64_t variant_B = 0;       // if > 0: pick the kernel variants as for a batch of this size (sampler with several chains)
   // the constants (G, g0, scal) depend on the data AND on n_div (the reference divides the truncation covariance by
   // the number of in-bounds rows of each call): one entry per n_div seen with the current data, so that a batch
   // size that comes back costs nothing.  G / g0 / scal below point into the current entry.
@@ -134,6 +136,10 @@ struct AcceptArgs {
   int *flags = nullptr;           // [1] NaN counter
   double *chain = nullptr;        // [W][d] row of this step, or null
   double *lpchain = nullptr;      // [W]
+  // several chains stacked in one batch: row b of the launch is row first + b of the stacked list, which holds
+  // chain_per rows per chain; 0 = one chain.  Selects the chain's data constants (g0, q0) in the likelihood.
+  int chain_per = 0;
+  int64_t first = 0;
 };
 
 // optional fused stretch-move proposal: kstar_kernel builds its query rows from the ensemble

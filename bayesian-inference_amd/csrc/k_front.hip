@@ -346,7 +346,7 @@ void front_release(gpemu_sampler *s) {
 
 bool front_eligible(const gpemu_sampler *s) {
   static const bool off = getenv("GPEMU_NO_FUSED") != nullptr;
-  if (off || s->groups.size() != 1) return false;
+  if (off || s->groups.size() != 1 || s->nchains != 1) return false;
   const gpemu_model *m = s->groups[0];
   if (m->k > 16 || s->W > 2048) return false;       // every workgroup of a launch must be resident (they wait on each other)
   return true;

@@ -39,33 +39,37 @@ __global__ void build_A_kernel(const double *__restrict__ cun, const double *__r
 __global__ __launch_bounds__(CHOL_THREADS) void lik_setup_kernel(
     double *A, double *PT, double *Z /*[F][k+1]*/, const double *__restrict__ comp,
     const double *__restrict__ s, const double *__restrict__ smean, const double *__restrict__ yexp,
-    const int *__restrict__ blk_start, double *G, double *g0, double *scal, int F, int k, int *info, int max_nf) {
+    const int *__restrict__ blk_start, double *G, double *g0, double *scal, int F, int k, int *info, int max_nf,
+    int nch) {
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int o = blockIdx.x;
+  const int o = blockIdx.x, nblk = gridDim.x;
   const int f0 = blk_start[o], nf = blk_start[o + 1] - f0;
   if (nf > max_nf) return;       // large blocks go through the blocked path (launch_lik_setup)
-  const int k1 = k + 1;
+  const int k1 = k + nch;
   double *Ao = A + (int64_t)f0 * F + f0;
   double *Zo = Z + (int64_t)f0 * k1;
   double *PTo = PT + (int64_t)o * chol_scratch_size(F);
   for (int idx = tid; idx < nf * k1; idx += nthr) {
     int f = f0 + idx / k1, p = idx % k1;
-    Zo[idx] = (p < k) ? s[f] * comp[(int64_t)p * F + f] : (smean[f] - yexp[f]);
+    Zo[idx] = (p < k) ? s[f] * comp[(int64_t)p * F + f] : (smean[f] - yexp[(int64_t)(p - k) * F + f]);
   }
   wg_cholesky_lower(Ao, nf, F, PTo, info + o);
-  wg_forward_solve_multi(Ao, nf, F, Zo, k1, k1);
+  for (int c0 = 0; c0 < k1; c0 += nthr)        // one thread per right-hand side
+    wg_forward_solve_multi(Ao, nf, F, Zo + c0, k1, (k1 - c0 < nthr) ? (k1 - c0) : nthr);
   for (int idx = tid; idx < k1 * k1; idx += nthr) {
     int p = idx / k1, q = idx - p * k1;
+    const bool wanted = (p < k && q < k) || (p < k && q >= k) || (p == q);
+    if (!wanted) continue;
     double acc = 0.0;
     for (int f = 0; f < nf; ++f) acc = fma(Zo[(int64_t)f * k1 + p], Zo[(int64_t)f * k1 + q], acc);
     if (p < k && q < k) G[((int64_t)o * k + p) * k + q] = acc;
-    else if (p < k && q == k) g0[(int64_t)o * k + p] = acc;
-    else if (p == k && q == k) scal[2 * o] = acc;
+    else if (p < k) g0[((int64_t)(q - k) * nblk + o) * k + p] = acc;
+    else scal[((int64_t)(p - k) * nblk + o) * 2] = acc;
   }
   double ld = 0.0;
   for (int f = tid; f < nf; f += nthr) ld += log(Ao[(int64_t)f * F + f]);
   ld = wg_sum(ld);
-  if (tid == 0) scal[2 * o + 1] = 2.0 * ld;
+  if (tid < nch) scal[((int64_t)tid * nblk + o) * 2 + 1] = 2.0 * ld;
 }
 
 // ---- large observable blocks: blocked MFMA Cholesky + triangular inverse instead of one workgroup ------------
@@ -85,16 +89,16 @@ __global__ void lik_pad_block_kernel(const double *__restrict__ A, int ld, int n
 __global__ __launch_bounds__(256) void lik_z_kernel(const double *__restrict__ W, int Np, int nf, int f0, int F, int k,
                                                     const double *__restrict__ comp, const double *__restrict__ s,
                                                     const double *__restrict__ smean, const double *__restrict__ yexp,
-                                                    double *__restrict__ Z) {
+                                                    double *__restrict__ Z, int nch) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= nf) return;
-  const int k1 = k + 1;
+  const int k1 = k + nch;
   for (int c = 0; c < k1; ++c) {
     double acc = 0.0;
     for (int j = lane; j <= i; j += 64) {
       const int f = f0 + j;
-      const double r = (c < k) ? s[f] * comp[(int64_t)c * F + f] : (smean[f] - yexp[f]);
+      const double r = (c < k) ? s[f] * comp[(int64_t)c * F + f] : (smean[f] - yexp[(int64_t)(c - k) * F + f]);
       acc = fma(W[(int64_t)i * Np + j], r, acc);
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
@@ -104,21 +108,24 @@ __global__ __launch_bounds__(256) void lik_z_kernel(const double *__restrict__ W
 
 // G_o = Zu^T Zu, g0_o = Zu^T zr, q0_o = zr^T zr, logdet A_o = 2 sum log diag C: one workgroup
 __global__ __launch_bounds__(1024) void lik_gram_kernel(const double *__restrict__ Z, const double *__restrict__ Lb, int Np,
-                                                        int nf, int f0, int k, int o, double *G, double *g0, double *scal) {
-  const int tid = threadIdx.x, k1 = k + 1;
+                                                        int nf, int f0, int k, int o, double *G, double *g0, double *scal,
+                                                        int nch, int nblk) {
+  const int tid = threadIdx.x, k1 = k + nch;
   const double *Zo = Z + (int64_t)f0 * k1;
   for (int idx = tid; idx < k1 * k1; idx += 1024) {
     const int p = idx / k1, q = idx - p * k1;
+    const bool wanted = (p < k && q < k) || (p < k && q >= k) || (p == q);
+    if (!wanted) continue;
     double acc = 0.0;
     for (int f = 0; f < nf; ++f) acc = fma(Zo[(int64_t)f * k1 + p], Zo[(int64_t)f * k1 + q], acc);
     if (p < k && q < k) G[((int64_t)o * k + p) * k + q] = acc;
-    else if (p < k && q == k) g0[(int64_t)o * k + p] = acc;
-    else if (p == k && q == k) scal[2 * o] = acc;
+    else if (p < k) g0[((int64_t)(q - k) * nblk + o) * k + p] = acc;
+    else scal[((int64_t)(p - k) * nblk + o) * 2] = acc;
   }
   double ld = 0.0;
   for (int f = tid; f < nf; f += 1024) ld += log(Lb[(int64_t)f * Np + f]);
   ld = wg_sum(ld);
-  if (tid == 0) scal[2 * o + 1] = 2.0 * ld;
+  if (tid < nch) scal[((int64_t)tid * nblk + o) * 2 + 1] = 2.0 * ld;
 }
 
 // hstart: the observable block boundaries (host copy).  Small blocks: one workgroup each (lik_setup_kernel, all of
@@ -132,7 +139,7 @@ int launch_lik_setup(gpemu_model *m, const std::vector<int> &hstart, double *dA,
                      m->sscale, m->yerr, dA, F, 1.0 / m->n_div);
   hipLaunchKernelGGL(lik_setup_kernel, dim3((unsigned)m->nblk), dim3(CHOL_THREADS), 0, st, dA, dPT, dZ,
                      m->comp, m->sscale, m->smean, m->yexp, m->blk_start, m->G, m->g0, m->scal, F,
-                     k, dinfo, LIK_BLOCKED_MIN);
+                     k, dinfo, LIK_BLOCKED_MIN, m->lik_chains);
   GP_HIP(hipGetLastError());
   int64_t maxnp = 0;
   for (size_t o = 0; o + 1 < hstart.size(); ++o) {
@@ -157,8 +164,9 @@ int launch_lik_setup(gpemu_model *m, const std::vector<int> &hstart, double *dA,
     if (rc == GPEMU_OK) rc = device_trtri_blocked(Ab, Np, Dinv, W, T, st);
     if (rc != GPEMU_OK) break;
     hipLaunchKernelGGL(lik_z_kernel, dim3((unsigned)((nf + 3) / 4)), dim3(256), 0, st, W, Np, nf, f0, F, k, m->comp,
-                       m->sscale, m->smean, m->yexp, dZ);
-    hipLaunchKernelGGL(lik_gram_kernel, dim3(1), dim3(1024), 0, st, dZ, Ab, Np, nf, f0, k, (int)o, m->G, m->g0, m->scal);
+                       m->sscale, m->smean, m->yexp, dZ, m->lik_chains);
+    hipLaunchKernelGGL(lik_gram_kernel, dim3(1), dim3(1024), 0, st, dZ, Ab, Np, nf, f0, k, (int)o, m->G, m->g0, m->scal,
+                       m->lik_chains, (int)m->nblk);
     if (hipGetLastError() != hipSuccess) { set_error("likelihood_setup: launch failed"); rc = GPEMU_ERR_HIP; }
   }
   if (rc == GPEMU_OK && hipStreamSynchronize(st) != hipSuccess) { set_error("likelihood_setup: sync failed"); rc = GPEMU_ERR_HIP; }
@@ -181,6 +189,11 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
   const int wave = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * 4 + wave;
   if (b >= B) return;  // whole wave exits together; no workgroup barriers below
+  if (aa.chain_per) {  // several chains stacked: this row's chain selects the data constants
+    const int64_t ch = (aa.first + b) / aa.chain_per;
+    g0 += ch * nblk * k;
+    scal += ch * 2 * nblk;
+  }
 
   // everything that does not depend on the GP stage is requested first: the accept operands (a dependent
   // index -> state chain) and the first observable block's constants
@@ -214,6 +227,11 @@ __global__ __launch_bounds__(256) void loglik_lowrank_lds_kernel(
   const int wave = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * 4 + wave;
   if (b >= B) return;
+  if (aa.chain_per) {
+    const int64_t ch = (aa.first + b) / aa.chain_per;
+    g0 += ch * nblk * k;
+    scal += ch * 2 * nblk;
+  }
   double *M = smem + (size_t)wave * k * (k + 1);
   const int ldm = k + 1;
   bool in = true;

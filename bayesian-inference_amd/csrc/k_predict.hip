@@ -158,7 +158,8 @@ int launch_kstar(gpemu_model *m, int64_t B, double *dXq, hipStream_t st, const P
   // only the column tiles that hold real queries; the rows of dXq up to round_up(B, TILE) must be
   // finite (pad_queries_kernel / the sampler's proposal buffer zero them)
   Workspace &w = m->ws;
-  const bool small = B <= 256;                       // few columns: more, shorter workgroups
+  const int64_t Bv = m->variant_B > 0 ? m->variant_B : B;   // a chain stacked with others is evaluated as it would be alone
+  const bool small = Bv <= 256;                      // few columns: more, shorter workgroups
   static const int big_rpw = getenv("GPEMU_KSTAR_RPW") ? atoi(getenv("GPEMU_KSTAR_RPW")) : 32;
   const int rows_per_wg = small ? 32 : 4 * big_rpw;
   w.cur_nchunk = (int)(m->Npad / rows_per_wg);
@@ -911,11 +912,16 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
   Workspace &w = m->ws;
   static const int smallb_max = getenv("GPEMU_SMALLB_MAX") ? atoi(getenv("GPEMU_SMALLB_MAX")) : 128;
   static const bool old_smallb = getenv("GPEMU_TRMM_OLD_SMALLB") != nullptr;
-  if (B <= smallb_max && !old_smallb) {   // small batch: persistent 32 x 32 items, LDS-direct loads (k_trmm_small.hip)
+  const int64_t Bv = m->variant_B > 0 ? m->variant_B : B;   // a chain stacked with others is evaluated as it would be alone
+  if (Bv <= smallb_max && !old_smallb) {  // small batch: persistent 32 x 32 items, operands straight into registers
     const int rc = launch_trmm_vsq_small(m, B, st);
     if (rc != GPEMU_ERR_UNSUPPORTED) return rc;
+    if (m->variant_B > 0) {
+      set_error("stacked chains: the small-batch triangular GEMM cannot take %lld columns", (long long)B);
+      return rc;
+    }
   }
-  if (B <= smallb_max) {   // general small-batch form: 32 x 64 items with the K range split inside the workgroup (at 129..256
+  if (Bv <= smallb_max && m->variant_B == 0) {   // general small-batch form: 32 x 64 items with the K range split inside the workgroup (at 129..256
                            // rows the persistent kernel with every item halved is faster: 69 us vs 81 us)
     const int nrb32 = (int)(m->Npad / SB_TM);
     const int ncb64 = (int)(round_up(B, SB_TN) / SB_TN);

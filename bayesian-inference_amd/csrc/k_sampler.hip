@@ -57,14 +57,19 @@ __host__ __device__ static inline double u01_from(uint32_t hi, uint32_t lo) {
 namespace gpemu {
 
 // ---- kernels ------------------------------------------------------------------------------------
-// One workgroup per step (grid = steps generated ahead): random balanced split (rank of W random
+// One workgroup per (step, chain) (grid = steps generated ahead x chains): random balanced split (rank of W random
 // keys by counting), set member lists (ballot prefix sums), and the step's zz / rint / log u draws
 // for both halves.  Step s writes slot s % RNG_RING of the ring buffers.
+// Several independent chains (closure tests, ref: steer_analysis.py:168-183) share one sampler: chain c owns walkers
+// c W .. c W + W - 1 of the Wt = C W stacked ones and proposals c n_h .. of each half's C n_h; its draws depend only
+// on its own seed and on LOCAL indices, so it is the chain a one-chain sampler with that seed produces.  Stored
+// walker / proposal indices are global (offset by the chain), which is all the evaluation kernels see.
 
 __global__ __launch_bounds__(1024) void rng_step_kernel(int *inds_r, int *idx_r, double *zz_r,
                                                         double *logu_r, int *rint_r, double *fac_r, int *pos_r,
-                                                        int W, int n0, int n1, int d, double a, uint32_t k0,
-                                                        uint32_t k1, unsigned long long step0) {
+                                                        int W, int n0, int n1, int d, double a,
+                                                        const unsigned long long *__restrict__ seeds, int Wt,
+                                                        unsigned long long step0) {
   extern __shared__ unsigned long long keys[];  // [W]
   __shared__ int wcnt[2][16];
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -72,13 +77,17 @@ __global__ __launch_bounds__(1024) void rng_step_kernel(int *inds_r, int *idx_r,
   const unsigned long long step = step0 + blockIdx.x;
   const uint32_t step_lo = (uint32_t)step, step_hi = (uint32_t)(step >> 32);
   const int slot = (int)(step % RNG_RING);
-  int *inds = inds_r + (size_t)slot * W;
-  int *idx = idx_r + (size_t)slot * 2 * W;
-  double *zz = zz_r + (size_t)slot * 2 * W;
-  double *logu = logu_r + (size_t)slot * 2 * W;
-  int *rint = rint_r + (size_t)slot * 2 * W;
-  double *fac = fac_r + (size_t)slot * 2 * W;
-  int *pos = pos_r + (size_t)slot * W;
+  const int ch = blockIdx.y;
+  const uint32_t k0 = (uint32_t)seeds[ch], k1 = (uint32_t)(seeds[ch] >> 32);
+  const int woff = ch * W;                         // first walker of this chain
+  const int poff[2] = {ch * n0, ch * n1};          // first proposal of this chain in each half
+  int *inds = inds_r + (size_t)slot * Wt + woff;
+  int *idx = idx_r + (size_t)slot * 2 * Wt;        // [2][Wt], half h at h * Wt
+  double *zz = zz_r + (size_t)slot * 2 * Wt;
+  double *logu = logu_r + (size_t)slot * 2 * Wt;
+  int *rint = rint_r + (size_t)slot * 2 * Wt;
+  double *fac = fac_r + (size_t)slot * 2 * Wt;
+  int *pos = pos_r + (size_t)slot * Wt + woff;
 
   for (int w = tid; w < W; w += nthr) {
     u32x4 r = philox4x32_10(u32x4{(uint32_t)w, 0u, step_lo, step_hi}, k0, k1);
@@ -107,8 +116,8 @@ __global__ __launch_bounds__(1024) void rng_step_kernel(int *inds_r, int *idx_r,
       if (v < wave) { off0 += wcnt[0][v]; off1 += wcnt[1][v]; }
       tot0 += wcnt[0][v]; tot1 += wcnt[1][v];
     }
-    if (sp == 0) { const int i = off0 + __popcll(b0 & lt); idx[i] = w; pos[w] = i; }
-    if (sp == 1) { const int i = off1 + __popcll(b1 & lt); idx[W + i] = w; pos[w] = i; }
+    if (sp == 0) { const int i = poff[0] + off0 + __popcll(b0 & lt); idx[i] = woff + w; pos[w] = i; }
+    if (sp == 1) { const int i = poff[1] + off1 + __popcll(b1 & lt); idx[Wt + i] = woff + w; pos[w] = i; }
     base0 += tot0; base1 += tot1;
     __syncthreads();
   }
@@ -120,13 +129,14 @@ __global__ __launch_bounds__(1024) void rng_step_kernel(int *inds_r, int *idx_r,
       double u = u01_from(r.x, r.y);
       double t = (a - 1.0) * u + 1.0;
       const double z = t * t / a;
-      zz[h * W + i] = z;
-      fac[h * W + i] = (d - 1.0) * log(z);     // emcee moves/stretch.py: factors = (ndim - 1) * log(zz)
+      const size_t o = (size_t)h * Wt + poff[h] + i;
+      zz[o] = z;
+      fac[o] = (d - 1.0) * log(z);             // emcee moves/stretch.py: factors = (ndim - 1) * log(zz)
       // partner = member `randint(nc)` of the complementary set, stored as a walker index so that the
       // consumers need one dependent load less (the set lists of this step are complete: barrier above)
       const int rpos = (int)(((unsigned long long)r.z * (unsigned long long)nc) >> 32);
-      rint[h * W + i] = idx[(1 - h) * W + rpos];
-      logu[h * W + i] = log(u01_from(r2.x, r2.y));
+      rint[o] = idx[(size_t)(1 - h) * Wt + poff[1 - h] + rpos];
+      logu[o] = log(u01_from(r2.x, r2.y));
     }
   }
 }
@@ -224,10 +234,11 @@ static int ensure_chain(gpemu_sampler *s, int64_t need) {
 }
 
 static int launch_rng_batch(gpemu_sampler *s, hipStream_t st, uint64_t first, int64_t n) {
-  size_t shm = sizeof(unsigned long long) * s->W;
-  hipLaunchKernelGGL(rng_step_kernel, dim3((unsigned)n), dim3(1024), shm, st, s->inds, s->idx, s->zz,
-                     s->logu, s->rint, s->fac, s->pos, (int)s->W, (int)s->ns[0], (int)s->ns[1], (int)s->d, s->a,
-                     (uint32_t)s->seed, (uint32_t)(s->seed >> 32), (unsigned long long)first);
+  const int C = s->nchains, Wc = (int)(s->W / C);
+  size_t shm = sizeof(unsigned long long) * Wc;
+  hipLaunchKernelGGL(rng_step_kernel, dim3((unsigned)n, (unsigned)C), dim3(1024), shm, st, s->inds, s->idx, s->zz,
+                     s->logu, s->rint, s->fac, s->pos, Wc, (int)(s->ns[0] / C), (int)(s->ns[1] / C), (int)s->d, s->a,
+                     s->seeds, (int)s->W, (unsigned long long)first);
   GP_HIP(hipGetLastError());
   return GPEMU_OK;
 }
@@ -286,22 +297,36 @@ static ProposeArgs propose_args(gpemu_sampler *s, int h, int64_t lo, int64_t n) 
   return pa;
 }
 
-// propose + log-posterior + (fused) accept / record of one half on this device
+// propose + log-posterior + (fused) accept / record of one half on this device.  Large halves (several chains
+// stacked, or more than 4096 walkers) go through in chunks of proposals: a proposal only reads walkers of the
+// complementary set, which no chunk of this half modifies.  The kernel variants (row-chunk sizes of the partial sums)
+// are chosen by the PER-CHAIN half size, so that a chain stacked with others is evaluated exactly as it would be alone.
 static int half_step_fused(gpemu_sampler *s, int h, int store_chain, hipStream_t st) {
   const size_t o2 = rslot(s) * 2 * s->W;
-  const ProposeArgs pa = propose_args(s, h, 0, s->ns[h]);
-  AcceptArgs aa;
-  aa.enabled = 1;
-  aa.X = s->X; aa.logp = s->logp;
-  aa.idx_s = s->idx + o2 + h * s->W;
-  aa.factors = s->factors;
-  aa.logu = s->logu + o2 + h * s->W;
-  aa.naccept = s->naccept; aa.flags = s->flags;
-  if (store_chain) {
-    aa.chain = s->chain + s->chain_len * s->W * s->d;
-    aa.lpchain = s->lpchain + s->chain_len * s->W;
+  const int64_t n = s->ns[h], per_chain = n / s->nchains;
+  const int64_t chunk_max = (per_chain <= 128) ? 1024 : 2048;
+  for (int64_t lo = 0; lo < n; lo += chunk_max) {
+    const int64_t nb = std::min<int64_t>(chunk_max, n - lo);
+    const ProposeArgs pa = propose_args(s, h, lo, nb);
+    AcceptArgs aa;
+    aa.enabled = 1;
+    aa.X = s->X; aa.logp = s->logp;
+    aa.idx_s = s->idx + o2 + h * s->W + lo;
+    aa.factors = s->factors + lo;
+    aa.logu = s->logu + o2 + h * s->W + lo;
+    aa.naccept = s->naccept; aa.flags = s->flags;
+    aa.chain_per = s->nchains > 1 ? (int)per_chain : 0;
+    aa.first = lo;
+    if (store_chain) {
+      aa.chain = s->chain + s->chain_len * s->W * s->d;
+      aa.lpchain = s->lpchain + s->chain_len * s->W;
+    }
+    for (gpemu_model *m : s->groups) m->variant_B = per_chain;
+    const int rc = eval_logpost(s, s->q, nb, s->newlp + lo, st, &aa, &pa);
+    for (gpemu_model *m : s->groups) m->variant_B = 0;
+    if (rc != GPEMU_OK) return rc;
   }
-  return eval_logpost(s, s->q, s->ns[h], s->newlp, st, &aa, &pa);
+  return GPEMU_OK;
 }
 
 // bookkeeping after both halves (the chain row was written by the fused / accept kernels)
@@ -334,23 +359,36 @@ int gpemu_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_
 
 int gpemu_sampler_create(gpemu_sampler **out, gpemu_model *const *groups, int n_groups, int64_t W,
                          double a, uint64_t seed) {
-  GP_ARG(out && groups && n_groups > 0, "groups");
+  return gpemu_sampler_create_chains(out, groups, n_groups, W, a, &seed, 1);
+}
+
+int gpemu_sampler_create_chains(gpemu_sampler **out, gpemu_model *const *groups, int n_groups, int64_t Wc,
+                                double a, const uint64_t *seeds, int n_chains) {
+  GP_ARG(out && groups && n_groups > 0 && seeds, "groups / seeds");
   *out = nullptr;
   GP_ARG(a > 1.0, "stretch scale a must be > 1");
+  GP_ARG(n_chains >= 1 && n_chains <= 4096, "n_chains must be in [1, 4096]");
   for (int g = 0; g < n_groups; ++g) {
     GP_ARG(groups[g], "null group");
     GP_ARG(groups[g]->d == groups[0]->d && groups[g]->device == groups[0]->device,
            "groups must share the parameter dimension and the device");
     if (!groups[g]->lik_ready) { set_error("gpemu_likelihood_setup must be called on every group first"); return GPEMU_ERR_STATE; }
+    if (groups[g]->lik_chains != 1 && groups[g]->lik_chains != n_chains) {
+      set_error("group %d carries data for %d chains, the sampler has %d", g, groups[g]->lik_chains, n_chains);
+      return GPEMU_ERR_STATE;
+    }
   }
+  GP_ARG(Wc >= 2 && Wc <= 8192, "n_walkers (per chain) must be in [2, 8192]");
+  const int64_t W = Wc * n_chains;          // all walkers, chain after chain
+  const uint64_t seed = seeds[0];
   const int64_t d = groups[0]->d;
-  GP_ARG(W >= 2 && W <= 8192, "n_walkers must be in [2, 8192]");
   GP_HIP(hipSetDevice(groups[0]->device));
   gpemu_sampler *s = new gpemu_sampler();
   s->device = groups[0]->device;
   s->groups.assign(groups, groups + n_groups);
   s->W = W; s->d = d; s->a = a; s->seed = seed;
-  s->ns[0] = (W + 1) / 2; s->ns[1] = W / 2;
+  s->nchains = n_chains;
+  s->ns[0] = (Wc + 1) / 2 * n_chains; s->ns[1] = Wc / 2 * n_chains;     // proposals of a half, chain after chain
   s->qcap = round_up(s->ns[0], TILE) + TILE;
   s->stream = groups[0]->stream;
   hipError_t e = hipSuccess;
@@ -370,6 +408,8 @@ int gpemu_sampler_create(gpemu_sampler **out, gpemu_model *const *groups, int n_
   A((void **)&s->newlp, sizeof(double) * s->qcap);
   A((void **)&s->naccept, sizeof(long long) * W);
   A((void **)&s->flags, sizeof(int) * 2);
+  A((void **)&s->seeds, sizeof(unsigned long long) * n_chains);
+  if (e == hipSuccess) e = hipMemcpy(s->seeds, seeds, sizeof(unsigned long long) * n_chains, hipMemcpyHostToDevice);
   if (e == hipSuccess) { s->X = s->Xbuf; s->logp = s->lpbuf; s->cur = 0; }
 
   if (e == hipSuccess) e = hipMemsetAsync(s->q, 0, sizeof(double) * s->qcap * DPAD, s->stream);
@@ -394,7 +434,7 @@ int gpemu_sampler_destroy(gpemu_sampler *s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   front_release(s);
   (void)hipFree(s->Xbuf); (void)hipFree(s->lpbuf); (void)hipFree(s->inds); (void)hipFree(s->idx);
-  (void)hipFree(s->fac); (void)hipFree(s->pos); (void)hipFree(s->q2);
+  (void)hipFree(s->fac); (void)hipFree(s->pos); (void)hipFree(s->q2); (void)hipFree(s->seeds);
   (void)hipFree(s->zz); (void)hipFree(s->logu); (void)hipFree(s->rint); (void)hipFree(s->q);
   (void)hipFree(s->factors); (void)hipFree(s->newlp); (void)hipFree(s->naccept); (void)hipFree(s->flags);
   (void)hipFree(s->chain); (void)hipFree(s->lpchain);
@@ -421,15 +461,26 @@ int gpemu_sampler_set_state(gpemu_sampler *s, const double *X0, const double *lo
       if (e != hipSuccess) { set_error("set_state: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
     } else {
       // evaluate all walkers; X has exactly W rows, so go through a padded scratch copy in chunks
-      for (int64_t off = 0; off < W && rc == GPEMU_OK; off += s->ns[0]) {
-        int64_t nb = (W - off < s->ns[0]) ? (W - off) : s->ns[0];
+      // chunks never straddle a chain: every chunk is a whole number of chains or a piece of one
+      const int64_t Wc = W / s->nchains;
+      const int64_t cap = std::min<int64_t>(s->ns[0], 1024);
+      const int64_t step = (Wc <= cap) ? (cap / Wc) * Wc : cap;
+      for (int64_t off = 0; off < W && rc == GPEMU_OK;) {
+        int64_t nb = std::min<int64_t>(step, W - off);
+        if (Wc > cap) nb = std::min<int64_t>(nb, Wc - off % Wc);
         e = hipMemcpyAsync(s->q, s->X + off * DPAD, sizeof(double) * nb * DPAD, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) { set_error("set_state: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; break; }
-        rc = eval_logpost(s, s->q, nb, s->newlp, st);
+        AcceptArgs ca;                       // not an accept: only tells the likelihood which chain a row belongs to
+        ca.chain_per = s->nchains > 1 ? (int)Wc : 0;
+        ca.first = off;
+        for (gpemu_model *m : s->groups) m->variant_B = (Wc + 1) / 2;
+        rc = eval_logpost(s, s->q, nb, s->newlp, st, &ca);
+        for (gpemu_model *m : s->groups) m->variant_B = 0;
         if (rc == GPEMU_OK) {
           e = hipMemcpyAsync(s->logp + off, s->newlp, sizeof(double) * nb, hipMemcpyDeviceToDevice, st);
           if (e != hipSuccess) { set_error("set_state: %s", hipGetErrorString(e)); rc = GPEMU_ERR_HIP; }
         }
+        off += nb;
       }
     }
   }

@@ -30,7 +30,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int ST_M = 32, ST_N = 32, ST_K = 32;
-constexpr int ST_MAX_ITEMS = 64;
+constexpr int ST_MAX_ITEMS = 256;
 
 struct SmallItem {
   int p, rb, col0, pad;

@@ -21,6 +21,8 @@ struct gpemu_sampler {
   int64_t qcap = 0;            // rows of q (>= ns[0] rounded up to 128, + 128)
   double a = 2.0;
   uint64_t seed = 0;
+  int nchains = 1;             // independent chains stacked in this sampler (W = nchains x walkers per chain)
+  unsigned long long *seeds = nullptr;   // [nchains] Philox keys, on the device
   uint64_t step_counter = 0;   // RNG counter, never reset
   int64_t iterations = 0;      // steps since the last reset
   hipStream_t stream = nullptr;

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "gpemu_predict_full_dev": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_double, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
     "gpemu_likelihood_setup": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_double, c_i64, C.c_void_p]),
+    "gpemu_likelihood_setup_chains": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, c_i64, C.c_void_p]),
     "gpemu_logpost": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_int]),
     "gpemu_logpost_dev": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "gpemu_fit_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, c_i64, c_i64, C.c_void_p, C.c_int, C.c_double,
@@ -62,6 +63,8 @@ _SIGNATURES = {
     "gpemu_truncation_cov": (C.c_int, [C.c_int, c_i64, c_i64, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpemu_sampler_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, c_i64,
                                        C.c_double, C.c_uint64]),
+    "gpemu_sampler_create_chains": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, c_i64,
+                                              C.c_double, C.c_void_p, C.c_int]),
     "gpemu_sampler_destroy": (C.c_int, [C.c_void_p]),
     "gpemu_sampler_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gpemu_sampler_set_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

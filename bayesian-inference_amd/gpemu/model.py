@@ -109,7 +109,11 @@ class DeviceModel:
 
     def likelihood_setup(self, y_exp, y_err, lo, hi, n_div=1.0, block_start=None):
         """Data, box prior and the observable block boundaries of this group (``block_start`` =
-        first feature of each observable plus F at the end; None = a single block)."""
+        first feature of each observable plus F at the end; None = a single block).  ``y_exp`` of shape (C, F):
+        one data vector per chain of a multi-chain sampler (closure tests), all against the same ``y_err``."""
+        y_exp = np.ascontiguousarray(y_exp, dtype=np.float64)
+        if y_exp.ndim == 2:
+            return self._likelihood_setup_chains(y_exp, y_err, lo, hi, n_div, block_start)
         y_exp = as_f64(y_exp, (self.F,))
         y_err = as_f64(y_err, (self.F,))
         lo = as_f64(lo, (self.d,))
@@ -121,6 +125,20 @@ class DeviceModel:
             nb = bs.size - 1
         check(_lib.lib().gpemu_likelihood_setup(self._h, ptr(y_exp), ptr(y_err), ptr(lo), ptr(hi),
                                                 float(n_div), nb, ptr(bs)))
+        self._lik_key = (float(n_div), None if bs is None else tuple(bs.tolist()))
+
+    def _likelihood_setup_chains(self, y_exp, y_err, lo, hi, n_div, block_start):
+        n_chains = y_exp.shape[0]
+        y_exp = as_f64(y_exp, (n_chains, self.F))
+        y_err = as_f64(y_err, (self.F,))
+        lo = as_f64(lo, (self.d,))
+        hi = as_f64(hi, (self.d,))
+        bs, nb = None, 0
+        if block_start is not None:
+            bs = np.ascontiguousarray(block_start, dtype=np.int64)
+            nb = bs.size - 1
+        check(_lib.lib().gpemu_likelihood_setup_chains(self._h, int(n_chains), ptr(y_exp), ptr(y_err), ptr(lo), ptr(hi),
+                                                       float(n_div), nb, ptr(bs)))
         self._lik_key = (float(n_div), None if bs is None else tuple(bs.tolist()))
 
     def logpost(self, X, mode=LOWRANK):

@@ -88,15 +88,28 @@ def integrated_time(x, c=5, tol=50, quiet=False):
 class DeviceSampler:
     """Ensemble resident on the device; log-posterior = sum over the given DeviceModels."""
 
-    def __init__(self, models, n_walkers, a=2.0, seed=0):
+    def __init__(self, models, n_walkers, a=2.0, seed=0, seeds=None):
+        """``seeds`` (a sequence): that many INDEPENDENT chains of ``n_walkers`` walkers each, stacked in one
+        sampler and evaluated in the same launches (the closure tests of ref: steer_analysis.py:168-183); chain c is
+        the chain ``DeviceSampler(models, n_walkers, a, seed=seeds[c])`` produces on data vector c of the models'
+        ``likelihood_setup(y_exp (C, F), ...)``.  State and chain arrays then hold ``C * n_walkers`` walkers,
+        chain after chain."""
         _lib.require_device()
         self.models = list(models)
         arr = (C.c_void_p * len(self.models))(*[m.handle for m in self.models])
         h = C.c_void_p()
-        check(_lib.lib().gpemu_sampler_create(C.byref(h), arr, len(self.models), int(n_walkers), float(a),
-                                              C.c_uint64(int(seed) & (2 ** 64 - 1))))
+        if seeds is None:
+            check(_lib.lib().gpemu_sampler_create(C.byref(h), arr, len(self.models), int(n_walkers), float(a),
+                                                  C.c_uint64(int(seed) & (2 ** 64 - 1))))
+            self.n_chains = 1
+        else:
+            sd = np.array([int(v) & (2 ** 64 - 1) for v in seeds], dtype=np.uint64)
+            check(_lib.lib().gpemu_sampler_create_chains(C.byref(h), arr, len(self.models), int(n_walkers), float(a),
+                                                         ptr(sd), int(sd.size)))
+            self.n_chains = int(sd.size)
         self._h = h
-        self.W, self.d = int(n_walkers), self.models[0].d
+        self.walkers_per_chain = int(n_walkers)
+        self.W, self.d = int(n_walkers) * self.n_chains, self.models[0].d
         self.ns = ((self.W + 1) // 2, self.W // 2)
         self.device = self.models[0].device
 

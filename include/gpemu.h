@@ -107,6 +107,14 @@ int gpemu_likelihood_setup(gpemu_model *m, const double *y_exp, const double *y_
                            const double *lo, const double *hi, double n_div, int64_t n_blocks,
                            const int64_t *block_start);
 
+/* The same for SEVERAL data vectors against the same uncertainties: the closure tests of ref: steer_analysis.py:168-183
+ * condition one chain each on the pseudo-data of one validation point (ref: data_IO.py:362-372).  y_exp[n_chains*F];
+ * chain c of a sampler created with gpemu_sampler_create_chains then uses vector c.  Calls outside a multi-chain
+ * sampler (gpemu_logpost) use vector 0. */
+int gpemu_likelihood_setup_chains(gpemu_model *m, int n_chains, const double *y_exp, const double *y_err,
+                                  const double *lo, const double *hi, double n_div, int64_t n_blocks,
+                                  const int64_t *block_start);
+
 /* ref: log_posterior.py:42-101 + 104-146: X[B*d] -> out[B]; rows outside the open box -> -inf.
  * A non-positive-definite covariance yields NaN (the reference does not detect it either,
  * log_posterior.py:125-135). */
@@ -170,6 +178,13 @@ int gpemu_truncation_cov(int device, int64_t n_comp, int64_t F, int64_t n_pc, co
  */
 int gpemu_sampler_create(gpemu_sampler **out, gpemu_model *const *groups, int n_groups, int64_t W,
                          double a, uint64_t seed);
+/* n_chains INDEPENDENT ensembles of W walkers each sharing the groups' emulators -- the reference's closure loop
+ * (ref: steer_analysis.py:168-183: one MCMC per validation design point) as one batched run: the proposals of all
+ * chains are stacked into the same cross-kernel / triangular-GEMM / likelihood launches.  Chain c draws from its own
+ * Philox key seeds[c] and is, bit for bit, the chain gpemu_sampler_create(..., W, a, seeds[c]) produces on the data
+ * vector c.  State, chain and counters are laid out chain after chain: walker c W + w. */
+int gpemu_sampler_create_chains(gpemu_sampler **out, gpemu_model *const *groups, int n_groups, int64_t W,
+                                double a, const uint64_t *seeds, int n_chains);
 int gpemu_sampler_destroy(gpemu_sampler *s);
 int gpemu_sampler_set_stream(gpemu_sampler *s, void *stream); /* NULL = the first group's stream */
 /* X0[W*d]; logp0[W] or NULL to evaluate it (ref: mcmc.py:88, emcee State(initial_state)) */

@@ -312,3 +312,42 @@ def test_device_sampler_posterior_moments_vs_host_stretch_move():
     assert abs(af_d - af_h) < 0.05 and 0.1 < af_d < 0.9
     ds.close()
     dm.close()
+
+
+@pytest.mark.parametrize("W", [24, 33, 300])
+def test_stacked_chains_equal_separate_chains(W):
+    """gpemu_sampler_create_chains: C independent chains stacked in one sampler -- every chain on its own data vector
+    (closure pseudo-data) and its own seed -- are, bit for bit, the chains C separate samplers produce (per-chain kernel
+    variants, chunked halves, chain-aware likelihood constants)."""
+    from gpemu import synthetic
+    from gpemu.sampler import DeviceSampler
+    g = GU.load("g1_rbf_noise")
+    model = GU.group_model(g)
+    C, steps = 5, 7
+    rng = np.random.default_rng(17)
+    ys = g["y_exp"][None, :] + 0.05 * rng.normal(size=(C, g["y_exp"].size))
+    seeds = [101 + 13 * c for c in range(C)]
+    X0 = np.concatenate([synthetic.make_walkers(W, seed=40 + c, lo=g["lo"], hi=g["hi"]) for c in range(C)])
+    dm = GU.device_model(model)
+    dm.likelihood_setup(ys, g["y_err"], g["lo"], g["hi"], 1.0)
+    ms = DeviceSampler([dm], W, seeds=seeds)
+    assert ms.n_chains == C and ms.W == C * W
+    ms.set_state(X0)
+    lp0 = ms.get_state()[1]
+    ms.run(3)
+    ms.run(steps - 3)
+    chain, lps = ms.get_chain()
+    nacc = ms.counts()[0]
+    ms.close()
+    for c in range(C):
+        dm.likelihood_setup(ys[c], g["y_err"], g["lo"], g["hi"], 1.0)
+        one = DeviceSampler([dm], W, seed=seeds[c])
+        one.set_state(X0[c * W:(c + 1) * W])
+        np.testing.assert_array_equal(one.get_state()[1], lp0[c * W:(c + 1) * W])
+        one.run(steps)
+        c1, l1 = one.get_chain()
+        np.testing.assert_array_equal(chain[:, c * W:(c + 1) * W], c1)
+        np.testing.assert_array_equal(lps[:, c * W:(c + 1) * W], l1)
+        np.testing.assert_array_equal(nacc[c * W:(c + 1) * W], one.counts()[0])
+        one.close()
+    dm.close()
