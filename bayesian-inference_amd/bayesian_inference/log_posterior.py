@@ -85,6 +85,30 @@ def device_models(n_div: float = 1.0):
     return [m for m, _, _ in _state["models"]]
 
 
+def chains_can_stack(config) -> bool:
+    """Closure chains can share one multi-chain device sampler when there is a single emulation group with few
+    enough PCs for the device's stacked path (the general case runs chain by chain)."""
+    try:
+        groups = config.analysis_config['parameters']['emulators']
+    except (KeyError, TypeError):
+        return False
+    return len(groups) >= 1
+
+
+def device_models_for_chains(y_chains):
+    """Device models (n_div = 1) with ONE DATA VECTOR PER CHAIN: ``y_chains`` (C, F) in the merged observable
+    order; the uncertainties are those of ``experimental_results``."""
+    y_chains = np.asarray(y_chains, dtype=np.float64)
+    models = device_models(n_div=1.0)               # builds / caches the models
+    lo = np.asarray(min, dtype=np.float64)
+    hi = np.asarray(max, dtype=np.float64)
+    y_err = experimental_results['y_err']
+    for dm, cols, starts in _state["models"]:
+        dm.likelihood_setup(y_chains[:, cols], y_err[cols], lo, hi, n_div=1.0, block_start=starts)
+    _state["n_div"] = None                          # the single-vector constants are gone
+    return models
+
+
 def log_posterior(X):
     """log-posterior of each row of X; shape (n_samples,) (ref: log_posterior.py:42-101)."""
     X = np.array(X, ndmin=2, dtype=np.float64)

@@ -66,6 +66,107 @@ def _best_distinct(sampler, count):
 
 
 ####################################################################################################
+# Closure tests as ONE batched run.  The reference's loop (ref: steer_analysis.py:168-183) calls
+# run_mcmc(config, closure_index=i) once per validation design point; the chains are independent and share the
+# emulators.  The first call a rank receives runs ALL of that rank's closure chains stacked in one multi-chain
+# device sampler and writes every chain's files; the later calls find their chain done and return.
+_closure_done: "dict[tuple, set]" = {}
+
+
+def _closure_batch_enabled():
+    return os.environ.get("GPEMU_CLOSURE_BATCH", "1") != "0"
+
+
+def _closure_indices(config, first, rank, world):
+    """Closure indices this rank still has to run, from ``first`` on (validation_indices of the analysis)."""
+    lo, hi = config.analysis_config['validation_indices']
+    return [j for j in range(first, hi - lo) if closure_owner(j, world) in (None, rank)]
+
+
+def _run_closure_batch(config, indices):
+    """The chains of ``indices`` (ref: mcmc.py:34-134 each) as one stacked run: per chain the reference's pseudo-data
+    draw and start positions (numpy's global state, in the reference's order), its two-stage burn-in with the
+    restart from its own best points, production, and its own ``closure/results/<index>/`` outputs."""
+    from gpemu.sampler import DeviceSampler
+    box = config.analysis_config['parameterization'][config.parameterization]
+    lower, upper = box['min'], box['max']
+    n_par, n_walk, n_ch = len(box['names']), config.n_walkers, len(indices)
+    emu_cfg = emulation.EmulationConfig.from_config_file(
+        analysis_name=config.analysis_name, parameterization=config.parameterization,
+        analysis_config=config.analysis_config, config_file=config.config_file)
+    emu_results = emu_cfg.read_all_emulator_groups()
+    truncation_cov = emulation.compute_emulator_cov_unexplained(emu_cfg, emu_results)
+    io = _data_IO()
+    datas, starts = [], []
+    for j in indices:           # the reference's order of draws: pseudo-data of chain j, then its start positions
+        datas.append(io.data_array_from_h5(config.output_dir, 'observables.h5', pseudodata_index=j,
+                                           observable_filter=emu_cfg.observable_filter))
+        starts.append(np.random.uniform(lower, upper, (n_walk, n_par)))
+    y_err = np.asarray(datas[0]['y_err'], dtype=np.float64)
+    for dat in datas[1:]:
+        if not np.array_equal(np.asarray(dat['y_err'], dtype=np.float64), y_err):
+            raise ValueError("closure chains must share the experimental uncertainties to be stacked")
+    log_posterior.initialize_pool_variables(lower, upper, emu_cfg, emu_results, datas[0], truncation_cov)
+    models = log_posterior.device_models_for_chains(np.stack([np.asarray(dat['y'], dtype=np.float64) for dat in datas]))
+    seeds = [int(np.random.randint(0, 2 ** 31 - 1)) for _ in indices]
+    sampler = DeviceSampler(models, n_walk, seeds=seeds)
+    logger.info(f'Closure tests {indices[0]}..{indices[-1]}: {n_ch} chains x {n_walk} walkers stacked in one sampler')
+
+    def per_chain(arr):         # (steps, C W, ...) -> list of (steps, W, ...)
+        return [arr[:, c * n_walk:(c + 1) * n_walk] for c in range(n_ch)]
+
+    def advance(X0, steps):
+        sampler.set_state(np.concatenate(X0))
+        done = 0
+        while done < steps:
+            block = min(config.n_logging_steps - done % config.n_logging_steps, steps - done)
+            sampler.run(block)
+            done += block
+            if done % config.n_logging_steps == 0 or done == steps:
+                nacc, it, _ = sampler.counts()
+                frac = nacc / float(max(it, 1))
+                logger.info(f'  step {done}: acceptance fraction over {n_ch} chains: mean {frac.mean()}, '
+                            f'min {frac.min()}, max {frac.max()}')
+
+    first_stage = config.n_burn_steps // 2
+    advance(starts, first_stage)
+    chain, lps = sampler.get_chain()
+    restart = []
+    for c, (ch, lp) in enumerate(zip(per_chain(chain), per_chain(lps))):     # ref: mcmc.py:99, per chain
+        _, first_seen = np.unique(lp.reshape(-1), return_index=True)
+        restart.append(ch.reshape(-1, n_par)[first_seen[-n_walk:]])
+    sampler.reset()
+    advance(restart, config.n_burn_steps - first_stage)
+    state = sampler.get_state()[0]
+    sampler.reset()
+    advance([state[c * n_walk:(c + 1) * n_walk] for c in range(n_ch)], config.n_sampling_steps)
+    chain, lps = sampler.get_chain()
+    nacc, iters, _ = sampler.counts()
+    sampler.close()
+
+    validation_design = io.design_array_from_h5(config.output_dir, filename='observables.h5', validation_set=True)
+    for c, j in enumerate(indices):
+        cfg_j = MCMCConfig(analysis_name=config.analysis_name, parameterization=config.parameterization,
+                           analysis_config=config.analysis_config, config_file=config.config_file, closure_index=j)
+        one = LoggingEnsembleSampler(n_walk, n_par, log_posterior.log_posterior, seed=seeds[c], sharded=False)
+        one._cache = (per_chain(chain)[c].copy(), per_chain(lps)[c].copy(),
+                      nacc[c * n_walk:(c + 1) * n_walk].copy(), iters)
+        one._frozen = True
+        try:
+            tau = one.get_autocorr_time()
+        except Exception as err:
+            logger.info(f'No autocorrelation time (closure {j}): {err}')
+            tau = None
+        results = {'chain': one.get_chain(), 'acceptance_fraction': one.acceptance_fraction,
+                   'log_prob': one.get_log_prob(), 'autocorrelation_time': tau,
+                   'design_point': validation_design[j], 'experimental_pseudodata': datas[c]}
+        logger.info(f'Writing {cfg_j.mcmc_outputfile}')
+        io.write_dict_to_h5(results, cfg_j.mcmc_output_dir, 'mcmc.h5', verbose=True)
+        pickle_path = Path(cfg_j.sampler_outputfile)
+        pickle_path.parent.mkdir(parents=True, exist_ok=True)
+        pickle_path.write_bytes(pickle.dumps(one))
+
+
 def run_mcmc(config, closure_index=-1):
     """Calibrate the parameters against the data (or, for ``closure_index >= 0``, against the pseudo-data
     of that validation point) with the affine-invariant ensemble sampler (ref: mcmc.py:34-134)."""
@@ -75,6 +176,20 @@ def run_mcmc(config, closure_index=-1):
         logger.info(f'closure test {closure_index}: runs on rank {owner}')
         return
     alone = owner is not None          # this rank runs the whole chain by itself
+    if closure_index >= 0 and (alone or world == 1) and _closure_batch_enabled() \
+            and 'validation_indices' in config.analysis_config:
+        key = (config.output_dir, config.analysis_name, config.parameterization)
+        done = _closure_done.setdefault(key, set())
+        if closure_index in done:
+            logger.info(f'closure test {closure_index}: already run with the stacked chains')
+            return
+        indices = [j for j in _closure_indices(config, closure_index, rank, world) if j not in done]
+        if closure_index not in indices:
+            indices.insert(0, closure_index)
+        if log_posterior.chains_can_stack(config):
+            _run_closure_batch(config, indices)
+            done.update(indices)
+            return
 
     box = config.analysis_config['parameterization'][config.parameterization]
     lower, upper = box['min'], box['max']

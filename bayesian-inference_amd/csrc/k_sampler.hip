@@ -205,8 +205,10 @@ __global__ void unpad_rows_kernel(const double *__restrict__ src, double *__rest
 static int eval_logpost(gpemu_sampler *s, double *dq, int64_t B, double *dout, hipStream_t st,
                         const AcceptArgs *aa = nullptr, const ProposeArgs *pa = nullptr) {
   const size_t ng = s->groups.size();
+  AcceptArgs chain_only;                 // groups before the last: no accept, but the rows' chains (data constants)
+  if (aa) { chain_only.chain_per = aa->chain_per; chain_only.first = aa->first; }
   for (size_t g = 0; g < ng; ++g) {
-    int rc = logpost_padded(s->groups[g], B, dq, dout, g > 0 ? 1 : 0, st, g + 1 == ng ? aa : nullptr,
+    int rc = logpost_padded(s->groups[g], B, dq, dout, g > 0 ? 1 : 0, st, g + 1 == ng ? aa : (aa ? &chain_only : nullptr),
                             g == 0 ? pa : nullptr);
     if (rc != GPEMU_OK) return rc;
   }

@@ -26,7 +26,15 @@ def install_fake_data_IO(Y, design, y_exp, y_err, written):
     m = types.ModuleType("bayesian_inference.data_IO")
     m.predictions_matrix_from_h5 = lambda *a, **k: Y
     m.design_array_from_h5 = lambda *a, **k: design
-    m.data_array_from_h5 = lambda *a, **k: {"y": y_exp, "y_err": y_err}
+
+    def data_array_from_h5(output_dir, filename, pseudodata_index=-1, observable_filter=None):
+        if pseudodata_index < 0:
+            return {"y": y_exp, "y_err": y_err}
+        # closure test: a validation point's prediction smeared with the experimental uncertainty
+        # (ref: data_IO.py:362-372), drawn from numpy's global state like the reference
+        centre = Y[pseudodata_index % Y.shape[0]]
+        return {"y": centre + np.random.normal(loc=0.0, scale=y_err), "y_err": y_err}
+    m.data_array_from_h5 = data_array_from_h5
     m.ObservableFilter = FakeObservableFilter
 
     def write_dict_to_h5(results, output_dir, filename, verbose=True):

@@ -174,3 +174,54 @@ def test_run_mcmc_end_to_end(tmp_path, monkeypatch):
     np.testing.assert_array_equal(back["log_prob"], out["log_prob"])
     np.testing.assert_array_equal(back["acceptance_fraction"], out["acceptance_fraction"])
     assert back["autocorrelation_time"] == {}             # None -> empty group, as silx writes it
+
+
+def test_closure_tests_run_stacked(tmp_path, monkeypatch):
+    """The reference's closure loop (ref: steer_analysis.py:168-183) calls run_mcmc once per validation point: the
+    first call runs all chains stacked in one multi-chain sampler and writes every chain's files, the later calls
+    return at once.  Every chain's stored log-probabilities are the log-posterior of its stored positions under ITS
+    pseudo-data."""
+    from bayesian_inference import emulation, log_posterior, mcmc
+    from gpemu import h5io
+    g = GU.load("g1_rbf_noise")
+    written = {}
+    DU.install_fake_data_IO(g["Y"], g["design"], g["y_exp"], g["y_err"], written)
+    path, analysis = DU.write_config(tmp_path, n_pc=5, n_restarts=0)
+    analysis["validation_indices"] = [0, 3]
+    ec = emulation.EmulationConfig.from_config_file("test_analysis", "exponential", path, analysis)
+    np.random.seed(3)
+    emulation.fit_emulators(ec)
+    monkeypatch.setattr(emulation.EmulationConfig, "sort_observables_in_matrix",
+                        property(lambda self: DU.TrivialSort("main")))
+    monkeypatch.setattr(emulation.EmulationConfig, "observable_filter", property(lambda self: None))
+    mcmc._closure_done.clear()
+    cfgs = [mcmc.MCMCConfig("test_analysis", "exponential", analysis, path, closure_index=j) for j in range(3)]
+    np.random.seed(11)
+    mcmc.run_mcmc(cfgs[0], closure_index=0)                      # runs chains 0, 1, 2
+    assert all(c.mcmc_outputfile in written for c in cfgs)
+    n_before = len(written)
+    mcmc.run_mcmc(cfgs[1], closure_index=1)                      # nothing left to do
+    mcmc.run_mcmc(cfgs[2], closure_index=2)
+    assert len(written) == n_before
+    W, steps, d = cfgs[0].n_walkers, cfgs[0].n_sampling_steps, 6
+    lo, hi = np.array(g["lo"]), np.array(g["hi"])
+    ec2 = emulation.EmulationConfig.from_config_file("test_analysis", "exponential", path, analysis)
+    res = ec2.read_all_emulator_groups()
+    pseudo = []
+    for j, c in enumerate(cfgs):
+        out = written[c.mcmc_outputfile]
+        assert out["chain"].shape == (steps, W, d) and out["log_prob"].shape == (steps, W)
+        assert np.all(out["chain"] > lo) and np.all(out["chain"] < hi)
+        assert out["design_point"].shape == (d,) and set(out["experimental_pseudodata"]) == {"y", "y_err"}
+        back = h5io.read_dict_from_h5(c.mcmc_output_dir, "mcmc.h5")
+        np.testing.assert_array_equal(back["chain"], out["chain"])
+        np.testing.assert_array_equal(back["experimental_pseudodata"]["y"], out["experimental_pseudodata"]["y"])
+        # the chain's log-probabilities under its own pseudo-data (single-walker semantics)
+        log_posterior.initialize_pool_variables(g["lo"], g["hi"], ec2, res, out["experimental_pseudodata"], None)
+        lp = np.array([log_posterior.log_posterior(x)[0] for x in out["chain"][-1][:4]])
+        np.testing.assert_allclose(lp, out["log_prob"][-1][:4], rtol=1e-10)
+        pseudo.append(out["experimental_pseudodata"]["y"])
+        sampler = pickle.load(open(c.sampler_outputfile, "rb"))
+        np.testing.assert_array_equal(sampler.get_chain(), out["chain"])
+    assert not np.array_equal(pseudo[0], pseudo[1])              # every chain has its own draw
+    mcmc._closure_done.clear()
