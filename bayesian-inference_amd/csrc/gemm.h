@@ -11,6 +11,10 @@ struct GemmArgs {
   double *C = nullptr;
   int64_t lda = 0, ldb = 0, ldc = 0;
   int64_t strideA = 0, strideB = 0, strideC = 0;  // per batch entry (blockIdx.z)
+  // second batch level (several matrices, each with its own inner batch): blockIdx.z = z1 + batch1 * z2, operands at
+  // z1 * stride + z2 * stride2.  batch1 = 0: one level.
+  int batch1 = 0;
+  int64_t stride2A = 0, stride2B = 0, stride2C = 0;
   int M = 0, N = 0, K = 0;
   double alpha = 1.0, beta = 0.0;
   int lower_only = 0;  // skip 64 x 64 tiles strictly above the diagonal

@@ -169,8 +169,8 @@ int logpost_padded(gpemu_model *m, int64_t B, double *dXq, double *dout, int acc
                    hipStream_t st, const AcceptArgs *aa = nullptr, const ProposeArgs *pa = nullptr);
 // fit-side building blocks (k_fit.hip): in-place blocked Cholesky of an Np x Np matrix (Np multiple of 64) with the
 // inverted diagonal blocks in Dinv [Np/64][64][64], and W = L^-1 from it (T: Np x Np scratch)
-int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hipStream_t st);
-int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double *W, double *T, hipStream_t st);
+int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hipStream_t st, int nb = 1);
+int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double *W, double *T, hipStream_t st, int nb = 1);
 int device_invert_factor_to_Wt(const double *dL, int64_t N, double *Wt, int64_t Npad, double *A, double *Dinv,
                                double *W, double *T, hipStream_t st);
 // profiling helpers: record an event on `st` and return its pool index (-1 when profiling is off)

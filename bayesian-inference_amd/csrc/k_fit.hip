@@ -39,11 +39,14 @@ __device__ __forceinline__ double base_from_r2(int kind, double r2) {
 }
 
 // X [Np][DPAD] raw inputs; hp = {ls[DPAD], const, noise}; K[i][j] for i,j < N, identity tail
+// blockIdx.z: problem of a batch (own hyper-parameters and matrix, shared inputs)
 __global__ void kmat_kernel(const double *__restrict__ X, const double *__restrict__ hp, double *__restrict__ K,
                             int N, int Np, int kind, double jitter) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = blockIdx.y;
   if (j >= Np) return;
+  hp += (int64_t)blockIdx.z * (DPAD + 2);
+  K += (int64_t)blockIdx.z * Np * Np;
   double v;
   if (i >= N || j >= N) {
     v = (i == j) ? 1.0 : 0.0;
@@ -158,8 +161,12 @@ __device__ __forceinline__ void merge_level(double (*D)[NB + 1], double (*X)[NB 
   __syncthreads();
 }
 
+// blockIdx.x: diagonal block (64 apart), blockIdx.y: problem of a batch (strides batchA, batchD; info per problem)
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda, double *Dinv, int do_factor,
-                                                         int block_index, int *info) {
+                                                         int block_index, int *info, int64_t batchA, int64_t batchD) {
+  A += (int64_t)blockIdx.y * batchA;
+  Dinv += (int64_t)blockIdx.y * batchD;
+  info += blockIdx.y;
   constexpr int PB = 16;
   __shared__ double D[NB][NB + 1];     // the factor
   __shared__ double X[NB][NB + 1];     // its inverse
@@ -214,6 +221,8 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda,
 __global__ __launch_bounds__(256) void scatter_diag_blocks_kernel(const double *__restrict__ Dinv, double *__restrict__ W,
                                                                   int64_t Np) {
   const int64_t ib = blockIdx.x;
+  Dinv += (int64_t)blockIdx.y * Np * NB;      // blockIdx.y: problem of a batch
+  W += (int64_t)blockIdx.y * Np * Np;
   const double *src = Dinv + ib * NB * NB;
   double *dst = W + (ib * NB) * Np + ib * NB;
   for (int idx = threadIdx.x; idx < NB * NB; idx += 256) dst[(int64_t)(idx >> 6) * Np + (idx & 63)] = src[idx];
@@ -221,12 +230,14 @@ __global__ __launch_bounds__(256) void scatter_diag_blocks_kernel(const double *
 
 // In-place lower Cholesky of the Np x Np matrix A (Np multiple of 64); Dinv receives the inverted
 // diagonal blocks [Np/64][64][64].
-int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hipStream_t st) {
+// nb > 1: a batch of matrices A + z Np^2 (Dinv + z Np 64, dinfo + z), every launch serving all of them
+int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hipStream_t st, int nb) {
   const int nblk = (int)(Np / NB);
   for (int jb = 0; jb < nblk; ++jb) {
     const int64_t j0 = (int64_t)jb * NB;
     double *Ajj = A + j0 * Np + j0;
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, Ajj, Np, Dinv + (int64_t)jb * NB * NB, 1, jb, dinfo);
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, (unsigned)nb), dim3(256), 0, st, Ajj, Np, Dinv + (int64_t)jb * NB * NB, 1,
+                       jb, dinfo, Np * Np, Np * NB);
     GP_HIP(hipGetLastError());
     const int M = (int)(Np - j0 - NB);
     if (M <= 0) break;
@@ -236,13 +247,15 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
     g.B = Dinv + (int64_t)jb * NB * NB; g.ldb = NB;
     g.C = A21; g.ldc = Np;
     g.M = M; g.N = NB; g.K = NB;
-    int rc = launch_gemm(g, false, false, 1, st);
+    g.strideA = Np * Np; g.strideB = Np * NB; g.strideC = Np * Np;
+    int rc = launch_gemm(g, false, false, nb, st);
     if (rc != GPEMU_OK) return rc;
     GemmArgs s;   // A22 -= panel . panel^T (lower tiles)
     s.A = A21; s.lda = Np; s.B = A21; s.ldb = Np;
     s.C = A + (j0 + NB) * Np + (j0 + NB); s.ldc = Np;
     s.M = M; s.N = M; s.K = NB; s.alpha = -1.0; s.beta = 1.0; s.lower_only = 1;
-    rc = launch_gemm(s, false, false, 1, st);
+    s.strideA = Np * Np; s.strideB = Np * Np; s.strideC = Np * Np;
+    rc = launch_gemm(s, false, false, nb, st);
     if (rc != GPEMU_OK) return rc;
   }
   return GPEMU_OK;
@@ -253,11 +266,11 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
 // diagonal of W; a pair (W11, W22) becomes inv([[L11,0],[L21,L22]]) by  W21 = -W22 (L21 W11),
 // two GEMMs per level, batched over all pairs (blockIdx.z), so the whole inverse takes
 // 2 log2(Np/64) (+ ragged-tail) launches of large MFMA GEMMs.  T is an Np x Np scratch.
-int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double *W, double *T, hipStream_t st) {
+int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double *W, double *T, hipStream_t st, int nb) {
   const int nblk = (int)(Np / NB);
-  GP_HIP(hipMemsetAsync(W, 0, sizeof(double) * (size_t)(Np * Np), st));
+  GP_HIP(hipMemsetAsync(W, 0, sizeof(double) * (size_t)(Np * Np) * nb, st));
   // diagonal blocks: Dinv [nblk][64][64] -> W, one launch
-  hipLaunchKernelGGL(scatter_diag_blocks_kernel, dim3((unsigned)nblk), dim3(256), 0, st, Dinv, W, Np);
+  hipLaunchKernelGGL(scatter_diag_blocks_kernel, dim3((unsigned)nblk, (unsigned)nb), dim3(256), 0, st, Dinv, W, Np);
   GP_HIP(hipGetLastError());
   for (int64_t b = NB; b < Np; b *= 2) {
     // pairs start at p0 = 2 b t; first block [p0, p0 + b), second [p0 + b, min(p0 + 2b, Np))
@@ -271,7 +284,8 @@ int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double
       g.C = T + (p0 + b) * Np + p0; g.ldc = Np; g.strideC = 2 * b * Np + 2 * b;
       g.M = (int)b2; g.N = (int)b; g.K = (int)b;
       g.k_from_n = 1;                                          // W11 is lower triangular: W11[k][n] = 0 for k < n
-      int rc = launch_gemm(g, false, true, batch, st);
+      g.batch1 = batch; g.stride2A = Np * Np; g.stride2B = Np * Np; g.stride2C = Np * Np;   // x nb matrices
+      int rc = launch_gemm(g, false, true, batch * nb, st);
       if (rc != GPEMU_OK) return rc;
       // W21 = -W22 . T21  (b2 x b) = (b2 x b2) (b2 x b)
       GemmArgs h;
@@ -280,7 +294,8 @@ int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double
       h.C = W + (p0 + b) * Np + p0; h.ldc = Np; h.strideC = 2 * b * Np + 2 * b;
       h.M = (int)b2; h.N = (int)b; h.K = (int)b2; h.alpha = -1.0;
       h.k_to_m = 1;                                            // W22 is lower triangular: W22[m][k] = 0 for k > m
-      return launch_gemm(h, false, true, batch, st);
+      h.batch1 = batch; h.stride2A = Np * Np; h.stride2B = Np * Np; h.stride2C = Np * Np;
+      return launch_gemm(h, false, true, batch * nb, st);
     };
     if (nfull > 0) {
       int rc = merge(0, b, (int)nfull);
@@ -298,6 +313,9 @@ int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double
 // out[i] = sum_j M[i][j] v[j] (trans = 0, one wave per row) or sum_j M[j][i] v[j] (trans = 1)
 __global__ void gemv_kernel(const double *__restrict__ Mx, int64_t ld, const double *__restrict__ v,
                             double *__restrict__ out, int n, int trans) {
+  Mx += (int64_t)blockIdx.y * ld * ld;        // blockIdx.y: problem of a batch (square matrices ld x ld, vectors of ld)
+  v += (int64_t)blockIdx.y * ld;
+  out += (int64_t)blockIdx.y * ld;
   if (!trans) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -323,6 +341,9 @@ __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double *__res
   const int col = blockIdx.x * 256 + threadIdx.x;
   const int j0 = blockIdx.y * 64;
   if (col >= n) return;
+  Mx += (int64_t)blockIdx.z * ld * ld;        // blockIdx.z: problem of a batch
+  v += (int64_t)blockIdx.z * ld;
+  part += (int64_t)blockIdx.z * ld * ld;
   double s0 = 0.0, s1 = 0.0;
   const int j1 = (j0 + 64 < n) ? j0 + 64 : n;
   int j = j0;
@@ -338,6 +359,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const double *__restrict__ 
                                                      double *__restrict__ out) {
   const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= n) return;
+  part += (int64_t)blockIdx.y * n * n;        // blockIdx.y: problem of a batch (n = Np)
+  out += (int64_t)blockIdx.y * n;
   double s = 0.0;
   for (int c = 0; c < nchunk; ++c) s += part[(int64_t)c * n + col];
   out[col] = s;
@@ -348,6 +371,10 @@ __global__ __launch_bounds__(1024) void lml_terms_kernel(const double *__restric
                                                          const double *__restrict__ L, int64_t ld, int N,
                                                          double *__restrict__ scal) {
   __shared__ double part[2][16];
+  y += (int64_t)blockIdx.x * ld;              // blockIdx.x: problem of a batch
+  alpha += (int64_t)blockIdx.x * ld;
+  L += (int64_t)blockIdx.x * ld * ld;
+  scal += blockIdx.x * 4;
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     a = fma(y[i], alpha[i], a);
@@ -375,6 +402,10 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(const double *__restrict_
   __shared__ double red[NTH_MAX][4];
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;
+  hp += (int64_t)blockIdx.z * (DPAD + 2);              // blockIdx.z: problem of a batch
+  alpha += (int64_t)blockIdx.z * ld;
+  Kinv += (int64_t)blockIdx.z * ld * ld;
+  gpart += (int64_t)blockIdx.z * gridDim.x * gridDim.y * NTH_MAX;
   if ((int)(blockIdx.x * blockDim.x) > j) {            // wholly above the diagonal: nothing to add
     if (threadIdx.x < NTH_MAX) gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NTH_MAX + threadIdx.x] = 0.0;
     return;
@@ -428,6 +459,8 @@ constexpr int GR_BLOCKS = 128;
 __global__ __launch_bounds__(256) void grad_reduce_stage1_kernel(const double *__restrict__ gpart, int nparts,
                                                                  double *__restrict__ stage, int nth) {
   __shared__ double part[4];
+  gpart += (int64_t)blockIdx.y * nparts * NTH_MAX;     // blockIdx.y: problem of a batch
+  stage += (int64_t)blockIdx.y * GR_BLOCKS * NTH_MAX;
   const int per = (nparts + GR_BLOCKS - 1) / GR_BLOCKS;
   const int i0 = blockIdx.x * per, i1 = (i0 + per < nparts) ? i0 + per : nparts;
   for (int t = 0; t < nth; ++t) {
@@ -443,6 +476,8 @@ __global__ __launch_bounds__(256) void grad_reduce_stage1_kernel(const double *_
 
 // ... and one workgroup sums the GR_BLOCKS slices
 __global__ __launch_bounds__(64) void grad_reduce_kernel(const double *__restrict__ stage, double *__restrict__ grad, int nth) {
+  stage += (int64_t)blockIdx.x * GR_BLOCKS * NTH_MAX;  // blockIdx.x: problem of a batch
+  grad += blockIdx.x * NTH_MAX;
   for (int t = 0; t < nth; ++t) {
     double s = 0.0;
     for (int i = threadIdx.x; i < GR_BLOCKS; i += 64) s += stage[i * NTH_MAX + t];
@@ -490,7 +525,8 @@ int device_invert_factor_to_Wt(const double *dL, int64_t N, double *Wt, int64_t 
                                double *W, double *T, hipStream_t st) {
   const int64_t Np = round_up(N, NB);
   hipLaunchKernelGGL(pad_lower_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)Np), dim3(256), 0, st, dL, (int)N, A, (int)Np);
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3((unsigned)(Np / NB)), dim3(256), 0, st, A, Np, Dinv, 0, 0, (int *)nullptr);
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3((unsigned)(Np / NB)), dim3(256), 0, st, A, Np, Dinv, 0, 0, (int *)nullptr,
+                     (int64_t)0, (int64_t)0);
   GP_HIP(hipGetLastError());
   int rc = device_trtri_blocked(A, Np, Dinv, W, T, st);
   if (rc != GPEMU_OK) return rc;
@@ -511,6 +547,7 @@ struct gpemu_fit {
          *scal = nullptr, *grad = nullptr, *gstage = nullptr;
   int *info = nullptr;
   int n_gparts = 0;
+  int cap = 0;              // problems the workspace holds (fit_reserve)
 };
 
 using namespace gpemu;
@@ -525,68 +562,109 @@ static int kind_of(int kernel_kind, double nu) {
   return nu == 0.5 ? 1 : (nu == 1.5 ? 2 : 3);
 }
 
-// K, Cholesky, W, alpha, lml terms for (theta, y); optional K^-1 + gradient
-static int fit_eval(gpemu_fit *f, const double *y, const double *theta, int64_t n_theta, bool want_grad,
-                    double *lml, double *grad) {
+// workspace for `nb` problems evaluated together (one set of matrices each)
+static int fit_reserve(gpemu_fit *f, int nb) {
+  if (nb <= f->cap) return GPEMU_OK;
+  GP_HIP(hipStreamSynchronize(f->stream));
+  double **ptrs[] = {&f->hp, &f->K, &f->Dinv, &f->W, &f->T, &f->Kinv, &f->y, &f->v, &f->alpha, &f->gpart, &f->scal,
+                     &f->grad, &f->gstage};
+  for (double **p : ptrs) { (void)hipFree(*p); *p = nullptr; }
+  (void)hipFree(f->info);
+  f->info = nullptr;
+  f->cap = 0;
+  const int64_t Np = f->Np;
+  hipError_t e = hipSuccess;
+  auto A = [&](double **p, int64_t n) { if (e == hipSuccess) e = hipMalloc((void **)p, sizeof(double) * (size_t)(n > 0 ? n : 1) * nb); };
+  A(&f->hp, DPAD + 2); A(&f->K, Np * Np); A(&f->Dinv, Np * NB); A(&f->W, Np * Np); A(&f->T, Np * Np);
+  A(&f->Kinv, Np * Np); A(&f->y, Np); A(&f->v, Np); A(&f->alpha, Np);
+  A(&f->gpart, (int64_t)f->n_gparts * NTH_MAX); A(&f->scal, 4); A(&f->grad, NTH_MAX);
+  A(&f->gstage, (int64_t)GR_BLOCKS * NTH_MAX);
+  if (e == hipSuccess) e = hipMalloc((void **)&f->info, sizeof(int) * nb);
+  if (e != hipSuccess) { set_error("fit workspace for %d problems: %s", nb, hipGetErrorString(e)); return GPEMU_ERR_HIP; }
+  f->cap = nb;
+  return GPEMU_OK;
+}
+
+// K, Cholesky, W, alpha, lml terms for nb problems (theta_z, y_z) at once -- every launch of the chain serves all of
+// them (blockIdx carries the problem index, the GEMMs run batched) --; optional K^-1 + gradient.  info[z] > 0: the
+// kernel matrix of problem z is not positive definite (its lml / grad are then meaningless).
+static int fit_eval_batch(gpemu_fit *f, int nb, const double *ys, const double *thetas, int64_t n_theta, bool want_grad,
+                          double *lml, double *grad, int *info_out) {
   const int64_t N = f->N, Np = f->Np, d = f->d;
   const int nth = (int)(d + f->has_const + f->has_noise);
   GP_ARG(n_theta == nth, "n_theta must be d (+1 constant) (+1 noise)");
+  GP_ARG(nb >= 1, "empty batch");
+  GP_TRY(fit_reserve(f, nb));
   hipStream_t st = f->stream;
-  double hp[DPAD + 2];
-  for (int i = 0; i < DPAD; ++i) hp[i] = i < d ? std::exp(theta[i]) : 1.0;
-  hp[DPAD] = f->has_const ? std::exp(theta[d]) : 0.0;
-  hp[DPAD + 1] = f->has_noise ? std::exp(theta[d + f->has_const]) : 0.0;
-  std::vector<double> hy((size_t)Np, 0.0);
-  for (int64_t i = 0; i < N; ++i) hy[i] = y[i];
-  GP_HIP(hipMemcpyAsync(f->hp, hp, sizeof(hp), hipMemcpyHostToDevice, st));
-  GP_HIP(hipMemcpyAsync(f->y, hy.data(), sizeof(double) * Np, hipMemcpyHostToDevice, st));
-  GP_HIP(hipMemsetAsync(f->info, 0, sizeof(int), st));
-  hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)Np), dim3(256), 0, st, f->X, f->hp,
-                     f->K, (int)N, (int)Np, f->kind, f->jitter);
+  std::vector<double> hp((size_t)nb * (DPAD + 2)), hy((size_t)nb * Np, 0.0);
+  for (int z = 0; z < nb; ++z) {
+    const double *theta = thetas + (size_t)z * nth;
+    double *h = hp.data() + (size_t)z * (DPAD + 2);
+    for (int i = 0; i < DPAD; ++i) h[i] = i < d ? std::exp(theta[i]) : 1.0;
+    h[DPAD] = f->has_const ? std::exp(theta[d]) : 0.0;
+    h[DPAD + 1] = f->has_noise ? std::exp(theta[d + f->has_const]) : 0.0;
+    for (int64_t i = 0; i < N; ++i) hy[(size_t)z * Np + i] = ys[(size_t)z * N + i];
+  }
+  GP_HIP(hipMemcpyAsync(f->hp, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice, st));
+  GP_HIP(hipMemcpyAsync(f->y, hy.data(), sizeof(double) * hy.size(), hipMemcpyHostToDevice, st));
+  GP_HIP(hipMemsetAsync(f->info, 0, sizeof(int) * nb, st));
+  hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)Np, (unsigned)nb), dim3(256), 0, st, f->X,
+                     f->hp, f->K, (int)N, (int)Np, f->kind, f->jitter);
   GP_HIP(hipGetLastError());
-  GP_TRY(device_cholesky_blocked(f->K, Np, f->Dinv, f->info, st));
-  GP_TRY(device_trtri_blocked(f->K, Np, f->Dinv, f->W, f->T, st));
+  GP_TRY(device_cholesky_blocked(f->K, Np, f->Dinv, f->info, st, nb));
+  GP_TRY(device_trtri_blocked(f->K, Np, f->Dinv, f->W, f->T, st, nb));
   // alpha = W^T (W y)
-  hipLaunchKernelGGL(gemv_kernel, dim3((unsigned)((Np + 3) / 4)), dim3(256), 0, st, f->W, Np, f->y, f->v, (int)Np, 0);
+  hipLaunchKernelGGL(gemv_kernel, dim3((unsigned)((Np + 3) / 4), (unsigned)nb), dim3(256), 0, st, f->W, Np, f->y, f->v,
+                     (int)Np, 0);
   {
     const int nchunk = (int)((Np + 63) / 64);                 // T (Np x Np) is free again after the inverse
-    hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)nchunk), dim3(256), 0, st,
-                       f->W, Np, f->v, f->T, (int)Np);
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, st, f->T, nchunk, (int)Np,
-                       f->alpha);
+    hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)nchunk, (unsigned)nb), dim3(256),
+                       0, st, f->W, Np, f->v, f->T, (int)Np);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)nb), dim3(256), 0, st, f->T, nchunk,
+                       (int)Np, f->alpha);
   }
-  hipLaunchKernelGGL(lml_terms_kernel, dim3(1), dim3(1024), 0, st, f->y, f->alpha, f->K, Np, (int)N, f->scal);
+  hipLaunchKernelGGL(lml_terms_kernel, dim3((unsigned)nb), dim3(1024), 0, st, f->y, f->alpha, f->K, Np, (int)N, f->scal);
   GP_HIP(hipGetLastError());
   if (want_grad) {
     GemmArgs g;  // K^-1 = W^T W: symmetric, so only the tiles on and below the diagonal; W is lower triangular, so
     g.A = f->W; g.lda = Np; g.B = f->W; g.ldb = Np; g.C = f->Kinv; g.ldc = Np;   // (W^T W)[a][b] = sum_{i >= max(a, b)}:
     g.M = (int)Np; g.N = (int)Np; g.K = (int)Np;                                  // N^3/3 FLOP instead of 2 N^3
     g.lower_only = 1; g.k_from_m = 1;
-    GP_TRY(launch_gemm(g, true, true, 1, st));
-    dim3 grid((unsigned)((N + 255) / 256), (unsigned)N);
+    g.strideA = Np * Np; g.strideB = Np * Np; g.strideC = Np * Np;
+    GP_TRY(launch_gemm(g, true, true, nb, st));
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)N, (unsigned)nb);
     hipLaunchKernelGGL(lml_grad_kernel, grid, dim3(256), 0, st, f->X, f->hp, f->alpha, f->Kinv, Np, f->gpart, (int)N,
                        (int)d, f->kind, f->has_const, f->has_noise);
-    hipLaunchKernelGGL(grad_reduce_stage1_kernel, dim3(GR_BLOCKS), dim3(256), 0, st, f->gpart, (int)(grid.x * grid.y),
-                       f->gstage, nth);
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3(1), dim3(64), 0, st, f->gstage, f->grad, nth);
+    hipLaunchKernelGGL(grad_reduce_stage1_kernel, dim3(GR_BLOCKS, (unsigned)nb), dim3(256), 0, st, f->gpart,
+                       (int)(grid.x * grid.y), f->gstage, nth);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)nb), dim3(64), 0, st, f->gstage, f->grad, nth);
     GP_HIP(hipGetLastError());
   }
-  double hs[2];
-  double hg[NTH_MAX];
-  int info = 0;
-  GP_HIP(hipMemcpyAsync(hs, f->scal, sizeof(hs), hipMemcpyDeviceToHost, st));
-  GP_HIP(hipMemcpyAsync(&info, f->info, sizeof(int), hipMemcpyDeviceToHost, st));
-  if (want_grad) GP_HIP(hipMemcpyAsync(hg, f->grad, sizeof(double) * nth, hipMemcpyDeviceToHost, st));
+  std::vector<double> hs((size_t)nb * 4), hg((size_t)nb * NTH_MAX);
+  std::vector<int> info((size_t)nb, 0);
+  GP_HIP(hipMemcpyAsync(hs.data(), f->scal, sizeof(double) * hs.size(), hipMemcpyDeviceToHost, st));
+  GP_HIP(hipMemcpyAsync(info.data(), f->info, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+  if (want_grad) GP_HIP(hipMemcpyAsync(hg.data(), f->grad, sizeof(double) * hg.size(), hipMemcpyDeviceToHost, st));
   GP_HIP(hipStreamSynchronize(st));
-  if (info != 0) {
-    set_error("kernel matrix is not positive definite (pivot %d): the kernel is not returning a positive "
-              "definite matrix; try increasing alpha", info);
-    return info;   // sklearn raises LinAlgError here (skl _gpr.py:350-358)
+  int first_bad = 0;
+  for (int z = 0; z < nb; ++z) {
+    if (info_out) info_out[z] = info[z];
+    if (info[z] != 0 && first_bad == 0) first_bad = info[z];
+    if (lml) lml[z] = -0.5 * hs[(size_t)z * 4] - hs[(size_t)z * 4 + 1] - 0.5 * (double)N * std::log(2.0 * M_PI);
+    if (want_grad && grad)
+      for (int t = 0; t < nth; ++t) grad[(size_t)z * nth + t] = hg[(size_t)z * NTH_MAX + t];
   }
-  if (lml) *lml = -0.5 * hs[0] - hs[1] - 0.5 * (double)N * std::log(2.0 * M_PI);
-  if (want_grad && grad)
-    for (int t = 0; t < nth; ++t) grad[t] = hg[t];
+  if (first_bad != 0 && !info_out) {
+    set_error("kernel matrix is not positive definite (pivot %d): the kernel is not returning a positive "
+              "definite matrix; try increasing alpha", first_bad);
+    return first_bad;   // sklearn raises LinAlgError here (skl _gpr.py:350-358)
+  }
   return GPEMU_OK;
+}
+
+static int fit_eval(gpemu_fit *f, const double *y, const double *theta, int64_t n_theta, bool want_grad,
+                    double *lml, double *grad) {
+  return fit_eval_batch(f, 1, y, theta, n_theta, want_grad, lml, grad, nullptr);
 }
 
 extern "C" {
@@ -612,12 +690,8 @@ int gpemu_fit_create(gpemu_fit **out, int device, int64_t N, int64_t d, const do
   const int64_t Np = f->Np;
   f->n_gparts = (int)(((N + 255) / 256) * N);
   hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
-  auto A = [&](double **p, int64_t n) { if (e == hipSuccess) e = hipMalloc((void **)p, sizeof(double) * (size_t)(n > 0 ? n : 1)); };
-  A(&f->X, Np * DPAD); A(&f->hp, DPAD + 2); A(&f->K, Np * Np); A(&f->Dinv, Np * NB);
-  A(&f->W, Np * Np); A(&f->T, Np * Np); A(&f->Kinv, Np * Np); A(&f->y, Np); A(&f->v, Np); A(&f->alpha, Np);
-  A(&f->gpart, (int64_t)f->n_gparts * NTH_MAX); A(&f->scal, 4); A(&f->grad, NTH_MAX);
-  A(&f->gstage, (int64_t)GR_BLOCKS * NTH_MAX);
-  if (e == hipSuccess) e = hipMalloc((void **)&f->info, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void **)&f->X, sizeof(double) * (size_t)(Np * DPAD));
+  if (e == hipSuccess && fit_reserve(f, 1) != GPEMU_OK) e = hipErrorOutOfMemory;
   std::vector<double> hX((size_t)(Np * DPAD), 0.0);
   for (int64_t i = 0; i < N; ++i)
     for (int64_t dd = 0; dd < d; ++dd) hX[i * DPAD + dd] = X[i * d + dd];
@@ -648,6 +722,14 @@ int gpemu_fit_lml(gpemu_fit *f, const double *y, const double *theta, int64_t n_
   GP_ARG(f && y && theta && lml, "null pointer");
   GP_HIP(hipSetDevice(f->device));
   return fit_eval(f, y, theta, n_theta, grad != nullptr, lml, grad);
+}
+
+int gpemu_fit_lml_batch(gpemu_fit *f, int64_t n_problems, const double *ys, const double *thetas, int64_t n_theta,
+                        double *lml, double *grad, int32_t *info) {
+  GP_ARG(f && ys && thetas && lml && info, "null pointer");
+  GP_ARG(n_problems >= 1 && n_problems <= 4096, "n_problems");
+  GP_HIP(hipSetDevice(f->device));
+  return fit_eval_batch(f, (int)n_problems, ys, thetas, n_theta, grad != nullptr, lml, grad, info);
 }
 
 int gpemu_fit_factor(gpemu_fit *f, const double *y, const double *theta, int64_t n_theta, double *L_out,

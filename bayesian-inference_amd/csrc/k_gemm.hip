@@ -28,9 +28,11 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double sB[2][GK * GSK];
   const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
   if (g.lower_only && n0 > m0) return;
-  const double *A = g.A + (int64_t)blockIdx.z * g.strideA;
-  const double *B = g.B + (int64_t)blockIdx.z * g.strideB;
-  double *C = g.C + (int64_t)blockIdx.z * g.strideC;
+  const int z1 = g.batch1 > 0 ? (int)(blockIdx.z % g.batch1) : (int)blockIdx.z;
+  const int z2 = g.batch1 > 0 ? (int)(blockIdx.z / g.batch1) : 0;
+  const double *A = g.A + (int64_t)z1 * g.strideA + (int64_t)z2 * g.stride2A;
+  const double *B = g.B + (int64_t)z1 * g.strideB + (int64_t)z2 * g.stride2B;
+  double *C = g.C + (int64_t)z1 * g.strideC + (int64_t)z2 * g.stride2C;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;

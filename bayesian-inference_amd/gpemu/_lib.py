@@ -54,6 +54,7 @@ _SIGNATURES = {
                                    C.c_int, C.c_int, C.c_double]),
     "gpemu_fit_destroy": (C.c_int, [C.c_void_p]),
     "gpemu_fit_lml": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.POINTER(C.c_double), C.c_void_p]),
+    "gpemu_fit_lml_batch": (C.c_int, [C.c_void_p, c_i64, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpemu_fit_factor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64, C.c_void_p, C.c_void_p,
                                    C.POINTER(C.c_double)]),
     "gpemu_kernel_matrix": (C.c_int, [C.c_int, c_i64, c_i64, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_double,

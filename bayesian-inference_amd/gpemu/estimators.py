@@ -190,7 +190,10 @@ class GaussianProcessRegressor:
         import scipy.optimize
 
         def obj(theta):
-            lml, grad = dfit.lml(y, theta, eval_gradient=True)
+            try:
+                lml, grad = dfit.lml(y, theta, eval_gradient=True)
+            except _fit.LinAlgError:        # skl _gpr.py:586-590: a kernel matrix that is not positive definite
+                return np.inf, np.zeros_like(theta)
             return -lml, -grad
         res = scipy.optimize.minimize(obj, theta0, method="L-BFGS-B", jac=True, bounds=bounds)
         if res.status != 0:
@@ -281,20 +284,72 @@ class GaussianProcessRegressor:
         return mean[:, 0]
 
 
+class _LockStepEvaluator:
+    """Rendezvous of concurrent L-BFGS-B runs on ONE DeviceFit: every optimiser thread hands in its (target, theta)
+    and waits; when all running optimisers are waiting (or ``max_batch`` have gathered) the last arriver evaluates
+    the whole batch in one launch chain (``gpemu_fit_lml_batch``) and wakes the others.  Each problem's arithmetic
+    is what a stand-alone evaluation does, so the optima do not depend on who shares a batch with whom."""
+
+    def __init__(self, dfit, max_batch):
+        import threading
+        self.dfit, self.max_batch = dfit, int(max_batch)
+        self.cv = threading.Condition()
+        self.waiting = []
+        self.running = 0
+        self.error = None
+
+    def enter(self):
+        with self.cv:
+            self.running += 1
+
+    def leave(self):
+        with self.cv:
+            self.running -= 1
+            if self.waiting and len(self.waiting) >= self.running:
+                self._flush()
+
+    def _flush(self):
+        batch, self.waiting = self.waiting, []
+        try:
+            lml, grad, info = self.dfit.lml_batch(np.stack([b["y"] for b in batch]), np.stack([b["theta"] for b in batch]))
+            for i, b in enumerate(batch):
+                b["out"] = (lml[i], grad[i], int(info[i]))
+        except BaseException as exc:        # every waiting optimiser must wake up
+            self.error = exc
+            for b in batch:
+                b["out"] = (np.nan, None, -1)
+        self.cv.notify_all()
+
+    def evaluate(self, y, theta):
+        slot = {"y": y, "theta": np.array(theta, dtype=np.float64), "out": None}
+        with self.cv:
+            self.waiting.append(slot)
+            if len(self.waiting) >= min(self.running, self.max_batch):
+                self._flush()
+            while slot["out"] is None:
+                self.cv.wait()
+            if self.error is not None:
+                raise self.error
+        lml, grad, info = slot["out"]
+        if info != 0:                       # skl _gpr.py:586-590
+            return np.inf, np.zeros_like(slot["theta"])
+        return -lml, -grad
+
+
 def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy_X_train=False, device=None,
             n_streams=None):
     """One GaussianProcessRegressor per column of ``Y_columns`` (N x k), fitted concurrently.
 
     The k GPs and their restarts are ``k (1 + n_restarts)`` independent L-BFGS-B problems on the same design
     (ref: emulation.py:169-172 fits them one after the other).  They are spread over a pool of host threads,
-    each driving its own ``DeviceFit`` -- its own HIP stream and workspace -- so that the short, latency-bound
-    kernels of one log-marginal-likelihood evaluation overlap with those of the others on the GPU.  The
+    advancing in LOCK STEP on one ``DeviceFit``: whenever all running optimisers wait for a function value, the
+    whole batch of (target, theta) pairs goes through ONE chain of launches (``gpemu_fit_lml_batch``: kernel matrices,
+    blocked Cholesky, triangular inverses, K^-1 and gradient contractions of all problems together).  The
     restart points are drawn first, from numpy's global RandomState in the order the sequential loop draws
-    them, so the result does not depend on the thread schedule.  ``n_streams`` (env GPEMU_FIT_STREAMS,
-    default 8): 1 reproduces the sequential loop.
+    them, so the result does not depend on the thread schedule.  ``n_streams`` (env GPEMU_FIT_BATCH, default 32):
+    optimisers in flight = problems per launch chain; 1 reproduces the sequential loop.
     """
     import concurrent.futures
-    import threading
 
     X = np.array(design, dtype=np.float64) if copy_X_train else np.asarray(design, dtype=np.float64)
     Yc = np.asarray(Y_columns, dtype=np.float64)
@@ -317,33 +372,39 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
             for _ in range(n_restarts_optimizer):
                 starts[i].append(rng.uniform(bounds[:, 0], bounds[:, 1]))
     if n_streams is None:
-        n_streams = int(os.environ.get("GPEMU_FIT_STREAMS", "8"))
+        n_streams = int(os.environ.get("GPEMU_FIT_BATCH", "32"))
     tasks = [(i, j) for i in range(k_gp) for j in range(len(starts[i]))]
-    n_threads = max(1, min(int(n_streams), max(len(tasks), k_gp)))
-    local = threading.local()
-    handles, hlock = [], threading.Lock()
+    n_threads = max(1, min(int(n_streams), max(len(tasks), 1)))
+    shared = _fit.DeviceFit(X, kk.kind, kk.nu, kk.has_const, kk.has_noise, alpha, device)
+    handles = [shared]
+    evaluator = _LockStepEvaluator(shared, n_threads)
+    columns = [np.ascontiguousarray(Yc[:, i]) for i in range(k_gp)]
 
-    def dfit():
-        if getattr(local, "dfit", None) is None:
-            local.dfit = _fit.DeviceFit(X, kk.kind, kk.nu, kk.has_const, kk.has_noise, alpha, device)
-            with hlock:
-                handles.append(local.dfit)
-        return local.dfit
+    class _Shared:                      # what GaussianProcessRegressor._optimise calls on its fit handle
+        def lml(self, y, theta, eval_gradient=True):
+            val, grad = evaluator.evaluate(y, theta)
+            if not np.isfinite(val):
+                raise _fit.LinAlgError("kernel matrix is not positive definite")
+            return -val, -grad
 
     def run_start(task):
         i, j = task
-        return gprs[i]._optimise(dfit(), Yc[:, i], starts[i][j], kk.bounds)
-
-    def finish(i, optima):
-        return gprs[i]._adopt(dfit(), X, Yc[:, i], optima)
+        evaluator.enter()
+        try:
+            if n_threads == 1:          # the sequential loop, stand-alone evaluations
+                return gprs[i]._optimise(shared, columns[i], starts[i][j], kk.bounds)
+            return gprs[i]._optimise(_Shared(), columns[i], starts[i][j], kk.bounds)
+        finally:
+            evaluator.leave()
 
     try:
         with concurrent.futures.ThreadPoolExecutor(max_workers=n_threads) as pool:
             optima = list(pool.map(run_start, tasks))
-            per_gp = [[] for _ in range(k_gp)]
-            for (i, _j), opt in zip(tasks, optima):
-                per_gp[i].append(opt)
-            list(pool.map(finish, range(k_gp), per_gp))
+        per_gp = [[] for _ in range(k_gp)]
+        for (i, _j), opt in zip(tasks, optima):
+            per_gp[i].append(opt)
+        for i in range(k_gp):
+            gprs[i]._adopt(shared, X, columns[i], per_gp[i])
     finally:
         n_eval = sum(h.n_evaluations for h in handles)
         for h in handles:

@@ -58,6 +58,22 @@ class DeviceFit:
         self._check(_lib.lib().gpemu_fit_lml(self._h, ptr(y), ptr(theta), self.n_theta, C.byref(val), ptr(grad)))
         return (val.value, grad) if eval_gradient else val.value
 
+    def lml_batch(self, ys, thetas, eval_gradient=True):
+        """``n`` (target, theta) pairs evaluated together (one launch chain for all of them): ys (n, N),
+        thetas (n, n_theta) -> lml (n,), grad (n, n_theta) or None, info (n,) (non-zero: that kernel matrix is not
+        positive definite)."""
+        ys = as_f64(ys)
+        thetas = as_f64(thetas)
+        n = ys.shape[0]
+        if ys.shape != (n, self.N) or thetas.shape != (n, self.n_theta):
+            raise ValueError("ys must be (n, N) and thetas (n, n_theta)")
+        lml = np.empty(n)
+        grad = np.empty((n, self.n_theta)) if eval_gradient else None
+        info = np.zeros(n, dtype=np.int32)
+        self.n_evaluations += n
+        check(_lib.lib().gpemu_fit_lml_batch(self._h, n, ptr(ys), ptr(thetas), self.n_theta, ptr(lml), ptr(grad), ptr(info)))
+        return lml, grad, info
+
     def factor(self, y, theta):
         """(L_ (N,N) lower, alpha_ (N,), lml) at theta (skl _gpr.py:346-364)."""
         y = as_f64(y, (self.N,))

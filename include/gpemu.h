@@ -137,6 +137,13 @@ int gpemu_fit_destroy(gpemu_fit *f);
 /* lml and, if grad != NULL, d lml / d theta [n_theta] for target y[N] */
 int gpemu_fit_lml(gpemu_fit *f, const double *y, const double *theta, int64_t n_theta, double *lml,
                   double *grad);
+/* The same for n_problems (target, theta) pairs AT ONCE: ys[n_problems*N], thetas[n_problems*n_theta] ->
+ * lml[n_problems], grad[n_problems*n_theta] (or NULL), info[n_problems] (0, or the failing pivot of a kernel matrix
+ * that is not positive definite: that problem's lml / grad are meaningless, the others are valid).  Every launch of the
+ * evaluation chain serves the whole batch: the k GPs x (1 + n_restarts) independent maximisations of
+ * ref: emulation.py:169-172 (n_restarts: 50 in config/jet_substructure.yaml:80) advance in lock step. */
+int gpemu_fit_lml_batch(gpemu_fit *f, int64_t n_problems, const double *ys, const double *thetas, int64_t n_theta,
+                        double *lml, double *grad, int32_t *info);
 /* L_out[N*N] (lower, zeros above), alpha_out[N], lml at theta; any output may be NULL */
 int gpemu_fit_factor(gpemu_fit *f, const double *y, const double *theta, int64_t n_theta,
                      double *L_out, double *alpha_out, double *lml);

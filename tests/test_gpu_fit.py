@@ -119,8 +119,9 @@ def test_scaler_pca_vs_reference(name):
 
 
 def test_concurrent_gp_fits_equal_the_sequential_loop():
-    """fit_gps (k GPs x (1 + restarts) optimisations over a pool of host threads, one DeviceFit / HIP stream each)
-    gives exactly what the sequential per-PC loop gives for the same numpy seed."""
+    """fit_gps (k GPs x (1 + restarts) optimisations advancing in lock step, their log-marginal-likelihood
+    evaluations batched into one launch chain: gpemu_fit_lml_batch) gives exactly what the sequential per-PC loop
+    gives for the same numpy seed."""
     from gpemu import estimators as E
     g = GU.load("g1_matern15_noise")
     spec = GU.spec_of(g)
@@ -141,3 +142,40 @@ def test_concurrent_gp_fits_equal_the_sequential_loop():
         np.testing.assert_array_equal(a.L_, b.L_)
         np.testing.assert_array_equal(a.alpha_, b.alpha_)
         assert a.log_marginal_likelihood_value_ == b.log_marginal_likelihood_value_
+
+
+def test_batched_lml_equals_single_evaluations():
+    """gpemu_fit_lml_batch: several (target, theta) pairs through ONE launch chain give, bit for bit, what the
+    stand-alone evaluations give (every kernel carries the problem index, the GEMMs run batched), including a
+    problem whose kernel matrix is not positive definite next to valid ones."""
+    from gpemu.fit import DeviceFit, LinAlgError
+    g = GU.load("g2_rbf_noise")
+    fit, spec, X = _fit_for(g)
+    ytr = g["Y_pca_truncated"]
+    k = int(g["n_pc"])
+    rng = np.random.default_rng(8)
+    ys = np.stack([ytr[:, i % k] for i in range(7)])
+    thetas = np.stack([g["theta"][i % k] + 0.3 * rng.normal(size=g["theta"].shape[1]) for i in range(7)])
+    lml, grad, info = fit.lml_batch(ys, thetas)
+    assert np.all(info == 0)
+    for i in range(7):
+        l1, g1 = fit.lml(ys[i], thetas[i])
+        assert l1 == lml[i]
+        np.testing.assert_array_equal(g1, grad[i])
+    lml2, _, info2 = fit.lml_batch(ys[:3], thetas[:3], eval_gradient=False)
+    np.testing.assert_array_equal(lml2, lml[:3])
+    fit.close()
+    # a noise-free kernel with tiny length scales on duplicated rows is singular: that problem alone is flagged
+    Xd = np.vstack([X[:40], X[:40]])
+    f2 = DeviceFit(Xd, kernel_kind=0, has_noise=False, jitter=0.0)
+    th_ok = np.log((g["hi"] - g["lo"]) * 0.5)
+    yd = np.r_[ytr[:40, 0], ytr[:40, 0]]
+    with pytest.raises(LinAlgError):
+        f2.lml(yd, th_ok)
+    f3 = DeviceFit(X[:80], kernel_kind=0, has_noise=False, jitter=1e-6)
+    l_ok, _ = f3.lml(ytr[:80, 0], th_ok)
+    f3.close()
+    lb, gb, ib = f2.lml_batch(np.stack([yd, yd]), np.stack([th_ok, th_ok]))
+    assert np.all(ib != 0)
+    f2.close()
+    assert np.isfinite(l_ok)
