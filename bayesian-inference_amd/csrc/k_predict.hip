@@ -531,10 +531,11 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_persistent_kernel(
 typedef const __attribute__((address_space(1))) void *gas_ptr;
 typedef __attribute__((address_space(3))) void *las_ptr;
 
+template <bool INTERLEAVE>   // the six loads of k-tile s+2 go out one by one between the MFMA groups of k-tile s
 __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
     const double *__restrict__ Wt, const double *__restrict__ KS, double *__restrict__ out,
     const TrmmItem *__restrict__ sched, const int *__restrict__ sched_cnt, int max_items,
-    int64_t Npad, int64_t Bcap, int k, int nrb) {
+    int64_t Npad, int64_t Bcap, int k, int nrb, unsigned long long *__restrict__ stamps) {
   constexpr int BUFD = KT * TM + KT * TILE;            // one k-tile: [W tile | K_*^T tile], 48 KiB
   __shared__ __attribute__((aligned(16))) double L0[BUFD];
   __shared__ __attribute__((aligned(16))) double L1[BUFD];
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
   const int wm = wave >> 2, wn = wave & 3;
   const int lr = lane & 15, lk = lane >> 4;
 
+  if (stamps && tid == 0) stamps[blockIdx.x * 16] = __builtin_amdgcn_s_memrealtime();
   const int nitems = sched_cnt[blockIdx.x];
   if (tid < nitems) s_items[tid] = sched[(int64_t)blockIdx.x * max_items + tid];
   __syncthreads();
@@ -589,13 +591,12 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
                  : "s"(lds_off), "v"(src)
                  : "memory");
   };
-  auto dma = [&](double *dA) {
+  // one of the wave's six loads of a k-tile (part compile-time after unrolling); the cursor moves on after the last
+  auto dma_part = [&](double *dA, int part) {
     double *dB = dA + KT * TM;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) dma1(l_pa + offA[j], dA + (wave * 2 + j) * 128);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dma1(l_pb + offB[r], dB + (wave * 4 + r) * 128);
-    if (l_item < nitems) {
+    if (part < 2) dma1(l_pa + offA[part], dA + (wave * 2 + part) * 128);
+    else dma1(l_pb + offB[part - 2], dB + (wave * 4 + part - 2) * 128);
+    if (part == 5 && l_item < nitems) {
       if (++l_t == l_nt) {
         if (++l_item < nitems) l_open();   // else: stay on the last k-tile (harmless re-read)
       } else {
@@ -603,6 +604,10 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
         l_pb += bstep;
       }
     }
+  };
+  auto dma = [&](double *dA) {
+#pragma unroll
+    for (int part = 0; part < 6; ++part) dma_part(dA, part);
   };
 
   // vmcnt(6) lgkmcnt(0): everything but this wave's six newest loads has landed, every LDS read has returned
@@ -614,6 +619,7 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
   dma(L0);
   dma(L1);
   tile_barrier();
+  if (stamps && tid == 0) stamps[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime();
 
   d4 acc[2][2];
 #pragma unroll
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
 
   auto step = [&](const double *cA, double *nA) -> bool {
     const double *cB = cA + KT * TM;
-    dma(nA);                                                    // k-tile +2 -> the buffer k-tile -1 was read from
+    if (!INTERLEAVE) dma(nA);                                   // k-tile +2 -> the buffer k-tile -1 was read from
     if (cur.half) {
       const int ib = lk * TILE + (((cur.col0 & 64) + wn * 16 + lr) ^ sw);
       double a[2][2], b[2];
@@ -648,6 +654,7 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
           acc[mi][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cu][mi], b[cu], acc[mi][0], 0, 0, 0);
+        if (INTERLEAVE && ks < 6) dma_part(nA, ks);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -672,6 +679,7 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cu][mi], b[cu][ni], acc[mi][ni], 0, 0, 0);
+        if (INTERLEAVE && ks < 6) dma_part(nA, ks);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -699,6 +707,7 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+      if (stamps && tid == 0 && c_item < 13) stamps[blockIdx.x * 16 + 2 + c_item] = __builtin_amdgcn_s_memrealtime();
       if (++c_item == nitems) return true;
       cur = my[c_item];
       c_nt = (int)(((int64_t)cur.rb * TM + TM + KT - 1) / KT);
@@ -967,16 +976,45 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
   }
   const int pe0 = prof_mark(m, st);
   static const bool use_dma = getenv("GPEMU_TRMM_NO_DMA") == nullptr;   // register-staged variant kept for comparison
-  if (use_dma)
-    hipLaunchKernelGGL(trmm_vsq_dma_kernel, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
+  static const bool interleave = getenv("GPEMU_TRMM_DMA_TOP") == nullptr;
+  static const char *stamp_path = getenv("GPEMU_TRMM_STAMP_FILE");       // diagnostic: per-worker time stamps
+  static unsigned long long *dstamps = nullptr;
+  static int stamp_calls = 0;
+  if (stamp_path && !dstamps) {
+    GP_HIP(hipMalloc((void **)&dstamps, sizeof(unsigned long long) * 16 * 1024));
+    GP_HIP(hipMemset(dstamps, 0, sizeof(unsigned long long) * 16 * 1024));
+  }
+  if (use_dma && interleave)
+    hipLaunchKernelGGL(trmm_vsq_dma_kernel<true>, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
                        w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
-                       m->Npad, w.Bcap, (int)m->k, nrb);
+                       m->Npad, w.Bcap, (int)m->k, nrb, dstamps);
+  else if (use_dma)
+    hipLaunchKernelGGL(trmm_vsq_dma_kernel<false>, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
+                       w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
+                       m->Npad, w.Bcap, (int)m->k, nrb, dstamps);
   else
     hipLaunchKernelGGL(trmm_vsq_persistent_kernel, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
                        w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
                        m->Npad, w.Bcap, (int)m->k, nrb);
   GP_HIP(hipGetLastError());
   prof_pair(m, 0, pe0, prof_mark(m, st));
+  if (stamp_path && ++stamp_calls == 600) {
+    GP_HIP(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h(16 * 1024);
+    GP_HIP(hipMemcpy(h.data(), dstamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    std::vector<int> cnt(m->sched_workers);
+    GP_HIP(hipMemcpy(cnt.data(), m->sched_cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost));
+    if (FILE *f = fopen(stamp_path, "w")) {
+      unsigned long long t0 = ~0ull;
+      for (int wk = 0; wk < m->sched_workers; ++wk) t0 = std::min(t0, h[wk * 16]);
+      for (int wk = 0; wk < m->sched_workers; ++wk) {
+        fprintf(f, "%d %d", wk, cnt[wk]);
+        for (int i = 0; i < 2 + std::min(cnt[wk], 13); ++i) fprintf(f, " %.2f", (double)(h[wk * 16 + i] - t0) / 100.0);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
 #ifdef GPEMU_TRMM_STAMPS
   if (getenv("GPEMU_DUMP_STAMPS")) {
     static int dumped = 0;
