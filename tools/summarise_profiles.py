@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Turn a tools/collect_profiles.sh run (gpurun_out/<tag>/) into the summaries committed under profiles/:
+    python tools/summarise_profiles.py <tag> <prefix>      e.g.  r2p r02
+kernel-stats CSVs are copied as they are; the PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) are reduced to
+bytes per launch per kernel -- counters are in KiB... FETCH_SIZE doubled (gfx950: 128-byte requests tallied at 64,
+MI355X_MICROARCH.md section HBM) -- and written as <prefix>_traffic.json."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag, prefix = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+
+
+def first(pattern):
+    hits = glob.glob(os.path.join(src, pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+for name, out in (("stats_bench/**/*kernel_stats.csv", f"{prefix}_bench_kernel_stats.csv"),
+                  ("stats_emu8/**/*kernel_stats.csv", f"{prefix}_emulated_world8_kernel_stats.csv")):
+    f = first(name)
+    if f:
+        shutil.copy(f, os.path.join(dst, out))
+for name, out in (("bench_default.json", f"{prefix}_bench_default.json"), ("emulated_sharding.jsonl", f"{prefix}_emulated_sharding.jsonl"),
+                  ("fit_lml.txt", f"{prefix}_fit_lml.txt"), ("predict_gbps.txt", f"{prefix}_predict_gbps.txt"),
+                  ("closure_batch.txt", f"{prefix}_closure_batch.txt"), ("pca.txt", f"{prefix}_pca.txt")):
+    f = os.path.join(src, name)
+    if os.path.exists(f):
+        lines = [ln for ln in open(f) if "amdgpu.ids" not in ln]
+        if name == "bench_default.json":
+            lines = [ln for ln in lines if ln.startswith("{")]
+        open(os.path.join(dst, out), "w").writelines(lines)
+
+
+def pmc(dirname, counter):
+    f = first(f"{dirname}/**/*counter_collection.csv")
+    per = {}
+    if not f:
+        return per
+    for row in csv.DictReader(open(f)):
+        if row.get("Counter_Name") != counter:
+            continue
+        name = row["Kernel_Name"].split("(")[0]
+        d = per.setdefault(name, {})
+        d[row["Dispatch_Id"]] = d.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+    return {k: (len(v), sum(v.values()) / len(v)) for k, v in per.items()}
+
+
+traffic = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over tools/prof_driver.py "
+                   "<B> 5 (C3 model, batched log-posterior calls of B rows); counter values in KiB summed over the 8 XCDs; "
+                   "FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM); fabric-side counters include "
+                   "Infinity-Cache hits", "batches": {}}
+for B in (512, 64):
+    fe, wr = pmc(f"pmc_fetch_{B}", "FETCH_SIZE"), pmc(f"pmc_write_{B}", "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fe) | set(wr)):
+        if not any(s in k for s in ("trmm", "kstar", "loglik", "front")):
+            continue
+        n, f_kb = fe.get(k, (0, 0.0))
+        _, w_kb = wr.get(k, (0, 0.0))
+        kernels[k] = {"launches": n, "FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb,
+                      "bytes_per_launch_corrected": 1024.0 * (2.0 * f_kb + w_kb)}
+    traffic["batches"][str(B)] = kernels
+json.dump(traffic, open(os.path.join(dst, f"{prefix}_traffic.json"), "w"), indent=1)
+print(json.dumps(traffic["batches"], indent=1)[:3000])
