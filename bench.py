@@ -146,17 +146,25 @@ def measure_fit_c3(device=0, n_restarts=50):
 
 
 def committed_traffic(world):
-    """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_e_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied).
-    The counters cannot be collected from inside this process; null when the file or shape differs."""
+    """HBM/fabric bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes
+    (profiles/rNN*_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied; made by
+    tools/collect_profiles.sh + tools/summarise_profiles.py).  The counters cannot be collected from inside this
+    process; null when no file holds the kernel at this shape."""
     if world != 1:
         return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_e_traffic.json")) as f:
-            k = json.load(f)["kernels"]["gpemu::trmm_vsq_dma_kernel"]
-        return {"bytes_per_launch": k["bytes_per_launch_corrected"], "source": "profiles/r01_e_traffic.json"}
-    except Exception:
-        return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+            kernels = doc.get("batches", {}).get("512") or doc.get("kernels", {})
+            for name, k in kernels.items():
+                if "trmm_vsq_dma_kernel" in name:
+                    return {"bytes_per_launch": k["bytes_per_launch_corrected"],
+                            "source": "profiles/" + os.path.basename(path)}
+        except Exception:
+            continue
+    return None
 
 
 def cpu_baseline(seconds_budget=20.0):
