@@ -20,6 +20,9 @@
 
 namespace gpemu {
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
 // per column (thread = column, rows accumulated in order, as numpy reduces axis 0)
 __global__ void column_stats_kernel(const double *__restrict__ Y, int N, int F, double *__restrict__ mean,
                                     double *__restrict__ var, double *__restrict__ scale) {
@@ -71,70 +74,301 @@ __global__ void pca_centre_kernel(const double *__restrict__ Ys, int N, int F, d
   }
 }
 
-__global__ void identity_kernel(double *V, int n, int64_t ld) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)n * ld) return;
-  V[idx] = ((idx / ld) == (idx % ld)) ? 1.0 : 0.0;
+// ---- block one-sided Jacobi ---------------------------------------------------------------------------------
+// The work matrix W holds, per column, the m entries of the matrix being orthogonalised followed (from row mpad
+// on) by the n entries of the accumulated rotations V; its columns are dealt into blocks of PB = 16 or 32.  One ROUND
+// pairs the blocks up (round-robin tournament); for every pair of blocks, i.e. PP = 2 PB columns X:
+//   gram   A = X^T X over the first mpad rows: MFMA, the rows split over several workgroups, partial sums to HBM
+//   solve  one workgroup adds the partials in a fixed order and runs Jacobi rotations on the PP x PP Gram matrix in
+//          LDS (two-sided: A <- R^T A R needs no dot products), accumulating them in J; every rotation also orders
+//          the two columns by norm (de Rijk), which speeds up convergence
+//   apply  X <- X J for all rows of W (MFMA, computed transposed so that loads and stores follow the columns)
+// The rotations are chosen from the Gram matrix but applied to the columns themselves, as orthogonal
+// transformations: like the scalar iteration this never squares the condition number of the data, and the
+// convergence test (largest |x_i . x_j| / (|x_i| |x_j|) met in a sweep <= sqrt(m) eps) is made on Gram entries
+// recomputed from the current columns.  Per sweep the matrix is read and written nb - 1 times instead of n - 1.
+constexpr int PCA_GLD = 66;   // LDS leading dimension of the gram tile: a half-wave's 16 x 2 fragment reads hit 32 banks
+constexpr int PCA_JLD = 80;   // and of J in the apply kernel
+
+__device__ __forceinline__ void block_pair(int nb, int round, int i, int &P, int &Q) {
+  const int nm1 = nb - 1;
+  if (i == 0) { P = nm1; Q = round % nm1; }
+  else { P = (round + i) % nm1; Q = (round - i + nm1) % nm1; }
+  if (P > Q) { const int t = P; P = Q; Q = t; }
 }
 
-// One round of the tournament: workgroup b rotates columns (p, q) of G (length m) and of V (length n).
-__global__ __launch_bounds__(256) void jacobi_round_kernel(double *__restrict__ G, int64_t ldg, int m,
-                                                           double *__restrict__ V, int64_t ldv, int n, int npad,
-                                                           int round, unsigned long long *__restrict__ offmax) {
-  __shared__ double red[3][4];
-  __shared__ double cs[2];
-  const int i = blockIdx.x;
-  const int nm1 = npad - 1;
-  int p, q;
-  if (i == 0) { p = nm1; q = round % nm1; }
-  else { p = (round + i) % nm1; q = (round - i + nm1) % nm1; }
-  if (p >= n || q >= n) return;          // padding player sits out
-  if (p > q) { const int t = p; p = q; q = t; }
-  double *gp = G + (int64_t)p * ldg, *gq = G + (int64_t)q * ldg;
-  double a = 0.0, b = 0.0, g = 0.0;
-  for (int r = threadIdx.x; r < m; r += 256) {
-    const double x = gp[r], y = gq[r];
-    a = fma(x, x, a);
-    b = fma(y, y, b);
-    g = fma(x, y, g);
+template <int PB>
+__device__ __forceinline__ int64_t pair_column(int P, int Q, int c) { return (c < PB) ? (int64_t)P * PB + c : (int64_t)Q * PB + (c - PB); }
+
+// 1 / x and 1 / sqrt(x) from the hardware seeds (v_rcp_f64 / v_rsq_f64) and two Newton steps: the rotation only needs
+// c^2 + s^2 = 1 to rounding, which c = rsqrt(1 + t^2), s = c t gives whatever the last bit of t
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(y, fma(-x, y, 1.0), y);
+  return fma(y, fma(-x, y, 1.0), y);
+}
+__device__ __forceinline__ double fast_rsq(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = fma(y * 0.5, fma(-x * y, y, 1.0), y);
+  return fma(y * 0.5, fma(-x * y, y, 1.0), y);
+}
+
+template <int PB>
+__global__ __launch_bounds__(256) void pca_gram_kernel(const double *__restrict__ W, int64_t ldw, int mpad, int nb,
+                                                       int round, int nsplit, double *__restrict__ part) {
+  constexpr int PP = 2 * PB, NT = PP / 16;      // columns of the pair, 16 x 16 tiles per side
+  constexpr int TPC = 256 / PP, RPT = 64 / TPC; // threads per column of the 64-row chunk, rows per thread
+  __shared__ double T[PP * PCA_GLD];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int P, Q;
+  block_pair(nb, round, blockIdx.x, P, Q);
+  const int chunks = mpad / 64;
+  const int c0 = (int)((int64_t)chunks * blockIdx.y / nsplit), c1 = (int)((int64_t)chunks * (blockIdx.y + 1) / nsplit);
+  d4 acc[NT][NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+  const int lcol = tid / TPC, lrow = (tid % TPC) * RPT;
+  const double *src = W + pair_column<PB>(P, Q, lcol) * ldw + lrow;
+  d2 stage[RPT / 2];
+  if (c0 < c1) {
+#pragma unroll
+    for (int v = 0; v < RPT / 2; ++v) stage[v] = *reinterpret_cast<const d2 *>(src + (int64_t)c0 * 64 + 2 * v);
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    a += __shfl_xor(a, off); b += __shfl_xor(b, off); g += __shfl_xor(g, off);
+  for (int c = c0; c < c1; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < RPT / 2; ++v) *reinterpret_cast<d2 *>(&T[lcol * PCA_GLD + lrow + 2 * v]) = stage[v];
+    __syncthreads();
+    if (c + 1 < c1) {
+#pragma unroll
+      for (int v = 0; v < RPT / 2; ++v) stage[v] = *reinterpret_cast<const d2 *>(src + (int64_t)(c + 1) * 64 + 2 * v);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      double f[NT];
+#pragma unroll
+      for (int a = 0; a < NT; ++a) f[a] = T[(16 * a + lr) * PCA_GLD + 16 * wave + 4 * ks + lk];
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[a], f[b], acc[a][b], 0, 0, 0);
+    }
   }
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; red[2][threadIdx.x >> 6] = g; }
+  // the four waves hold the sums over their quarter of every chunk: added in wave order through LDS
   __syncthreads();
-  if (threadIdx.x == 0) {
-    a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    b = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    g = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
-    double c = 1.0, s = 0.0;
-    const double denom = sqrt(a * b);
-    if (denom > 0.0 && g != 0.0) {
-      const double off = fabs(g) / denom;
-      atomicMax(offmax, (unsigned long long)__double_as_longlong(off));   // positive doubles order as integers
-      if (off > 1e-300) {
-        const double zeta = (b - a) / (2.0 * g);
-        const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        c = 1.0 / sqrt(1.0 + t * t);
-        s = c * t;
+  double *S = T;   // PP x PP, dense
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int idx = (16 * a + lk + 4 * r) * PP + 16 * b + lr;
+            S[idx] = (w == 0) ? acc[a][b][r] : S[idx] + acc[a][b][r];
+          }
+    }
+    __syncthreads();
+  }
+  double *dst = part + ((int64_t)blockIdx.x * nsplit + blockIdx.y) * (PP * PP);
+  for (int idx = tid; idx < PP * PP / 2; idx += 256) reinterpret_cast<d2 *>(dst)[idx] = reinterpret_cast<const d2 *>(S)[idx];
+}
+
+// Jacobi rotations on the PP x PP Gram matrix of one pair of blocks.  full = 1: every pair of its columns once per
+// inner sweep (PP - 1 tournament rounds); full = 0: only pairs with one column in either block (PB rounds) -- the
+// pairs inside a block are dealt with in the first round of an outer sweep.  Per round: wave 0 derives the PB
+// rotations of the NEXT round from the matrix while waves 1-3 apply this round's rotations to J; then all four waves
+// apply the next round's rotations to the matrix (2 x 2 blocks, one owner each).
+template <int PB>
+__global__ __launch_bounds__(256) void pca_solve_kernel(const double *__restrict__ part, int nsplit, int full,
+                                                        int inner_sweeps, double tol, double *__restrict__ Jbuf,
+                                                        int *__restrict__ flags, unsigned long long *__restrict__ offmax) {
+  constexpr int PP = 2 * PB;
+  constexpr int W2 = (PB == 32) ? 8 : 16;        // pairs along a row of 2 x 2 blocks owned by consecutive threads
+  constexpr int LDA = PP + W2;                   // a half-wave's blocks then fall into 32 different banks
+  constexpr int LDJ = PP + 1;
+  constexpr int MAXSW = 8;
+  __shared__ double As[PP * LDA];
+  __shared__ double Js[PP * LDJ];
+  __shared__ double rot[2][PB][4];
+  __shared__ int pq[2][PB][2];
+  __shared__ unsigned long long s_off;
+  __shared__ int s_any[MAXSW];
+  const int tid = threadIdx.x;
+  const double *src = part + (int64_t)blockIdx.x * nsplit * (PP * PP);
+  if (tid == 0) s_off = 0ull;
+  if (tid < MAXSW) s_any[tid] = 0;
+  for (int idx = tid; idx < PP * PP; idx += 256) {
+    double v = src[idx];
+    for (int sp = 1; sp < nsplit; ++sp) v += src[(int64_t)sp * (PP * PP) + idx];
+    const int i = idx / PP, j = idx % PP;
+    As[i * LDA + j] = v;
+    Js[i * LDJ + j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  {
+    constexpr int TPR = 256 / PP;                // threads per row
+    const int i = tid / TPR;
+    const double aii = As[i * LDA + i];
+    double worst = 0.0;
+    for (int j = tid % TPR; j < PP; j += TPR) {
+      if (j <= i) continue;
+      const double den2 = aii * As[j * LDA + j];
+      const double g = As[i * LDA + j];
+      if (den2 > 0.0 && g != 0.0) worst = fmax(worst, g * g / den2);
+    }
+    for (int off = 32; off > 0; off >>= 1) worst = fmax(worst, __shfl_xor(worst, off));
+    if ((tid & 63) == 0) atomicMax(&s_off, (unsigned long long)__double_as_longlong(sqrt(worst)));
+  }
+  __syncthreads();
+  const double worst = __longlong_as_double((long long)s_off);
+  if (tid == 0) {
+    atomicMax(offmax, s_off);
+    flags[blockIdx.x] = worst > tol ? 1 : 0;
+  }
+  if (!(worst > tol)) return;
+  if (inner_sweeps > MAXSW) inner_sweeps = MAXSW;
+  const int rounds = full ? PP - 1 : PB;
+  const int total = inner_sweeps * rounds;
+  const double tol2 = tol * tol;
+
+  auto derive = [&](int rr) {                    // rotations of flattened round rr (threads 0 .. PB-1)
+    const int r = rr % rounds, buf = rr & 1;
+    int p, q;
+    if (full) {
+      if (tid == 0) { p = PP - 1; q = r; }
+      else { p = (r + tid) % (PP - 1); q = (r - tid + (PP - 1)) % (PP - 1); }
+      if (p > q) { const int t = p; p = q; q = t; }
+    } else {
+      p = tid; q = PB + ((tid + r) & (PB - 1));
+    }
+    const double a = As[p * LDA + p], b = As[q * LDA + q], g = As[p * LDA + q];
+    double c = 1.0, s = 0.0, an = a, bn = b;
+    if (g * g > tol2 * (a * b)) {
+      // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (b - a) / (2 g)
+      const double d = b - a, h = 2.0 * g;
+      const double x = fma(d, d, h * h);
+      const double rt = x * fast_rsq(x);
+      double t = fabs(h) * fast_rcp(fabs(d) + rt);
+      if ((d < 0.0) != (h < 0.0)) t = -t;
+      c = fast_rsq(fma(t, t, 1.0));
+      s = c * t;
+      an = a - t * g;
+      bn = b + t * g;
+      if (an < bn) {                             // larger column first: (c, s) <- (s, -c)
+        const double cc = c;
+        c = s; s = -cc;
+        const double tt = an;
+        an = bn; bn = tt;
+      }
+      s_any[rr / rounds] = 1;
+    }
+    rot[buf][tid][0] = c; rot[buf][tid][1] = s; rot[buf][tid][2] = an; rot[buf][tid][3] = bn;
+    pq[buf][tid][0] = p; pq[buf][tid][1] = q;
+  };
+
+  if (tid < PB) derive(0);
+  __syncthreads();
+  for (int rr = 0; rr < total; ++rr) {
+    const int buf = rr & 1;
+    {                                            // the matrix: A <- R^T A R
+      const int P1 = (tid / W2) % PB;
+      const int p1 = pq[buf][P1][0], q1 = pq[buf][P1][1];
+      const double c1 = rot[buf][P1][0], s1 = rot[buf][P1][1];
+#pragma unroll
+      for (int j = 0; j < PB / W2; ++j) {
+        const int P2 = (tid % W2) + W2 * j;
+        const int p2 = pq[buf][P2][0], q2 = pq[buf][P2][1];
+        const double c2 = rot[buf][P2][0], s2 = rot[buf][P2][1];
+        if (s1 == 0.0 && s2 == 0.0) continue;
+        if (P1 == P2) {
+          As[p1 * LDA + p1] = rot[buf][P1][2]; As[q1 * LDA + q1] = rot[buf][P1][3];
+          As[p1 * LDA + q1] = 0.0; As[q1 * LDA + p1] = 0.0;
+          continue;
+        }
+        const double a = As[p1 * LDA + p2], b = As[p1 * LDA + q2], cc = As[q1 * LDA + p2], d = As[q1 * LDA + q2];
+        const double a1 = c2 * a - s2 * b, b1 = s2 * a + c2 * b;       // columns p2, q2
+        const double c1v = c2 * cc - s2 * d, d1 = s2 * cc + c2 * d;
+        As[p1 * LDA + p2] = c1 * a1 - s1 * c1v;                          // rows p1, q1
+        As[q1 * LDA + p2] = s1 * a1 + c1 * c1v;
+        As[p1 * LDA + q2] = c1 * b1 - s1 * d1;
+        As[q1 * LDA + q2] = s1 * b1 + c1 * d1;
       }
     }
-    cs[0] = c; cs[1] = s;
+    __syncthreads();
+    if (tid < 64) {
+      if (tid < PB && rr + 1 < total) derive(rr + 1);
+    } else {                                     // J <- J R
+      for (int item = tid - 64; item < PP * PB; item += 192) {
+        const int Pj = item % PB, row = item / PB;
+        const double cj = rot[buf][Pj][0], sj = rot[buf][Pj][1];
+        if (sj != 0.0) {
+          const int pj = pq[buf][Pj][0], qj = pq[buf][Pj][1];
+          const double x = Js[row * LDJ + pj], y = Js[row * LDJ + qj];
+          Js[row * LDJ + pj] = cj * x - sj * y;
+          Js[row * LDJ + qj] = sj * x + cj * y;
+        }
+      }
+    }
+    __syncthreads();
+    if ((rr + 1) % rounds == 0 && !s_any[rr / rounds]) break;   // a whole inner sweep without a rotation
   }
+  double *dst = Jbuf + (int64_t)blockIdx.x * (PP * PP);
+  for (int idx = tid; idx < PP * PP; idx += 256) dst[idx] = Js[(idx / PP) * LDJ + idx % PP];
+}
+
+// X <- X J for the PP columns of every pair of blocks that rotated, rows in strips of 16 (one wave per strip):
+// out^T (new column x row) = J^T (new column x old column) X^T (old column x row)
+template <int PB>
+__global__ __launch_bounds__(256) void pca_apply_kernel(double *__restrict__ W, int64_t ldw, int nstrips, int nb, int round,
+                                                        const double *__restrict__ Jbuf, const int *__restrict__ flags) {
+  constexpr int PP = 2 * PB;
+  __shared__ double Js[PP * PCA_JLD];
+  if (!flags[blockIdx.x]) return;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int P, Q;
+  block_pair(nb, round, blockIdx.x, P, Q);
+  const double *J = Jbuf + (int64_t)blockIdx.x * (PP * PP);
+  for (int idx = tid; idx < PP * PP; idx += 256) Js[(idx / PP) * PCA_JLD + (idx % PP)] = J[idx];
   __syncthreads();
-  const double c = cs[0], s = cs[1];
-  if (s == 0.0) return;
-  for (int r = threadIdx.x; r < m; r += 256) {
-    const double x = gp[r], y = gq[r];
-    gp[r] = c * x - s * y;
-    gq[r] = s * x + c * y;
+  for (int strip = blockIdx.y * 4 + wave; strip < nstrips; strip += gridDim.y * 4) {
+    const int64_t r0 = (int64_t)strip * 16 + lr;
+    double bf[PP / 4];
+#pragma unroll
+    for (int kk = 0; kk < PP / 4; ++kk) bf[kk] = W[pair_column<PB>(P, Q, 4 * kk + lk) * ldw + r0];
+#pragma unroll
+    for (int mt = 0; mt < PP / 16; ++mt) {
+      d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < PP / 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Js[(4 * kk + lk) * PCA_JLD + 16 * mt + lr], bf[kk], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) W[pair_column<PB>(P, Q, 16 * mt + lk + 4 * r) * ldw + r0] = acc[r];
+    }
   }
-  double *vp = V + (int64_t)p * ldv, *vq = V + (int64_t)q * ldv;
-  for (int r = threadIdx.x; r < n; r += 256) {
-    const double x = vp[r], y = vq[r];
-    vp[r] = c * x - s * y;
-    vq[r] = s * x + c * y;
-  }
+}
+
+template <int PB>
+static void jacobi_round(double *dW, int64_t ldw, int mpad, int nstrips, int nb, int r, int nsplit, int inner, double tol,
+                         double *dpart, double *dJ, int *dflags, unsigned long long *doff, int apply_y) {
+  const unsigned npairs = (unsigned)(nb / 2);
+  hipLaunchKernelGGL(pca_gram_kernel<PB>, dim3(npairs, (unsigned)nsplit), dim3(256), 0, nullptr, dW, ldw, mpad, nb, r, nsplit,
+                     dpart);
+  hipLaunchKernelGGL(pca_solve_kernel<PB>, dim3(npairs), dim3(256), 0, nullptr, dpart, nsplit, r == 0 ? 1 : 0, inner, tol, dJ,
+                     dflags, doff);
+  hipLaunchKernelGGL(pca_apply_kernel<PB>, dim3(npairs, (unsigned)apply_y), dim3(256), 0, nullptr, dW, ldw, nstrips, nb, r, dJ,
+                     dflags);
+}
+
+// W rows [mpad, mpad + n): identity
+__global__ void pca_identity_rows_kernel(double *W, int64_t ldw, int mpad, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) W[(int64_t)j * ldw + mpad + j] = 1.0;
 }
 
 }  // namespace gpemu
@@ -160,17 +394,30 @@ extern "C" int gpemu_pca_fit(int device, int64_t N, int64_t F, const double *Y, 
   GP_HIP(hipSetDevice(device));
   const bool tw = N < F;                          // work on the transpose when there are fewer rows
   const int m = (int)(tw ? F : N), n = (int)(tw ? N : F);
-  const int npad = (n + 1) & ~1;
-  const int64_t ldg = round_up(m, 16), ldv = round_up(n, 16);
+  int PB = n <= 1024 ? 16 : 32;                                     // columns per block (more, smaller pairs keep a small matrix's rounds short)
+  if (const char *e = getenv("GPEMU_PCA_PB")) PB = atoi(e) == 32 ? 32 : 16;
+  const int PP = 2 * PB;
+  const int nb = std::max(2, (int)(round_up(n, 2 * PB) / PB));      // blocks of PB columns, an even number of them
+  const int ncols = nb * PB, npairs = nb / 2;
+  const int mpad = (int)round_up(m, 64);
+  const int64_t ldw = (round_up(mpad + n, 32)) | 16;                // odd multiple of 16: columns start on different channels
+  const int nstrips = (int)((mpad + round_up(n, 16)) / 16);
+  const int chunks = mpad / 64;
+  const int nsplit = std::max(1, std::min(chunks, std::min(8, 256 / npairs)));
+  int inner = 2;
+  const bool trace = getenv("GPEMU_PCA_TRACE") != nullptr;
+  if (const char *e = getenv("GPEMU_PCA_INNER")) inner = std::max(1, atoi(e));
   double *dY = nullptr, *dYs = nullptr, *dmean = nullptr, *dvar = nullptr, *dscale = nullptr, *dpm = nullptr,
-         *dG = nullptr, *dV = nullptr;
+         *dW = nullptr, *dpart = nullptr, *dJ = nullptr;
+  int *dflags = nullptr;
   unsigned long long *doff = nullptr;
   hipError_t e = hipMalloc((void **)&dY, sizeof(double) * N * F);
   auto A = [&](double **p, int64_t cnt) { if (e == hipSuccess) e = hipMalloc((void **)p, sizeof(double) * (size_t)cnt); };
-  A(&dYs, N * F); A(&dmean, F); A(&dvar, F); A(&dscale, F); A(&dpm, F); A(&dG, (int64_t)n * ldg); A(&dV, (int64_t)n * ldv);
+  A(&dYs, N * F); A(&dmean, F); A(&dvar, F); A(&dscale, F); A(&dpm, F); A(&dW, (int64_t)ncols * ldw);
+  A(&dpart, (int64_t)npairs * nsplit * PP * PP); A(&dJ, (int64_t)npairs * PP * PP);
+  if (e == hipSuccess) e = hipMalloc((void **)&dflags, sizeof(int) * npairs);
   if (e == hipSuccess) e = hipMalloc((void **)&doff, sizeof(unsigned long long));
-  int rc = GPEMU_OK;
-  std::vector<double> hG, hV;
+  std::vector<double> hW;
   int sweeps = 0;
   if (e == hipSuccess) e = hipMemcpy(dY, Y, sizeof(double) * N * F, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
@@ -178,58 +425,66 @@ extern "C" int gpemu_pca_fit(int device, int64_t N, int64_t F, const double *Y, 
                        dmean, dvar, dscale);
     hipLaunchKernelGGL(standardise_kernel, dim3((unsigned)((N * F + 255) / 256)), dim3(256), 0, nullptr, dY, (int)N,
                        (int)F, dmean, dscale, dYs);
-    e = hipMemsetAsync(dG, 0, sizeof(double) * (size_t)n * ldg, nullptr);
+    e = hipMemsetAsync(dW, 0, sizeof(double) * (size_t)ncols * ldw, nullptr);
     hipLaunchKernelGGL(pca_centre_kernel, dim3((unsigned)((F + 63) / 64)), dim3(64), 0, nullptr, dYs, (int)N, (int)F,
-                       dpm, dG, ldg, tw ? 1 : 0);
-    hipLaunchKernelGGL(identity_kernel, dim3((unsigned)(((int64_t)n * ldv + 255) / 256)), dim3(256), 0, nullptr, dV, n, ldv);
-    const double tol = std::sqrt((double)m) * 2.220446049250313e-16;
+                       dpm, dW, ldw, tw ? 1 : 0);
+    hipLaunchKernelGGL(pca_identity_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, dW, ldw, mpad, n);
+    const double tol = 4.0 * std::sqrt((double)m) * 2.220446049250313e-16;   // the cosines recomputed from rounded Gram sums bottom out near sqrt(m) eps
+    const int apply_y = std::max(1, std::min((nstrips + 3) / 4, 2048 / npairs));
     for (sweeps = 0; sweeps < 60 && e == hipSuccess; ++sweeps) {
       e = hipMemsetAsync(doff, 0, sizeof(unsigned long long), nullptr);
-      for (int r = 0; r < npad - 1; ++r)
-        hipLaunchKernelGGL(jacobi_round_kernel, dim3((unsigned)(npad / 2)), dim3(256), 0, nullptr, dG, ldg, m, dV, ldv,
-                           n, npad, r, doff);
+      for (int r = 0; r < nb - 1; ++r) {
+        if (PB == 16) jacobi_round<16>(dW, ldw, mpad, nstrips, nb, r, nsplit, inner, tol, dpart, dJ, dflags, doff, apply_y);
+        else jacobi_round<32>(dW, ldw, mpad, nstrips, nb, r, nsplit, inner, tol, dpart, dJ, dflags, doff, apply_y);
+      }
       unsigned long long bits = 0;
       if (e == hipSuccess) e = hipMemcpy(&bits, doff, sizeof(bits), hipMemcpyDeviceToHost);
       double off;
       std::memcpy(&off, &bits, sizeof(off));
+      if (trace) fprintf(stderr, "pca_fit: sweep %d  largest cosine %.3e  (tol %.3e)\n", sweeps, off, tol);
       if (off <= tol) { ++sweeps; break; }
     }
     if (e == hipSuccess) e = hipGetLastError();
   }
   if (e == hipSuccess) {
-    hG.resize((size_t)n * ldg); hV.resize((size_t)n * ldv);
-    e = hipMemcpy(hG.data(), dG, sizeof(double) * hG.size(), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(hV.data(), dV, sizeof(double) * hV.size(), hipMemcpyDeviceToHost);
+    hW.resize((size_t)ncols * ldw);
+    e = hipMemcpy(hW.data(), dW, sizeof(double) * hW.size(), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(scaler_mean, dmean, sizeof(double) * F, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(scaler_var, dvar, sizeof(double) * F, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(scaler_scale, dscale, sizeof(double) * F, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(pca_mean, dpm, sizeof(double) * F, hipMemcpyDeviceToHost);
   }
   (void)hipFree(dY); (void)hipFree(dYs); (void)hipFree(dmean); (void)hipFree(dvar); (void)hipFree(dscale);
-  (void)hipFree(dpm); (void)hipFree(dG); (void)hipFree(dV); (void)hipFree(doff);
+  (void)hipFree(dpm); (void)hipFree(dW); (void)hipFree(dpart); (void)hipFree(dJ); (void)hipFree(dflags); (void)hipFree(doff);
   if (e != hipSuccess) { set_error("pca_fit: %s", hipGetErrorString(e)); return GPEMU_ERR_HIP; }
-  if (rc != GPEMU_OK) return rc;
   if (n_sweeps) *n_sweeps = sweeps;
 
   // ---- host assembly: order by singular value, normalise, sign convention -----------------------------
-  std::vector<double> sigma((size_t)n);
-  for (int j = 0; j < n; ++j) {
+  // column j of the work matrix: hW[j * ldw + r], r < m; its accumulated rotations: hW[j * ldw + mpad + r], r < n.
+  // The n columns that carry data are those with a non-zero rotation part (the padding columns stay zero).
+  std::vector<double> sigma((size_t)ncols);
+  std::vector<int> order;
+  for (int j = 0; j < ncols; ++j) {
+    const double *g = &hW[(size_t)j * ldw];
     double s2 = 0.0;
-    for (int r = 0; r < m; ++r) s2 += hG[(size_t)j * ldg + r] * hG[(size_t)j * ldg + r];
+    for (int r = 0; r < m; ++r) s2 += g[r] * g[r];
     sigma[j] = std::sqrt(s2);
+    bool real = false;
+    for (int r = 0; r < n && !real; ++r) real = g[mpad + r] != 0.0;
+    if (real) order.push_back(j);
   }
-  std::vector<int> order((size_t)n);
-  std::iota(order.begin(), order.end(), 0);
+  if ((int)order.size() != n) { set_error("pca_fit: internal error (%d of %d columns carry data)", (int)order.size(), n); return GPEMU_ERR_ARG; }
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sigma[a] > sigma[b]; });
   double total_var = 0.0;
-  for (int j = 0; j < n; ++j) total_var += sigma[j] * sigma[j] / (double)(N - 1);
+  for (int c = 0; c < n; ++c) total_var += sigma[order[(size_t)c]] * sigma[order[(size_t)c]] / (double)(N - 1);
   std::vector<double> comp((size_t)F);
   for (int64_t c = 0; c < nc; ++c) {
     const int j = order[(size_t)c];
     const double sg = sigma[j];
+    const double *g = &hW[(size_t)j * ldw], *v = g + mpad;
     // component row (length F): right singular vector of Xc
-    if (!tw) for (int64_t f = 0; f < F; ++f) comp[f] = hV[(size_t)j * ldv + f];
-    else for (int64_t f = 0; f < F; ++f) comp[f] = sg > 0.0 ? hG[(size_t)j * ldg + f] / sg : 0.0;
+    if (!tw) for (int64_t f = 0; f < F; ++f) comp[f] = v[f];
+    else for (int64_t f = 0; f < F; ++f) comp[f] = sg > 0.0 ? g[f] / sg : 0.0;
     int64_t arg = 0;
     double best = -1.0;
     for (int64_t f = 0; f < F; ++f)
@@ -240,8 +495,8 @@ extern "C" int gpemu_pca_fit(int device, int64_t N, int64_t F, const double *Y, 
     explained_variance[c] = sg * sg / (double)(N - 1);
     explained_variance_ratio[c] = explained_variance[c] / total_var;
     // Y_pca[:, c] = U[:, c] * S[c]
-    if (!tw) for (int64_t i = 0; i < N; ++i) Y_pca[i * nc + c] = sign * hG[(size_t)j * ldg + i];
-    else for (int64_t i = 0; i < N; ++i) Y_pca[i * nc + c] = sign * sg * hV[(size_t)j * ldv + i];
+    if (!tw) for (int64_t i = 0; i < N; ++i) Y_pca[i * nc + c] = sign * g[i];
+    else for (int64_t i = 0; i < N; ++i) Y_pca[i * nc + c] = sign * sg * v[i];
   }
   return GPEMU_OK;
 }
