@@ -809,19 +809,28 @@ int gpemu_sampler_run_sharded(gpemu_sampler *s, gpemu_comm *c, int64_t steps, in
                        emulate_world > 0 ? -INFINITY : 0.0);
   }
   s->gworld = world;
-  if (store_chain) GP_TRY(ensure_chain(s, s->chain_len + steps));
+  // A rank that hits an error of its own keeps taking part in the remaining all-gathers (its peers are inside them and
+  // would otherwise wait forever), skips its own launches and reports the first error at the end.
+  int err = GPEMU_OK;
+  auto keep = [&](int rc) { if (rc != GPEMU_OK && err == GPEMU_OK) err = rc; return err == GPEMU_OK; };
+  if (store_chain) keep(ensure_chain(s, s->chain_len + steps));
   for (int64_t it = 0; it < steps; ++it) {
-    GP_TRY(launch_rng(s, st, steps - it));
+    if (err == GPEMU_OK) keep(launch_rng(s, st, steps - it));
     for (int h = 0; h < 2; ++h) {
-      if (hi[h] > lo[h]) {
+      if (err == GPEMU_OK && hi[h] > lo[h]) {
         const ProposeArgs pa = propose_args(s, h, lo[h], hi[h] - lo[h]);
-        GP_TRY(eval_logpost(s, s->q, hi[h] - lo[h], s->gmine[h], st, nullptr, &pa));
+        keep(eval_logpost(s, s->q, hi[h] - lo[h], s->gmine[h], st, nullptr, &pa));
       }
-      GP_RCCL(g_rccl.AllGather(s->gmine[h], s->gfull[h], (size_t)s->gper[h], ncclDouble, c->comm, st));
-      GP_TRY(launch_accept(s, h, s->gfull[h], store_chain, st));
+      const ncclResult_t r = g_rccl.AllGather(s->gmine[h], s->gfull[h], (size_t)s->gper[h], ncclDouble, c->comm, st);
+      if (r != ncclSuccess) {                   // the communicator itself failed: nothing more can be exchanged
+        set_error("ncclAllGather: %s", g_rccl.GetErrorString(r));
+        return err != GPEMU_OK ? err : GPEMU_ERR_HIP;
+      }
+      if (err == GPEMU_OK) keep(launch_accept(s, h, s->gfull[h], store_chain, st));
     }
-    GP_TRY(end_step(s, store_chain, st, true));
+    if (err == GPEMU_OK) keep(end_step(s, store_chain, st, true));
   }
+  if (err != GPEMU_OK) { (void)hipStreamSynchronize(st); return err; }
   return check_nan(s);
 }
 

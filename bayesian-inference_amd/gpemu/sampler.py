@@ -177,9 +177,15 @@ class DeviceSampler:
         return chain, lp
 
     # -- multi-GPU: one process per GPU, the ensemble replicated, proposals sharded -------------
-    def _rccl_comm(self, group):
-        """RCCL communicator owned by the library (one per sampler and process group), bootstrapped
-        through torch.distributed: rank 0's 128-byte id is broadcast, then every rank joins."""
+    def _rccl_comm_agreed(self, group):
+        """RCCL communicator owned by the library (one per sampler and process group), bootstrapped through
+        torch.distributed -- or None on EVERY rank if any rank cannot provide it, so that all ranks take the same
+        transport.  Every rank goes through the same sequence of collectives whatever fails locally:
+          1. rank 0 makes the 128-byte id; it is broadcast together with a status byte (zeroed id + 0 on failure);
+          2. every rank probes that it can load librccl; the ranks vote (all-reduce MIN) BEFORE anyone enters
+             ncclCommInitRank, which would otherwise wait for the ranks that could not follow;
+          3. the ranks join, run one all-gather of their indices through the new communicator, and vote again."""
+        import warnings
         import torch
         import torch.distributed as dist
         key = id(group) if group is not None else 0
@@ -191,54 +197,65 @@ class DeviceSampler:
         dev = torch.device("cuda", self.device)
         bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         path = bundled.encode() if os.path.exists(bundled) else None   # the copy torch already loaded
+        err = None
+
+        def vote(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return int(t.item()) == 1
+
+        def give_up(reason):
+            warnings.warn(f"library-owned RCCL communicator unavailable ({reason}); using torch.distributed's all-gather")
+            comms[key] = None
+            return None
+
+        # 1. the id, always broadcast
         ident = (C.c_char * 128)()
+        status = 1
         if rank == 0:
-            check(L.gpemu_comm_unique_id(path, C.cast(ident, C.c_void_p)))
-        t = torch.tensor(list(ident.raw), dtype=torch.uint8, device=dev)
+            try:
+                check(L.gpemu_comm_unique_id(path, C.cast(ident, C.c_void_p)))
+            except Exception as e:
+                err, status = e, 0
+                ident = (C.c_char * 128)()
+        t = torch.tensor(list(ident.raw) + [status], dtype=torch.uint8, device=dev)
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast(t, src=src, group=group)
         raw = bytes(t.cpu().tolist())
-        buf = C.create_string_buffer(raw, 128)
-        h = C.c_void_p()
-        check(L.gpemu_comm_create(C.byref(h), int(self.device), int(rank), int(world), C.cast(buf, C.c_void_p), path))
-        comms[key] = h
-        return h
-
-    def _rccl_comm_agreed(self, group):
-        """The library's communicator, or None on every rank if any rank failed to create it (the ranks
-        agree through a torch.distributed all-reduce, so they all take the same transport)."""
-        import warnings
-        import torch
-        import torch.distributed as dist
-        key = id(group) if group is not None else 0
-        if key in self.__dict__.get("_comms", {}):
-            return self._comms[key]
-        comm, err = None, None
+        if raw[128] == 0:
+            return give_up(repr(err) if err is not None else "rank 0 could not create the id")
+        # 2. can this rank load the library?  (an id of its own, thrown away, exercises dlopen + the symbols)
         try:
-            comm = self._rccl_comm(group)
-            # one all-gather of the rank indices through the new communicator before the chain depends on it
-            world, rank = dist.get_world_size(group), dist.get_rank(group)
-            dev = torch.device("cuda", self.device)
-            src = torch.full((1,), float(rank), dtype=torch.float64, device=dev)
-            dst = torch.full((world,), -1.0, dtype=torch.float64, device=dev)
+            scratch = (C.c_char * 128)()
+            check(L.gpemu_comm_unique_id(path, C.cast(scratch, C.c_void_p)))
+            loadable = True
+        except Exception as e:
+            err, loadable = e, False
+        if not vote(loadable):
+            return give_up(repr(err) if err is not None else "another rank cannot load librccl")
+        # 3. join, self-check, vote
+        comm = None
+        try:
+            buf = C.create_string_buffer(raw[:128], 128)
+            h = C.c_void_p()
+            check(L.gpemu_comm_create(C.byref(h), int(self.device), int(rank), int(world), C.cast(buf, C.c_void_p), path))
+            comm = h
+            src_t = torch.full((1,), float(rank), dtype=torch.float64, device=dev)
+            dst_t = torch.full((world,), -1.0, dtype=torch.float64, device=dev)
             torch.cuda.synchronize(dev)
-            check(_lib.lib().gpemu_comm_all_gather(comm, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), 1, None))
+            check(L.gpemu_comm_all_gather(comm, C.c_void_p(src_t.data_ptr()), C.c_void_p(dst_t.data_ptr()), 1, None))
             torch.cuda.synchronize(dev)
-            if dst.cpu().tolist() != [float(r) for r in range(world)]:
-                raise RuntimeError(f"RCCL all-gather self-check returned {dst.cpu().tolist()}")
-        except Exception as e:      # missing librccl symbol, ncclCommInitRank failure, wrong data ...
-            err = e
-            comm = None
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=torch.device("cuda", self.device))
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if int(ok.item()) == 1:
+            if dst_t.cpu().tolist() != [float(r) for r in range(world)]:
+                raise RuntimeError(f"RCCL all-gather self-check returned {dst_t.cpu().tolist()}")
+            good = True
+        except Exception as e:      # ncclCommInitRank failure, wrong data ...
+            err, good = e, False
+        if vote(good):
+            comms[key] = comm
             return comm
-        stale = self.__dict__.get("_comms", {}).pop(key, None)
-        if stale is not None:
-            _lib.lib().gpemu_comm_destroy(stale)
-        warnings.warn(f"library-owned RCCL communicator unavailable ({err!r}); using torch.distributed's all-gather")
-        self.__dict__.setdefault("_comms", {})[key] = None
-        return None
+        if comm is not None:
+            L.gpemu_comm_destroy(comm)
+        return give_up(repr(err) if err is not None else "another rank failed the self-check")
 
     def _peer_ready(self, group):
         """Exchange the ranks' gather-buffer IPC handles (once per sampler and group) so that every rank can

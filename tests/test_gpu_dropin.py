@@ -225,3 +225,49 @@ def test_closure_tests_run_stacked(tmp_path, monkeypatch):
         np.testing.assert_array_equal(sampler.get_chain(), out["chain"])
     assert not np.array_equal(pseudo[0], pseudo[1])              # every chain has its own draw
     mcmc._closure_done.clear()
+
+
+def test_two_process_launch_one_writer_per_file(tmp_path):
+    """``python -m torch.distributed.run --nproc-per-node 2`` over a script that, like the reference's steering
+    script, never initialises a process group: the drop-in modules join the launcher's group themselves, the
+    emulator groups and the closure chains are dealt to the ranks, the production chain shards its walkers, and every
+    output file has exactly one writer.  The production chain equals the one a single process makes from rank 0's
+    seeds."""
+    import os
+    import subprocess
+    import sys
+    from gpemu import h5io
+    here = os.path.dirname(os.path.abspath(__file__))
+    port = 29800 + (os.getpid() % 1500)
+    path, analysis = DU.write_config(tmp_path, n_pc=5, n_restarts=0)
+    # two ranks share the one GPU of the box, which RCCL refuses ("duplicate GPU"): the group the drop-in joins is gloo
+    # here (GPEMU_DIST_BACKEND), the sampler's exchange the peer stores / torch.distributed path as in a real launch
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPEMU_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(here, "dist_dropin_worker.py"), str(tmp_path)]
+    done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
+    writes = [open(tmp_path / f"writes_rank{r}.txt").read().split() for r in (0, 1)]
+    everything = writes[0] + writes[1]
+    assert len(everything) == len(set(everything)), f"a file was written twice: {writes}"
+    names = sorted(os.path.relpath(p, tmp_path / "out") for p in everything)
+    # one emulator pickle; mcmc.h5 + sampler pickle of the production chain and of both closure chains
+    assert sum(n.endswith(".pkl") and "emulation" in n for n in names) == 1
+    assert sum(n.endswith("mcmc.h5") for n in names) == 3 and sum(n.endswith("mcmc_sampler.pkl") for n in names) == 3
+    production = [p for p in writes[0] if p.endswith("mcmc.h5") and "closure" not in p]
+    assert len(production) == 1                                   # rank 0 writes the sharded production chain
+    assert any("closure" in p for p in writes[1])                 # rank 1 owns closure chain 1
+    back = h5io.read_dict_from_h5(os.path.dirname(production[0]), "mcmc.h5")
+    assert np.all(np.isfinite(back["log_prob"])) and back["chain"].ndim == 3
+    # the stored log-probabilities are the log-posterior of the stored positions (the ranks held identical ensembles)
+    from bayesian_inference import emulation, log_posterior
+    g = GU.load("g1_rbf_noise")
+    DU.install_fake_data_IO(g["Y"], g["design"], g["y_exp"], g["y_err"], {})
+    ec = emulation.EmulationConfig.from_config_file("test_analysis", "exponential", path, analysis)
+    res = {"main": emulation.read_emulators(ec.emulation_groups_config["main"])}
+    emu_cfg = _EmuCfg(ec.emulation_groups_config, DU.TrivialSort("main"))
+    log_posterior.initialize_pool_variables(g["lo"], g["hi"], emu_cfg, res, {"y": g["y_exp"], "y_err": g["y_err"]}, None)
+    lp = np.array([log_posterior.log_posterior(x)[0] for x in back["chain"][-1][:6]])
+    np.testing.assert_allclose(lp, back["log_prob"][-1][:6], rtol=1e-10)

@@ -218,7 +218,7 @@ def _rccl_worker(rank, port, out_dir):
             src = torch.arange(5, dtype=torch.float64, device="cuda")
             dst = torch.zeros(5, dtype=torch.float64, device="cuda")
             torch.cuda.synchronize()
-            comm = a._rccl_comm(None)
+            comm = a._rccl_comm_agreed(None)
             _lib.check(_lib.lib().gpemu_comm_all_gather(comm, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()),
                                                         5, None))
             torch.cuda.synchronize()
