@@ -97,7 +97,11 @@ __device__ __forceinline__ void panel_step(double (*D)[NB + 1], int tid, int blk
     for (int j = 0; j < PB; ++j) {
       const double piv2 = readlane_f64(row[j], j);
       if (!(piv2 > 0.0) && bad == 0) bad = J0 + j + 1;
-      const double rinv = 1.0 / sqrt(piv2);
+      // 1 / sqrt(pivot): hardware estimate + two Newton steps instead of the IEEE sqrt-and-divide sequence, which sits
+      // on the serial path of all 64 pivots (relative error ~1e-16; a non-positive pivot gives NaN / inf as before)
+      double rinv = __builtin_amdgcn_rsq(piv2);
+      rinv = fma(0.5 * rinv, fma(-piv2 * rinv, rinv, 1.0), rinv);
+      rinv = fma(0.5 * rinv, fma(-piv2 * rinv, rinv, 1.0), rinv);
       const double lj = row[j] * rinv;      // lanes >= j: column J0+j of L; lanes < j hold zeros
       row[j] = lj;
 #pragma unroll
@@ -394,6 +398,7 @@ __global__ __launch_bounds__(1024) void lml_terms_kernel(const double *__restric
 // gpart[block][t] = 1/2 sum over this block's (j, l) of (alpha_j alpha_l - Kinv_jl) dK_jl/dtheta_t
 // theta order: log l_1..l_d, (log const), (log noise)   (skl kernels.py:733-760, Sum :861-866)
 constexpr int NTH_MAX = DPAD + 2;
+constexpr int GRAD_ROWS = 16;
 __global__ __launch_bounds__(256) void lml_grad_kernel(const double *__restrict__ X, const double *__restrict__ hp,
                                                        const double *__restrict__ alpha,
                                                        const double *__restrict__ Kinv, int64_t ld,
@@ -401,26 +406,34 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(const double *__restrict_
                                                        int has_const, int has_noise) {
   __shared__ double red[NTH_MAX][4];
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;
+  const int j0 = blockIdx.y * GRAD_ROWS;               // this workgroup's rows j0 .. j0 + GRAD_ROWS - 1 (one reduction for all)
   hp += (int64_t)blockIdx.z * (DPAD + 2);              // blockIdx.z: problem of a batch
   alpha += (int64_t)blockIdx.z * ld;
   Kinv += (int64_t)blockIdx.z * ld * ld;
   gpart += (int64_t)blockIdx.z * gridDim.x * gridDim.y * NTH_MAX;
-  if ((int)(blockIdx.x * blockDim.x) > j) {            // wholly above the diagonal: nothing to add
+  if ((int)(blockIdx.x * blockDim.x) > j0 + GRAD_ROWS - 1) {   // wholly above the diagonal: nothing to add
     if (threadIdx.x < NTH_MAX) gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NTH_MAX + threadIdx.x] = 0.0;
     return;
   }
   double acc[NTH_MAX];
 #pragma unroll
   for (int t = 0; t < NTH_MAX; ++t) acc[t] = 0.0;
+  double xl[DPAD], il2[DPAD];
+#pragma unroll
+  for (int dd = 0; dd < DPAD; ++dd) {
+    xl[dd] = (l < N) ? X[l * DPAD + dd] : 0.0;
+    il2[dd] = hp[dd] * hp[dd];
+  }
+  const double al = (l < N) ? alpha[l] : 0.0;
   // the summand is symmetric in (j, l): the lower triangle counts twice, Kinv is only read (and only valid) there
-  if (l <= j) {
-    const double wgt = (l < j ? 2.0 : 1.0) * (alpha[j] * alpha[l] - Kinv[(int64_t)j * ld + l]);
+  for (int j = j0; j < j0 + GRAD_ROWS && j < N; ++j) {
+    if (l > j) continue;
+    const double wgt = (l < j ? 2.0 : 1.0) * (alpha[j] * al - Kinv[(int64_t)j * ld + l]);
     double D[DPAD], r2 = 0.0;
 #pragma unroll
     for (int dd = 0; dd < DPAD; ++dd) {
-      double df = X[j * DPAD + dd] - X[l * DPAD + dd];
-      D[dd] = (df * df) / (hp[dd] * hp[dd]);   // (x - x')^2 / l^2   (skl kernels.py:1574, 1748)
+      double df = X[j * DPAD + dd] - xl[dd];
+      D[dd] = (df * df) / il2[dd];             // (x - x')^2 / l^2   (skl kernels.py:1574, 1748)
       r2 += D[dd];
     }
     double f;  // dK_base/dlog l_dd = f * D[dd]
@@ -436,9 +449,9 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(const double *__restrict_
       f = 5.0 / 3.0 * (tmp + 1.0) * exp(-tmp);                    // 5/3 D (tmp + 1) exp(-tmp)
     }
 #pragma unroll
-    for (int dd = 0; dd < DPAD; ++dd) acc[dd] = 0.5 * wgt * f * D[dd];
-    if (has_const) acc[d] = 0.5 * wgt * hp[DPAD];
-    if (has_noise && j == l) acc[d + has_const] = 0.5 * wgt * hp[DPAD + 1];
+    for (int dd = 0; dd < DPAD; ++dd) acc[dd] += 0.5 * wgt * f * D[dd];
+    if (has_const) acc[d] += 0.5 * wgt * hp[DPAD];
+    if (has_noise && j == l) acc[d + has_const] += 0.5 * wgt * hp[DPAD + 1];
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -632,7 +645,7 @@ static int fit_eval_batch(gpemu_fit *f, int nb, const double *ys, const double *
     g.lower_only = 1; g.k_from_m = 1;
     g.strideA = Np * Np; g.strideB = Np * Np; g.strideC = Np * Np;
     GP_TRY(launch_gemm(g, true, true, nb, st));
-    dim3 grid((unsigned)((N + 255) / 256), (unsigned)N, (unsigned)nb);
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)((N + GRAD_ROWS - 1) / GRAD_ROWS), (unsigned)nb);
     hipLaunchKernelGGL(lml_grad_kernel, grid, dim3(256), 0, st, f->X, f->hp, f->alpha, f->Kinv, Np, f->gpart, (int)N,
                        (int)d, f->kind, f->has_const, f->has_noise);
     hipLaunchKernelGGL(grad_reduce_stage1_kernel, dim3(GR_BLOCKS, (unsigned)nb), dim3(256), 0, st, f->gpart,
