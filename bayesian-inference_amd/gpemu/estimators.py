@@ -336,6 +336,126 @@ class _LockStepEvaluator:
         return -lml, -grad
 
 
+def _setulb_driver_ok():
+    """True when scipy's L-BFGS-B routine has the reverse-communication signature this module drives directly
+    (scipy 1.15: ``setulb(m, x, l, u, nbd, f, g, factr, pgtol, wa, iwa, task, lsave, isave, dsave, maxls, ln_task)``);
+    otherwise ``fit_gps`` runs one ``scipy.optimize.minimize`` per host thread."""
+    if os.environ.get("GPEMU_FIT_DRIVER", "") == "threads":
+        return False
+    try:
+        from scipy.optimize import _lbfgsb
+        doc = _lbfgsb.setulb.__doc__ or ""
+        return "ln_task" in doc and "csave" not in doc
+    except Exception:
+        return False
+
+
+class _LbfgsbRun:
+    """One L-BFGS-B minimisation held as explicit state around ``_lbfgsb.setulb``: what
+    ``scipy.optimize.minimize(fun, x0, method="L-BFGS-B", jac=True, bounds=bounds)`` does with its default options
+    (maxcor 10, ftol 2.22e-9, gtol 1e-5, maxls 20, maxiter = maxfun = 15000), cut at the points where it asks for a
+    function value, so that many runs can advance together and have their values computed in one batch.  The
+    sequence of points, values and the result are those of ``minimize`` (scipy/optimize/_lbfgsb_py.py: the
+    objective is first evaluated at the clipped start point, which is also the first point the routine asks for)."""
+
+    def __init__(self, x0, bounds):
+        n = len(x0)
+        self.m, self.maxls, self.maxiter, self.maxfun = 10, 20, 15000, 15000
+        self.factr, self.pgtol = 2.220446049250313e-09 / np.finfo(float).eps, 1e-5
+        lo, hi = np.asarray(bounds, dtype=np.float64)[:, 0], np.asarray(bounds, dtype=np.float64)[:, 1]
+        self.x = np.clip(np.asarray(x0, dtype=np.float64).ravel(), lo, hi)
+        self.nbd = np.zeros(n, np.int32)
+        self.low, self.up = np.zeros(n), np.zeros(n)
+        for i in range(n):
+            fin_l, fin_u = np.isfinite(lo[i]), np.isfinite(hi[i])
+            if fin_l:
+                self.low[i] = lo[i]
+            if fin_u:
+                self.up[i] = hi[i]
+            self.nbd[i] = {(False, False): 0, (True, False): 1, (True, True): 2, (False, True): 3}[(bool(fin_l), bool(fin_u))]
+        m = self.m
+        self.f = 0.0
+        self.g = np.zeros(n)
+        self.wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m)
+        self.iwa = np.zeros(3 * n, dtype=np.int32)
+        self.task = np.zeros(2, dtype=np.int32)
+        self.ln_task = np.zeros(2, dtype=np.int32)
+        self.lsave = np.zeros(4, dtype=np.int32)
+        self.isave = np.zeros(44, dtype=np.int32)
+        self.dsave = np.zeros(29)
+        self.nit = self.nfev = 0
+        self.done = False
+        self.last_x = None            # point of the newest value (the memo of scipy's ScalarFunction)
+
+    def advance(self):
+        """Run the routine up to its next request.  Returns the point to evaluate, or None when finished."""
+        from scipy.optimize import _lbfgsb
+        while True:
+            _lbfgsb.setulb(self.m, self.x, self.low, self.up, self.nbd, self.f, self.g, self.factr, self.pgtol, self.wa,
+                           self.iwa, self.task, self.lsave, self.isave, self.dsave, self.maxls, self.ln_task)
+            if self.task[0] == 3:
+                if self.last_x is not None and np.array_equal(self.x, self.last_x):
+                    continue            # value already known (scipy's memo): hand it straight back
+                return self.x.copy()
+            if self.task[0] == 1:
+                self.nit += 1
+                if self.nit >= self.maxiter:
+                    self.task[0], self.task[1] = 5, 504
+                elif self.nfev > self.maxfun:
+                    self.task[0], self.task[1] = 5, 502
+                continue
+            self.done = True
+            return None
+
+    def supply(self, x, f, g):
+        self.f, self.g = float(f), np.asarray(g, dtype=np.float64)
+        self.last_x = x
+        self.nfev += 1
+
+    @property
+    def status(self):
+        if self.task[0] == 4:
+            return 0
+        return 1 if (self.nfev > self.maxfun or self.nit >= self.maxiter) else 2
+
+
+def _lockstep_minimise(dfit, problems, bounds, max_batch):
+    """``problems``: list of (target y, start theta).  All minimisations advance together on one host thread: every
+    round takes the next requested point of each run in flight (at most ``max_batch``), evaluates them in ONE launch
+    chain (``gpemu_fit_lml_batch``) and hands the values back.  Returns [(theta, minimum)] in the order given."""
+    runs = [None] * len(problems)
+    results = [None] * len(problems)
+    nxt, active = 0, []
+    while True:
+        while len(active) < max_batch and nxt < len(problems):
+            runs[nxt] = _LbfgsbRun(problems[nxt][1], bounds)
+            active.append(nxt)
+            nxt += 1
+        if not active:
+            break
+        ask, still = [], []
+        for idx in active:
+            x = runs[idx].advance()
+            if x is None:
+                r = runs[idx]
+                if r.status != 0:
+                    warnings.warn(f"lbfgs failed to converge (status={r.status})", ConvergenceWarning)
+                results[idx] = (r.x, r.f)
+            else:
+                ask.append((idx, x))
+                still.append(idx)
+        active = still
+        if not ask:
+            continue
+        lml, grad, info = dfit.lml_batch(np.stack([problems[i][0] for i, _ in ask]), np.stack([x for _, x in ask]))
+        for j, (idx, x) in enumerate(ask):
+            if int(info[j]) != 0:       # skl _gpr.py:586-590: not positive definite -> +inf, zero gradient
+                runs[idx].supply(x, np.inf, np.zeros_like(x))
+            else:
+                runs[idx].supply(x, -lml[j], -grad[j])
+    return results
+
+
 def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy_X_train=False, device=None,
             n_streams=None):
     """One GaussianProcessRegressor per column of ``Y_columns`` (N x k), fitted concurrently.
@@ -346,8 +466,12 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
     whole batch of (target, theta) pairs goes through ONE chain of launches (``gpemu_fit_lml_batch``: kernel matrices,
     blocked Cholesky, triangular inverses, K^-1 and gradient contractions of all problems together).  The
     restart points are drawn first, from numpy's global RandomState in the order the sequential loop draws
-    them, so the result does not depend on the thread schedule.  ``n_streams`` (env GPEMU_FIT_BATCH, default 32):
-    optimisers in flight = problems per launch chain; 1 reproduces the sequential loop.
+    them, so the result does not depend on the schedule.  ``n_streams`` (env GPEMU_FIT_BATCH, default 64, less for
+    large N): optimisers in flight = problems per launch chain; 1 reproduces the sequential loop.  Where scipy's
+    L-BFGS-B routine has the expected reverse-communication signature, ONE host thread drives all runs through it
+    (``_lockstep_minimise``; same points, values and results as ``scipy.optimize.minimize``), otherwise -- or with
+    GPEMU_FIT_DRIVER=threads -- every run is a ``minimize`` call on its own host thread, meeting the others in
+    ``_LockStepEvaluator``.
     """
     import concurrent.futures
 
@@ -372,7 +496,10 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
             for _ in range(n_restarts_optimizer):
                 starts[i].append(rng.uniform(bounds[:, 0], bounds[:, 1]))
     if n_streams is None:
-        n_streams = int(os.environ.get("GPEMU_FIT_BATCH", "32"))
+        n_streams = int(os.environ.get("GPEMU_FIT_BATCH", "64"))
+        # every problem of a batch owns ~6 N x N f64 work matrices on the device: keep a batch within ~24 GB
+        n_pad = -(-X.shape[0] // 64) * 64
+        n_streams = max(1, min(n_streams, int(24e9 // (6 * 8 * n_pad * n_pad))))
     tasks = [(i, j) for i in range(k_gp) for j in range(len(starts[i]))]
     n_threads = max(1, min(int(n_streams), max(len(tasks), 1)))
     shared = _fit.DeviceFit(X, kk.kind, kk.nu, kk.has_const, kk.has_noise, alpha, device)
@@ -398,8 +525,12 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
             evaluator.leave()
 
     try:
-        with concurrent.futures.ThreadPoolExecutor(max_workers=n_threads) as pool:
-            optima = list(pool.map(run_start, tasks))
+        if n_threads > 1 and optimise and _setulb_driver_ok():
+            # one host thread drives all L-BFGS-B runs through the routine's reverse-communication interface
+            optima = _lockstep_minimise(shared, [(columns[i], starts[i][j]) for i, j in tasks], kk.bounds, n_threads)
+        else:
+            with concurrent.futures.ThreadPoolExecutor(max_workers=n_threads) as pool:
+                optima = list(pool.map(run_start, tasks))
         per_gp = [[] for _ in range(k_gp)]
         for (i, _j), opt in zip(tasks, optima):
             per_gp[i].append(opt)

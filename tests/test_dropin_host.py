@@ -211,3 +211,41 @@ def test_learn_mapping_matches_the_reference_on_its_fixture(monkeypatch):
 
 def m_groups(g):
     return [str(n) for n in g["group_names"]]
+
+
+def test_lbfgsb_lockstep_driver_equals_scipy_minimize():
+    """The thread-free lock-step driver (gpemu.estimators._LbfgsbRun: explicit state around scipy's L-BFGS-B routine, cut
+    where it asks for a value) asks for the same points in the same order and returns the same result as
+    scipy.optimize.minimize(method="L-BFGS-B", jac=True, bounds=...), which is what sklearn's GPR calls
+    (skl _gpr.py:655-668) -- also when the objective answers +inf (a kernel matrix that is not positive definite)."""
+    import scipy.optimize
+    from gpemu import estimators as E
+    if not E._setulb_driver_ok():
+        pytest.skip("scipy's setulb has another signature here: fit_gps uses one minimize() per thread")
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(6, 6))
+    A = A @ A.T + np.eye(6)
+    b = rng.normal(size=6)
+    for trial in range(6):
+        calls = []
+
+        def fun(x):
+            calls.append(x.copy())
+            if trial >= 4 and x[0] > 0.25:                       # part of the box is "not positive definite"
+                return np.inf, np.zeros_like(x)
+            return 0.5 * x @ A @ x - b @ x + 0.1 * np.sum(x ** 4), A @ x - b + 0.4 * x ** 3
+        bounds = np.array([[-1.0, 0.3 + 0.2 * trial]] * 6)
+        x0 = rng.uniform(-2, 2, 6)
+        ref = scipy.optimize.minimize(fun, x0, method="L-BFGS-B", jac=True, bounds=bounds)
+        ref_calls = list(calls)
+        calls.clear()
+        run = E._LbfgsbRun(x0, bounds)
+        while True:
+            x = run.advance()
+            if x is None:
+                break
+            f, g = fun(x)
+            run.supply(x, f, g)
+        assert len(calls) == len(ref_calls) and all(np.array_equal(a, c) for a, c in zip(calls, ref_calls))
+        np.testing.assert_array_equal(run.x, ref.x)
+        assert run.f == ref.fun and run.nit == ref.nit and run.nfev == ref.nfev and run.status == ref.status
