@@ -80,6 +80,31 @@ __device__ __forceinline__ double gather_wait(const double *entry, int *flags) {
   return __longlong_as_double((long long)bits);
 }
 
+// One-off check of the exchange path before a chain depends on it: every rank stores a token (1000 + its rank) into
+// entry `rank` of EVERY rank's buffer through the mapped pointers, then waits (bounded) until the tokens of all ranks
+// have arrived in its own buffer, and restores the entries.  *result = number of ranks whose token did not arrive.
+__global__ void peer_selftest_kernel(double *const *peers, double *mine, int world, int rank, int *result) {
+  const int t = threadIdx.x;
+  int missing = 0;
+  for (int q = t; q < world; q += blockDim.x) {
+    const unsigned long long token = (unsigned long long)__double_as_longlong(1000.0 + rank);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(peers[q] + rank), token, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  for (int q = t; q < world; q += blockDim.x) {
+    const unsigned long long want = (unsigned long long)__double_as_longlong(1000.0 + q);
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(mine + q);
+    bool ok = false;
+    for (int spins = 0; spins < (1 << 21); ++spins) {        // ~3 s at most: the grid always drains
+      if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == want) { ok = true; break; }
+      __builtin_amdgcn_s_sleep(32);
+    }
+    if (!ok) ++missing;
+    __hip_atomic_store(p, GATHER_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (missing) atomicAdd(result, missing);
+}
+
 // Position (and log-probability) of walker x AFTER the previous half's accept / reject (emcee moves/red_blue.py):
 // unchanged unless x proposed in that half and its proposal was accepted.
 __device__ __forceinline__ void state_after_prev(const FrontArgs &fa, int x, double (&px)[DPAD], double &lp, bool &acc,
@@ -622,6 +647,27 @@ int gpemu_sampler_peer_import(gpemu_sampler *s, int world, int rank, const char 
   GP_HIP(hipMemcpy(s->peers, ptrs.data(), sizeof(double *) * world, hipMemcpyHostToDevice));
   s->peer_world = world;
   s->peer_rank = rank;
+  return GPEMU_OK;
+}
+
+int gpemu_sampler_peer_selftest(gpemu_sampler *s) {
+  GP_ARG(s, "sampler");
+  GP_HIP(hipSetDevice(s->device));
+  if (s->peer_world < 1 || !s->peers) { set_error("gpemu_sampler_peer_import has not been called"); return GPEMU_ERR_STATE; }
+  if ((int64_t)s->peer_world > GATHER_SLOTS * s->ns[0]) { set_error("peer self-test: more ranks than buffer entries"); return GPEMU_ERR_ARG; }
+  int *dres = nullptr;
+  GP_HIP(hipMalloc((void **)&dres, sizeof(int)));
+  GP_HIP(hipMemsetAsync(dres, 0, sizeof(int), s->stream));
+  hipLaunchKernelGGL(peer_selftest_kernel, dim3(1), dim3(64), 0, s->stream, s->peers, s->gather, s->peer_world, s->peer_rank, dres);
+  int res = -1;
+  hipError_t e = hipMemcpyAsync(&res, dres, sizeof(int), hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  (void)hipFree(dres);
+  if (e != hipSuccess) { set_error("peer self-test: %s", hipGetErrorString(e)); return GPEMU_ERR_HIP; }
+  if (res != 0) {
+    set_error("peer self-test: the tokens of %d rank(s) did not arrive through the mapped buffers", res);
+    return GPEMU_ERR_STATE;
+  }
   return GPEMU_OK;
 }
 

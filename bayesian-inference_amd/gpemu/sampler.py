@@ -282,6 +282,12 @@ class DeviceSampler:
             buf = C.create_string_buffer(raw, 64 * world)
             if L.gpemu_sampler_peer_import(self._h, int(world), int(rank), C.cast(buf, C.c_void_p)) != 0:
                 ok = 0
+        # the data path itself, before a chain depends on it: every rank stores a token into every rank's buffer and
+        # waits (bounded) for all tokens in its own -- a mapping that opens but does not carry stores (or carries them
+        # too late) makes the ranks fall back to the collective transports together instead of losing an exchange
+        dist.barrier(group=group)
+        if ok and L.gpemu_sampler_peer_selftest(self._h) != 0:
+            ok = 0
         vote = torch.tensor([ok], dtype=torch.int32, device=where)
         dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=group)
         cache[key] = bool(int(vote.item()))

@@ -244,6 +244,11 @@ int gpemu_comm_all_gather(gpemu_comm *c, const double *dsend, double *drecv, int
 int gpemu_sampler_run_sharded(gpemu_sampler *s, gpemu_comm *c, int64_t steps, int store_chain,
                               int emulate_world);
 
+/* One-off check of the peer exchange before a chain depends on it: this rank stores a token into every rank's buffer
+ * through the pointers of gpemu_sampler_peer_import and waits (bounded, seconds) for all ranks' tokens in its own.
+ * Collective in effect: call on every rank at about the same time (after a barrier).  0 = all tokens arrived. */
+int gpemu_sampler_peer_selftest(gpemu_sampler *s);
+
 /* ---- sharded run without a collective: peer stores over xGMI ---------------------------------------------
  * Every rank owns a small "gather" buffer; after evaluating its share of a half's proposals a rank stores each new
  * log-probability (8 bytes) straight into every rank's buffer.  Setup: each rank exports a 64-byte IPC handle of its
