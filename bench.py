@@ -99,6 +99,7 @@ def measure_fit_c5(device=0):
     from gpemu.fit import DeviceFit
     N, F = 5000, 2000
     prob = synthetic.make_problem(N, F, seed=3)
+    estimators.scale_and_pca(prob["Y"][:96, :40], device=device)      # the code objects' first load is not the PCA's time
     t0 = time.perf_counter()
     scaler, pca, Y_pca = estimators.scale_and_pca(prob["Y"], device=device)
     t_pca = time.perf_counter() - t0
@@ -126,9 +127,10 @@ def measure_fit_c5(device=0):
 def measure_fit_c3(device=0, n_restarts=50):
     """The whole C3 emulator fit as the shipped configuration runs it (ref: emulation.py:169-172 with
     config/jet_substructure.yaml:80, n_restarts: 50): 10 GPs x 51 L-BFGS-B maximisations of the log-marginal
-    likelihood at N = 1000, the optimisers on host threads, every evaluation on the device."""
+    likelihood at N = 1000, the optimisers advancing in lock step on the host, their evaluations batched on the device."""
     from gpemu import estimators, synthetic
     prob = synthetic.make_problem(N_DESIGN, N_OBS, seed=0)
+    estimators.scale_and_pca(prob["Y"][:96, :40], device=device)      # the code objects' first load is not the PCA's time
     t0 = time.perf_counter()
     scaler, pca, Y_pca = estimators.scale_and_pca(prob["Y"], device=device)
     t_pca = time.perf_counter() - t0

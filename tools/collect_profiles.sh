@@ -20,4 +20,10 @@ python3 $R/tools/time_predict.py 512 1024 4096 > $OUT/predict_gbps.txt 2>&1
 python3 $R/tools/bench_closure.py > $OUT/closure_batch.txt 2>&1
 python3 $R/tools/time_pca.py 1000 500 > $OUT/pca.txt 2>&1
 python3 $R/tools/time_pca.py 5000 2000 >> $OUT/pca.txt 2>&1
+GPEMU_PCA_TRACE=1 python3 $R/tools/time_pca.py 1000 500 2>&1 | grep "pair 0:" | tail -1 >> $OUT/pca.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pca -- python3 $R/tools/time_pca.py 1000 500 > $OUT/stats_pca.log 2>&1
+python3 $R/tools/time_lml_batch.py 1000 32 > $OUT/fit_batch.txt 2>&1
+python3 $R/tools/time_lml_batch.py 1000 64 >> $OUT/fit_batch.txt 2>&1
+python3 $R/tools/time_fit_c3.py 50 64 >> $OUT/fit_batch.txt 2>&1
+GPEMU_FIT_DRIVER=threads python3 $R/tools/time_fit_c3.py 50 32 >> $OUT/fit_batch.txt 2>&1
 echo collected

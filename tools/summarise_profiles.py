@@ -23,13 +23,15 @@ def first(pattern):
 
 
 for name, out in (("stats_bench/**/*kernel_stats.csv", f"{prefix}_bench_kernel_stats.csv"),
-                  ("stats_emu8/**/*kernel_stats.csv", f"{prefix}_emulated_world8_kernel_stats.csv")):
+                  ("stats_emu8/**/*kernel_stats.csv", f"{prefix}_emulated_world8_kernel_stats.csv"),
+                  ("stats_pca/**/*kernel_stats.csv", f"{prefix}_pca_c3_kernel_stats.csv")):
     f = first(name)
     if f:
         shutil.copy(f, os.path.join(dst, out))
 for name, out in (("bench_default.json", f"{prefix}_bench_default.json"), ("emulated_sharding.jsonl", f"{prefix}_emulated_sharding.jsonl"),
                   ("fit_lml.txt", f"{prefix}_fit_lml.txt"), ("predict_gbps.txt", f"{prefix}_predict_gbps.txt"),
-                  ("closure_batch.txt", f"{prefix}_closure_batch.txt"), ("pca.txt", f"{prefix}_pca.txt")):
+                  ("closure_batch.txt", f"{prefix}_closure_batch.txt"), ("pca.txt", f"{prefix}_pca.txt"),
+                  ("fit_batch.txt", f"{prefix}_fit_batch.txt")):
     f = os.path.join(src, name)
     if os.path.exists(f):
         lines = [ln for ln in open(f) if "amdgpu.ids" not in ln]
