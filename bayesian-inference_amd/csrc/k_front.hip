@@ -61,7 +61,12 @@ struct FrontArgs {
   unsigned long long *stamps;          // diagnostic: per-workgroup time stamps (GPEMU_FRONT_STAMPS), else null
 };
 
-constexpr int GATHER_SPIN_LIMIT = 1 << 21;   // polls before an exchange is declared lost (seconds)
+// Polls before an exchange is declared lost: GATHER_FAST_POLLS short naps (the normal case: the value is at most a
+// half-step away, ~0.5 ms covers it), then long naps of ~3.5 us up to about half a minute -- ranks can fall that far
+// apart when one of them is held up on the host between two runs (logging, a file write) while the others have
+// already enqueued the next run; a rank that is really gone still ends the wait, so the grid always drains.
+constexpr int GATHER_FAST_POLLS = 1 << 12;
+constexpr int GATHER_SLOW_POLLS = 1 << 23;
 
 __device__ __forceinline__ double gather_wait(const double *entry, int *flags) {
   const unsigned long long *p = reinterpret_cast<const unsigned long long *>(entry);
@@ -70,12 +75,19 @@ __device__ __forceinline__ double gather_wait(const double *entry, int *flags) {
   for (;;) {
     bits = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (bits != GATHER_EMPTY) break;
-    if (++spins > GATHER_SPIN_LIMIT) {        // every wave reaches this exit: the grid always drains
+    if (++spins > GATHER_FAST_POLLS + GATHER_SLOW_POLLS) {   // every wave reaches this exit
       atomicAdd(flags + 1, 1);
       bits = 0x7FF8000000000000ull;
       break;
     }
-    __builtin_amdgcn_s_sleep(4);
+    if (spins <= GATHER_FAST_POLLS) {
+      __builtin_amdgcn_s_sleep(4);
+    } else {
+      // once an exchange has been declared lost (by any wave, in this or an earlier launch of the run) nobody waits long
+      if ((spins & 255) == 0 && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        spins = GATHER_FAST_POLLS + GATHER_SLOW_POLLS;
+      __builtin_amdgcn_s_sleep(127);
+    }
   }
   return __longlong_as_double((long long)bits);
 }

@@ -351,3 +351,32 @@ def test_stacked_chains_equal_separate_chains(W):
         np.testing.assert_array_equal(nacc[c * W:(c + 1) * W], one.counts()[0])
         one.close()
     dm.close()
+
+
+def test_bench_two_rank_rehearsal(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed with
+    both ranks on the one GPU of the box over gloo (RCCL refuses two ranks on a device): the N > 1 code path of the
+    bench -- rank-agreed warm-up passes, sharded run through the peer transport, max-over-ranks timing, one JSON line
+    from rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # 64 walkers: two processes time-share the one GPU, and full-size kernels of one rank would spin on stores of a rank
+    # that is not scheduled; small grids of both ranks are resident together (as in the other 2-rank tests)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPEMU_DIST_BACKEND="gloo", GPEMU_BENCH_REHEARSAL_WALKERS="64")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
+           "--no-cpu-baseline", "--no-fit"]
+    done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-3000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 30 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["rehearsal"] is True and out["config"]["n_walkers"] == 64
+    assert 0.1 < out["acceptance_fraction_mean"] < 0.9
