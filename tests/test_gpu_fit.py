@@ -179,3 +179,43 @@ def test_batched_lml_equals_single_evaluations():
     assert np.all(ib != 0)
     f2.close()
     assert np.isfinite(l_ok)
+
+
+def test_pca_rank_deficient_and_wide_matrices():
+    """Block-Jacobi SVD on matrices the goldens do not cover: duplicated and constant observables (numerically rank
+    deficient: columns of rounding residue), more observables than design points (the transposed work matrix), and
+    sizes around the block widths.  Checked against the oracle's LAPACK path in what is well defined: singular values
+    (absolute accuracy), the reconstruction Y_pca @ components, orthonormal components, sign rule indices of the
+    leading components."""
+    from gpemu.fit import pca_fit
+    rng = np.random.default_rng(42)
+    cases = []
+    base = rng.normal(size=(120, 12)) @ rng.normal(size=(12, 70)) + 1e-3 * rng.normal(size=(120, 70))
+    dup = np.hstack([base, base[:, :20], np.full((120, 3), 2.5)])          # 20 duplicated + 3 constant columns
+    cases.append(("rank deficient", dup, 12))
+    cases.append(("wide", rng.normal(size=(40, 6)) @ rng.normal(size=(6, 150)) + 1e-2 * rng.normal(size=(40, 150)), 6))
+    for n in (31, 33, 65):
+        cases.append((f"n={n}", rng.normal(size=(90, 5)) @ rng.normal(size=(5, n)) + 0.05 * rng.normal(size=(90, n)), 5))
+    for name, Y, k in cases:
+        out = pca_fit(Y)
+        mean, scale = O.scaler_fit(Y)[:2]
+        Ys = (Y - mean) / scale
+        ref = O.pca_fit(Ys)
+        nmin = min(Y.shape)
+        ev_ref = ref["explained_variance"]
+        assert np.max(np.abs(out["explained_variance"][:nmin] - ev_ref[:nmin])) < 1e-11 * ev_ref[0], name
+        Xc = Ys - Ys.mean(axis=0)
+        recon = out["Y_pca"] @ out["components"]
+        assert np.max(np.abs(recon - Xc)) < 1e-10 * np.max(np.abs(Xc)), name
+        # rows of components: orthonormal wherever the singular value is not rounding residue
+        keep = out["explained_variance"] > 1e-20 * ev_ref[0]
+        Cm = out["components"][keep]
+        assert np.max(np.abs(Cm @ Cm.T - np.eye(Cm.shape[0]))) < 1e-10, name
+        # sign rule: the entry picked is (one of) the largest in magnitude -- duplicated observables tie exactly -- and
+        # it is positive (skl utils/extmath.py:944-952)
+        for c in range(k):
+            row = out["components"][c]
+            j = int(out["flip_argmax"][c])
+            assert abs(row[j]) >= np.max(np.abs(row)) * (1 - 1e-12) and row[j] > 0, name
+        assert relerr(np.abs(out["components"][:k]), np.abs(ref["components"][:k])) < 1e-8, name
+        assert 1 <= out["n_sweeps"] <= 40, name
