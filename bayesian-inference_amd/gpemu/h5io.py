@@ -96,7 +96,8 @@ class _Writer:
     def dataset(self, arr):
         rank = arr.ndim
         space = struct.pack("<BBB5x", 1, rank, 0) + b"".join(struct.pack("<Q", n) for n in arr.shape)
-        raw = arr.tobytes()
+        # the array's own memory is written to the file later: no copy of a (possibly 500 MB) chain
+        raw = memoryview(arr if arr.flags.c_contiguous else np.ascontiguousarray(arr)).cast("B") if arr.size else b""
         msgs = [_message(0x0001, space), _message(0x0003, _datatype_message(arr.dtype), flags=1),
                 _message(0x0005, bytes([2, 2, 2, 1]) + struct.pack("<I", 0), flags=1)]
         hdr_len = 16 + sum(len(m) for m in msgs) + 8 + 24
@@ -181,13 +182,13 @@ def _write_native(tree, path):
     sb = (_SIG + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + struct.pack("<HHI", leaf_k, _INTERNAL_K, 0) +
           struct.pack("<QQQQ", 0, _UNDEF, eof, _UNDEF) + struct.pack("<QQIIQQ", 0, root, 1, 0, btree, heap))
     assert len(sb) == 96
-    buf = bytearray(eof)
-    buf[:96] = sb
-    for addr, data in w.chunks:
-        buf[addr:addr + len(data)] = data
     tmp = f"{path}.{os.getpid()}.tmp"
     with open(tmp, "wb") as f:
-        f.write(buf)
+        f.write(sb)
+        for addr, data in sorted(w.chunks, key=lambda c: c[0]):     # alignment gaps stay holes, i.e. zeros
+            f.seek(addr)
+            f.write(data)
+        f.truncate(eof)
     os.replace(tmp, path)
 
 
