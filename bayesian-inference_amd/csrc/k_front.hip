@@ -619,6 +619,10 @@ extern "C" {
 int gpemu_sampler_peer_export(gpemu_sampler *s, char *handle_out64) {
   GP_ARG(s && handle_out64, "null pointer");
   GP_HIP(hipSetDevice(s->device));
+  if (!front_eligible(s)) {     // the caller (every rank alike) then stays on the collective transports
+    set_error("the fused run needs one emulation group with at most 16 PCs and at most 2048 walkers");
+    return GPEMU_ERR_UNSUPPORTED;
+  }
   int rc = ensure_gather(s);
   if (rc != GPEMU_OK) return rc;
   hipIpcMemHandle_t h;

@@ -380,3 +380,59 @@ def test_bench_two_rank_rehearsal(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 30 and out["value"] > 0 and out["scaling"] == "strong"
     assert out["rehearsal"] is True and out["config"]["n_walkers"] == 64
     assert 0.1 < out["acceptance_fraction_mean"] < 0.9
+
+
+def _multigroup_models():
+    g = GU.load("g5_multigroup")
+    models = {grp: GU.group_model(g, prefix=grp + "_") for grp in ("g1", "g2")}
+    dms = []
+    for grp, cols, bs in (("g1", g["cols_g1"], [0, 10, 22]), ("g2", g["cols_g2"], [0, 8])):
+        dm = GU.device_model(models[grp])
+        dm.likelihood_setup(g["y_exp"][cols], g["y_err"][cols], g["lo"], g["hi"], 1.0, block_start=bs)
+        dms.append(dm)
+    return g, dms
+
+
+def _sharded_multigroup_worker(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gpemu.sampler import DeviceSampler
+    g, dms = _multigroup_models()
+    ds = DeviceSampler(dms, 16, seed=21)
+    ds.set_state(g["Xq"])
+    ds.run_sharded(6)                          # default transport: two groups are outside the fused run's limits
+    assert ds._peer_ok and not any(ds._peer_ok.values()), "the ranks should have agreed NOT to take the peer transport"
+    chain, lps = ds.get_chain()
+    np.save(os.path.join(out_dir, f"chain_{rank}.npy"), chain)
+    np.save(os.path.join(out_dir, f"lp_{rank}.npy"), lps)
+    dist.barrier()
+    dist.destroy_process_group()
+    ds.close()
+    for dm in dms:
+        dm.close()
+
+
+def test_sharded_multigroup_falls_back_together(tmp_path):
+    """Two emulation groups (the shipped analysis has three) are outside the fused two-launch run: with the default
+    transport both ranks agree to leave the peer path and exchange through torch.distributed; the chain is the
+    single-GPU chain of the same sampler, bit for bit."""
+    import os
+    import torch.multiprocessing as mp
+    from gpemu.sampler import DeviceSampler
+    port = 29300 + (os.getpid() % 200)
+    mp.spawn(_sharded_multigroup_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    c0, c1 = np.load(tmp_path / "chain_0.npy"), np.load(tmp_path / "chain_1.npy")
+    np.testing.assert_array_equal(c0, c1)
+    g, dms = _multigroup_models()
+    ds = DeviceSampler(dms, 16, seed=21)
+    ds.set_state(g["Xq"])
+    ds.run(6)
+    chain, lps = ds.get_chain()
+    np.testing.assert_array_equal(chain, c0)
+    np.testing.assert_array_equal(lps, np.load(tmp_path / "lp_0.npy"))
+    ds.close()
+    for dm in dms:
+        dm.close()
