@@ -922,6 +922,26 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
   static const int smallb_max = getenv("GPEMU_SMALLB_MAX") ? atoi(getenv("GPEMU_SMALLB_MAX")) : 128;
   static const bool old_smallb = getenv("GPEMU_TRMM_OLD_SMALLB") != nullptr;
   const int64_t Bv = m->variant_B > 0 ? m->variant_B : B;   // a chain stacked with others is evaluated as it would be alone
+  // More than 512 columns (emulation.predict on a large batch): one launch per 512 columns.  K_*^T of 1024 columns is
+  // 82 MB, and with W_p it no longer streams through the XCDs' L2s the way the 512-column schedule is built for: one
+  // launch of 1024 columns takes 228 us, two of 512 take 2 x 93 us.  Only when the pieces are equally wide (one
+  // cached schedule); the column partials of a piece land where the single launch would put them.
+  static const int64_t max_cols = getenv("GPEMU_TRMM_MAX_COLS") ? atoll(getenv("GPEMU_TRMM_MAX_COLS")) : 512;
+  if (m->variant_B == 0 && max_cols >= 256 && B > max_cols) {
+    const int64_t n = (B + max_cols - 1) / max_cols, per = round_up((B + n - 1) / n, TILE), last = B - (n - 1) * per;
+    if (last > 0 && round_up(last, TILE) == per) {
+      double *const KS0 = w.KS, *const V0 = w.vsq_part;
+      int rc = GPEMU_OK;
+      for (int64_t c0 = 0; c0 < B && rc == GPEMU_OK; c0 += per) {
+        w.KS = KS0 + c0;
+        w.vsq_part = V0 + c0 * m->k * m->vsq_nrb;
+        rc = launch_trmm_vsq(m, std::min(per, B - c0), st);
+      }
+      w.KS = KS0;
+      w.vsq_part = V0;
+      return rc;
+    }
+  }
   if (Bv <= smallb_max && !old_smallb) {  // small batch: persistent 32 x 32 items, operands straight into registers
     const int rc = launch_trmm_vsq_small(m, B, st);
     if (rc != GPEMU_ERR_UNSUPPORTED) return rc;
