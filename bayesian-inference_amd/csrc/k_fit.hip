@@ -16,6 +16,7 @@
 //   GEMM (SYRK)         A22 -= panel . panel^T, lower tiles only                     (MFMA f64)
 // Triangular inverse W = L^-1 by block rows with two MFMA GEMMs per block row; the inverted
 // diagonal blocks come from the Cholesky step.
+#include <algorithm>
 #include <cmath>
 
 #include "gemm.h"
@@ -234,32 +235,50 @@ __global__ __launch_bounds__(256) void scatter_diag_blocks_kernel(const double *
 
 // In-place lower Cholesky of the Np x Np matrix A (Np multiple of 64); Dinv receives the inverted
 // diagonal blocks [Np/64][64][64].
-// nb > 1: a batch of matrices A + z Np^2 (Dinv + z Np 64, dinfo + z), every launch serving all of them
+// nb > 1: a batch of matrices A + z Np^2 (Dinv + z Np 64, dinfo + z), every launch serving all of them.
+// Two levels: the 64-wide steps (diagonal factor, panel solve) only update the rest of their own PANEL of CHOL_Q blocks;
+// the trailing matrix beyond the panel gets ONE rank-(64 CHOL_Q) update per panel -- a quarter of the passes over it of a
+// rank-64 update per step (the update is HBM bound at K = 64: 8 FLOP per byte moved).
 int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hipStream_t st, int nb) {
   const int nblk = (int)(Np / NB);
-  for (int jb = 0; jb < nblk; ++jb) {
-    const int64_t j0 = (int64_t)jb * NB;
-    double *Ajj = A + j0 * Np + j0;
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, (unsigned)nb), dim3(256), 0, st, Ajj, Np, Dinv + (int64_t)jb * NB * NB, 1,
-                       jb, dinfo, Np * Np, Np * NB);
-    GP_HIP(hipGetLastError());
-    const int M = (int)(Np - j0 - NB);
-    if (M <= 0) break;
-    double *A21 = A + (j0 + NB) * Np + j0;
-    GemmArgs g;   // panel = A21 . inv(L11)^T, in place: a workgroup owns whole 64-wide rows of the panel and has
-    g.A = A21; g.lda = Np;   // read them completely (K = 64) before it stores
-    g.B = Dinv + (int64_t)jb * NB * NB; g.ldb = NB;
-    g.C = A21; g.ldc = Np;
-    g.M = M; g.N = NB; g.K = NB;
-    g.strideA = Np * Np; g.strideB = Np * NB; g.strideC = Np * Np;
-    int rc = launch_gemm(g, false, false, nb, st);
-    if (rc != GPEMU_OK) return rc;
-    GemmArgs s;   // A22 -= panel . panel^T (lower tiles)
-    s.A = A21; s.lda = Np; s.B = A21; s.ldb = Np;
-    s.C = A + (j0 + NB) * Np + (j0 + NB); s.ldc = Np;
-    s.M = M; s.N = M; s.K = NB; s.alpha = -1.0; s.beta = 1.0; s.lower_only = 1;
-    s.strideA = Np * Np; s.strideB = Np * Np; s.strideC = Np * Np;
-    rc = launch_gemm(s, false, false, nb, st);
+  static const int chol_q = getenv("GPEMU_CHOL_PANEL_BLOCKS") ? std::max(1, atoi(getenv("GPEMU_CHOL_PANEL_BLOCKS"))) : 4;
+  // A[rows r0 ..][cols c0 .. c1) -= A[rows r0 ..][k0 .. k1) . A[rows c0 .. c1)[k0 .. k1)^T, lower tiles only
+  auto update = [&](int64_t r0, int64_t c0, int64_t c1, int64_t k0, int64_t k1) -> int {
+    const int M = (int)(Np - r0), N = (int)(c1 - c0);
+    if (M <= 0 || N <= 0) return GPEMU_OK;
+    GemmArgs u;
+    u.A = A + r0 * Np + k0; u.lda = Np;
+    u.B = A + c0 * Np + k0; u.ldb = Np;
+    u.C = A + r0 * Np + c0; u.ldc = Np;
+    u.M = M; u.N = N; u.K = (int)(k1 - k0); u.alpha = -1.0; u.beta = 1.0; u.lower_only = (r0 == c0) ? 1 : 0;
+    u.strideA = Np * Np; u.strideB = Np * Np; u.strideC = Np * Np;
+    return launch_gemm(u, false, false, nb, st);
+  };
+  for (int jb0 = 0; jb0 < nblk; jb0 += chol_q) {
+    const int jb1 = std::min(nblk, jb0 + chol_q);             // the panel: blocks [jb0, jb1)
+    for (int jb = jb0; jb < jb1; ++jb) {
+      const int64_t j0 = (int64_t)jb * NB;
+      hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, (unsigned)nb), dim3(256), 0, st, A + j0 * Np + j0, Np,
+                         Dinv + (int64_t)jb * NB * NB, 1, jb, dinfo, Np * Np, Np * NB);
+      GP_HIP(hipGetLastError());
+      const int M = (int)(Np - j0 - NB);
+      if (M <= 0) break;
+      double *A21 = A + (j0 + NB) * Np + j0;
+      GemmArgs g;   // panel = A21 . inv(L11)^T, in place: a workgroup owns whole 64-wide rows of the panel and has
+      g.A = A21; g.lda = Np;   // read them completely (K = 64) before it stores
+      g.B = Dinv + (int64_t)jb * NB * NB; g.ldb = NB;
+      g.C = A21; g.ldc = Np;
+      g.M = M; g.N = NB; g.K = NB;
+      g.strideA = Np * Np; g.strideB = Np * NB; g.strideC = Np * Np;
+      int rc = launch_gemm(g, false, false, nb, st);
+      if (rc != GPEMU_OK) return rc;
+      // the rest of this panel's columns: blocks (jb, jb1), rows from block jb + 1 down
+      rc = update(j0 + NB, j0 + NB, (int64_t)jb1 * NB, j0, j0 + NB);
+      if (rc != GPEMU_OK) return rc;
+    }
+    // everything beyond the panel, with the whole panel at once
+    const int64_t t0 = (int64_t)jb1 * NB;
+    const int rc = update(t0, t0, Np, (int64_t)jb0 * NB, t0);
     if (rc != GPEMU_OK) return rc;
   }
   return GPEMU_OK;
