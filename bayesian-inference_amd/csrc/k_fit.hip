@@ -25,6 +25,7 @@
 namespace gpemu {
 
 constexpr int NB = 64;
+typedef double d4t __attribute__((ext_vector_type(4)));
 
 // ---- kernel matrix ---------------------------------------------------------------------------
 __device__ __forceinline__ double base_from_r2(int kind, double r2) {
@@ -118,18 +119,27 @@ __device__ __forceinline__ void panel_step(double (*D)[NB + 1], int tid, int blk
   __syncthreads();
   constexpr int T0 = J0 + PB, M = NB - T0;       // trailing block [T0, 64)^2, lower triangle
   if (M > 0) {
-    for (int idx = tid; idx < M * M; idx += 256) {
-      const int i = idx / (M > 0 ? M : 1), c = idx % (M > 0 ? M : 1);
-      if (c <= i) {
-        double acc0 = D[T0 + i][T0 + c], acc1 = 0.0;
+    // rank-16 update of the trailing lower triangle on the matrix cores: 16 x 16 tiles (ti >= tj) dealt to the four
+    // waves, four k-steps each; a diagonal tile writes its lower part only (the column sweep relies on zeros above)
+    const int lr = lane & 15, lk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    int t = 0;
 #pragma unroll
-        for (int t = 0; t < PB; t += 2) {
-          acc0 = fma(-D[T0 + i][J0 + t], D[T0 + c][J0 + t], acc0);
-          acc1 = fma(-D[T0 + i][J0 + t + 1], D[T0 + c][J0 + t + 1], acc1);
+    for (int ti = 0; ti < M / 16; ++ti)
+#pragma unroll
+      for (int tj = 0; tj <= ti; ++tj) {
+        if ((t++ & 3) != wv) continue;
+        d4t acc = d4t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < PB / 4; ++ks)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[T0 + 16 * ti + lr][J0 + 4 * ks + lk], D[T0 + 16 * tj + lr][J0 + 4 * ks + lk],
+                                                     acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = lk + 4 * r, col = lr;
+          if (ti != tj || col <= row) D[T0 + 16 * ti + row][T0 + 16 * tj + col] -= acc[r];
         }
-        D[T0 + i][T0 + c] = acc0 + acc1;
       }
-    }
     __syncthreads();
   }
 }
@@ -137,31 +147,49 @@ __device__ __forceinline__ void panel_step(double (*D)[NB + 1], int tid, int blk
 // X21 = -X22 (L21 X11) for every pair of adjacent B x B diagonal blocks of the 64 x 64 factor D / inverse X
 template <int B>
 __device__ __forceinline__ void merge_level(double (*D)[NB + 1], double (*X)[NB + 1], double (*T)[32 + 1], int tid) {
-  constexpr int NPAIR = NB / (2 * B);
-  // T = L21 . X11
-  for (int idx = tid; idx < NPAIR * B * B; idx += 256) {
-    const int pr = idx / (B * B), i = (idx / B) % B, c = idx % B;
-    const int p0 = pr * 2 * B;
-    double acc0 = 0.0, acc1 = 0.0;
+  constexpr int NPAIR = NB / (2 * B), NT = B / 16;      // 16 x 16 output tiles per side of a pair
+  const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // T = L21 . X11 on the matrix cores: NPAIR * NT * NT tiles over the four waves
+  {
+    int t = 0;
 #pragma unroll
-    for (int kk = 0; kk < B; kk += 2) {
-      acc0 = fma(D[p0 + B + i][p0 + kk], X[p0 + kk][p0 + c], acc0);
-      acc1 = fma(D[p0 + B + i][p0 + kk + 1], X[p0 + kk + 1][p0 + c], acc1);
-    }
-    T[(pr * B + i) & 31][c] = acc0 + acc1;
+    for (int pr = 0; pr < NPAIR; ++pr)
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+          if ((t++ & 3) != wv) continue;
+          const int p0 = pr * 2 * B;
+          d4t acc = d4t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < B / 4; ++ks)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[p0 + B + 16 * ti + lr][p0 + 4 * ks + lk],
+                                                       X[p0 + 4 * ks + lk][p0 + 16 * tj + lr], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) T[(pr * B + 16 * ti + lk + 4 * r) & 31][16 * tj + lr] = acc[r];
+        }
   }
   __syncthreads();
   // X21 = -X22 . T
-  for (int idx = tid; idx < NPAIR * B * B; idx += 256) {
-    const int pr = idx / (B * B), i = (idx / B) % B, c = idx % B;
-    const int p0 = pr * 2 * B;
-    double acc0 = 0.0, acc1 = 0.0;
+  {
+    int t = 0;
 #pragma unroll
-    for (int kk = 0; kk < B; kk += 2) {
-      acc0 = fma(X[p0 + B + i][p0 + B + kk], T[(pr * B + kk) & 31][c], acc0);
-      acc1 = fma(X[p0 + B + i][p0 + B + kk + 1], T[(pr * B + kk + 1) & 31][c], acc1);
-    }
-    X[p0 + B + i][p0 + c] = -(acc0 + acc1);
+    for (int pr = 0; pr < NPAIR; ++pr)
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+          if ((t++ & 3) != wv) continue;
+          const int p0 = pr * 2 * B;
+          d4t acc = d4t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < B / 4; ++ks)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[p0 + B + 16 * ti + lr][p0 + B + 4 * ks + lk],
+                                                       T[(pr * B + 4 * ks + lk) & 31][16 * tj + lr], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) X[p0 + B + 16 * ti + lk + 4 * r][p0 + 16 * tj + lr] = -acc[r];
+        }
   }
   __syncthreads();
 }
@@ -179,19 +207,30 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double *Ab = A + ((int64_t)blockIdx.x * NB) * lda + (int64_t)blockIdx.x * NB;
   double *Db = Dinv + (int64_t)blockIdx.x * NB * NB;
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int r = idx >> 6, c = idx & 63;
-    D[r][c] = (c <= r) ? Ab[(int64_t)r * lda + c] : 0.0;
-    X[r][c] = 0.0;
+  {
+    // all 16 loads of a thread in flight together (the block was written by the previous launch on other CUs: every
+    // load is a trip to memory; issued one by one between the LDS stores they cost 4.7 us)
+    double v[NB * NB / 256];
+#pragma unroll
+    for (int u = 0; u < NB * NB / 256; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
+      v[u] = (c <= r) ? Ab[(int64_t)r * lda + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < NB * NB / 256; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
+      D[r][c] = v[u];
+      X[r][c] = 0.0;
+    }
   }
   __syncthreads();
   if (do_factor) {
     const int blk = block_index + (int)blockIdx.x;
     panel_step<0>(D, tid, blk, info);
-    panel_step<16>(D, tid, blk, info);
+      panel_step<16>(D, tid, blk, info);
     panel_step<32>(D, tid, blk, info);
     panel_step<48>(D, tid, blk, info);
-    for (int idx = tid; idx < NB * NB; idx += 256) {
+      for (int idx = tid; idx < NB * NB; idx += 256) {
       const int r = idx >> 6, c = idx & 63;
       Ab[(int64_t)r * lda + c] = D[r][c];    // zeros above the diagonal
     }
