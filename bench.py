@@ -125,6 +125,20 @@ def measure_fit_c5(device=0):
         out[key + "_roofline"] = {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS,
                                   "unit": "TFLOP/s", "frac": flop / dt / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
                                   "algorithmic_gflop": flop / 1e9}
+    # the form the fit itself uses: several (target, theta) problems through one launch chain (gpemu_fit_lml_batch)
+    nbatch = 8
+    rng = np.random.default_rng(1)
+    ys = np.stack([Y_pca[:, i % Y_pca.shape[1]] for i in range(nbatch)])
+    thetas = np.stack([theta + 0.1 * rng.normal(size=theta.size) for _ in range(nbatch)])
+    fit.lml_batch(ys, thetas)
+    t0 = time.perf_counter()
+    fit.lml_batch(ys, thetas)
+    dt = (time.perf_counter() - t0) / nbatch
+    flop = N ** 3
+    out["lml_grad_batched_ms_per_problem"] = dt * 1e3
+    out["lml_grad_batched_roofline"] = {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": FP64_MATRIX_PEAK_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": flop / dt / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                                        "problems_per_launch_chain": nbatch}
     fit.close()
     return out
 
