@@ -25,7 +25,7 @@ struct GemmArgs {
 };
 
 // C = alpha op(A) op(B) + beta C; a_kmajor: A stored [k][m] else [m][k]; b_kmajor: B stored [k][n]
-// else [n][k].  M, N multiples of 64, K multiple of 32.
+// else [n][k].  M, N multiples of 64, K multiple of 16.
 int launch_gemm(const GemmArgs &g, bool a_kmajor, bool b_kmajor, int batch, hipStream_t st);
 
 }  // namespace gpemu

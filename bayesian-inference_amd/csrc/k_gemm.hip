@@ -6,9 +6,11 @@
 // Operand layouts are template flags so that every caller reads memory the way it lies:
 //   A_KMAJOR: A is stored [k][m] (i.e. op(A) = A^T of a row-major K x M array), else [m][k]
 //   B_KMAJOR: B is stored [k][n], else [n][k] (op(B) = B^T of a row-major N x K array)
-// All of M, N must be multiples of 64 and K a multiple of 32 (callers pad; the fit workspace is
+// All of M, N must be multiples of 64 and K a multiple of 16 (callers pad; the fit workspace is
 // padded to 64 with an identity tail).  Tile 64 x 64, 256 threads = 4 waves (2 x 2, 32 x 32 each),
-// K step 32, LDS double buffered.  `lower_only` skips tiles strictly above the diagonal (SYRK).
+// K step 16, LDS double buffered: 40 KiB per workgroup, four workgroups (16 waves) per CU -- with K step 32 only two
+// fit and the matrix pipes starve (batched N = 1000: 5.4 -> 5.0 ms per 64 problems; K step 8 is slower again).
+// `lower_only` skips tiles strictly above the diagonal (SYRK).
 #include "internal.h"
 #include "gemm.h"
 
@@ -18,13 +20,13 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int GT = 64;      // tile edge
-constexpr int GK = 32;      // K step
+constexpr int GK = 16;      // K step (16: 40 KiB of LDS per workgroup, four workgroups per CU)
 constexpr int GSK = 80;     // LDS stride of a k-major tile  [32][80]   ((2*80) % 64 == 32)
-constexpr int GSM = 34;     // LDS stride of an m-major tile [64][34]   (rows 4 banks apart)
+constexpr int GSM = 18;     // LDS stride of an m-major tile [64][18]
 
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) double sA[2][GK * GSK];   // either layout fits: 2560 doubles
+  __shared__ __attribute__((aligned(16))) double sA[2][GK * GSK];   // either layout fits (16 x 80 >= 64 x 18)
   __shared__ __attribute__((aligned(16))) double sB[2][GK * GSK];
   const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
   if (g.lower_only && n0 > m0) return;
@@ -42,25 +44,26 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   // staging: each operand tile is 64 x 32 doubles = 1024 x 16 B -> 4 per thread
   //   k-major source [k][m]: 32 rows of 64 doubles  -> idx = tid + 256 r: row = idx >> 5, c2 = idx & 31
   //   m-major source [m][k]: 64 rows of 32 doubles  -> idx = tid + 256 r: row = idx >> 4, c2 = idx & 15
-  d2 ra[4], rb[4];
+  constexpr int NST = GT * GK / 2 / 256;   // 16-byte pieces of an operand tile per thread
+  d2 ra[NST], rb[NST];
   auto gload = [&](int kt) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NST; ++r) {
       const int idx = tid + 256 * r;
       if (A_KMAJOR) ra[r] = *reinterpret_cast<const d2 *>(A + (int64_t)(kt * GK + (idx >> 5)) * g.lda + m0 + 2 * (idx & 31));
-      else ra[r] = *reinterpret_cast<const d2 *>(A + (int64_t)(m0 + (idx >> 4)) * g.lda + kt * GK + 2 * (idx & 15));
+      else ra[r] = *reinterpret_cast<const d2 *>(A + (int64_t)(m0 + idx / (GK / 2)) * g.lda + kt * GK + 2 * (idx % (GK / 2)));
       if (B_KMAJOR) rb[r] = *reinterpret_cast<const d2 *>(B + (int64_t)(kt * GK + (idx >> 5)) * g.ldb + n0 + 2 * (idx & 31));
-      else rb[r] = *reinterpret_cast<const d2 *>(B + (int64_t)(n0 + (idx >> 4)) * g.ldb + kt * GK + 2 * (idx & 15));
+      else rb[r] = *reinterpret_cast<const d2 *>(B + (int64_t)(n0 + idx / (GK / 2)) * g.ldb + kt * GK + 2 * (idx % (GK / 2)));
     }
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NST; ++r) {
       const int idx = tid + 256 * r;
       if (A_KMAJOR) *reinterpret_cast<d2 *>(&sA[buf][(idx >> 5) * GSK + 2 * (idx & 31)]) = ra[r];
-      else *reinterpret_cast<d2 *>(&sA[buf][(idx >> 4) * GSM + 2 * (idx & 15)]) = ra[r];
+      else *reinterpret_cast<d2 *>(&sA[buf][(idx / (GK / 2)) * GSM + 2 * (idx % (GK / 2))]) = ra[r];
       if (B_KMAJOR) *reinterpret_cast<d2 *>(&sB[buf][(idx >> 5) * GSK + 2 * (idx & 31)]) = rb[r];
-      else *reinterpret_cast<d2 *>(&sB[buf][(idx >> 4) * GSM + 2 * (idx & 15)]) = rb[r];
+      else *reinterpret_cast<d2 *>(&sB[buf][(idx / (GK / 2)) * GSM + 2 * (idx % (GK / 2))]) = rb[r];
     }
   };
 
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
 
 int launch_gemm(const GemmArgs &g, bool a_kmajor, bool b_kmajor, int batch, hipStream_t st) {
   if (g.M % GT || g.N % GT || g.K % GK) {
-    set_error("gemm: M, N must be multiples of 64 and K of 32 (got %d %d %d)", g.M, g.N, g.K);
+    set_error("gemm: M, N must be multiples of 64 and K of %d (got %d %d %d)", GK, g.M, g.N, g.K);
     return GPEMU_ERR_ARG;
   }
   if (g.M == 0 || g.N == 0) return GPEMU_OK;
