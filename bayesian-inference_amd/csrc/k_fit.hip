@@ -42,28 +42,44 @@ __device__ __forceinline__ double base_from_r2(int kind, double r2) {
 
 // X [Np][DPAD] raw inputs; hp = {ls[DPAD], const, noise}; K[i][j] for i,j < N, identity tail
 // blockIdx.z: problem of a batch (own hyper-parameters and matrix, shared inputs)
-__global__ void kmat_kernel(const double *__restrict__ X, const double *__restrict__ hp, double *__restrict__ K,
-                            int N, int Np, int kind, double jitter) {
+constexpr int KMAT_ROWS = 16;     // rows of K per workgroup: the scaled coordinates of column j are formed once for all of them
+__global__ __launch_bounds__(256) void kmat_kernel(const double *__restrict__ X, const double *__restrict__ hp,
+                                                   double *__restrict__ K, int N, int Np, int kind, double jitter) {
+  __shared__ double s_xi[KMAT_ROWS][DPAD];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = blockIdx.y;
-  if (j >= Np) return;
+  const int i0 = blockIdx.y * KMAT_ROWS;
   hp += (int64_t)blockIdx.z * (DPAD + 2);
   K += (int64_t)blockIdx.z * Np * Np;
-  double v;
-  if (i >= N || j >= N) {
-    v = (i == j) ? 1.0 : 0.0;
-  } else if (i == j) {
-    v = 1.0 + hp[DPAD] + hp[DPAD + 1] + jitter;   // np.fill_diagonal(K, 1) + const + noise + alpha
-  } else {
-    double r2 = 0.0;
-#pragma unroll
-    for (int dd = 0; dd < DPAD; ++dd) {
-      double df = X[i * DPAD + dd] / hp[dd] - X[j * DPAD + dd] / hp[dd];   // skl: X / length_scale
-      r2 = fma(df, df, r2);
-    }
-    v = base_from_r2(kind, r2) + hp[DPAD];
+  // skl: X / length_scale, then the difference -- the quotients are the same numbers whoever forms them
+  if (threadIdx.x < KMAT_ROWS * DPAD) {
+    const int r = threadIdx.x / DPAD, dd = threadIdx.x % DPAD;
+    s_xi[r][dd] = (i0 + r < N) ? X[(i0 + r) * DPAD + dd] / hp[dd] : 0.0;
   }
-  K[(int64_t)i * Np + j] = v;
+  double xj[DPAD];
+#pragma unroll
+  for (int dd = 0; dd < DPAD; ++dd) xj[dd] = (j < N) ? X[j * DPAD + dd] / hp[dd] : 0.0;
+  const double cst = hp[DPAD], diag = 1.0 + hp[DPAD] + hp[DPAD + 1] + jitter;   // np.fill_diagonal(K, 1) + const + noise + alpha
+  __syncthreads();
+  if (j >= Np) return;
+  for (int r = 0; r < KMAT_ROWS; ++r) {
+    const int i = i0 + r;
+    if (i >= Np) break;
+    double v;
+    if (i >= N || j >= N) {
+      v = (i == j) ? 1.0 : 0.0;
+    } else if (i == j) {
+      v = diag;
+    } else {
+      double r2 = 0.0;
+#pragma unroll
+      for (int dd = 0; dd < DPAD; ++dd) {
+        const double df = s_xi[r][dd] - xj[dd];
+        r2 = fma(df, df, r2);
+      }
+      v = base_from_r2(kind, r2) + cst;
+    }
+    K[(int64_t)i * Np + j] = v;
+  }
 }
 
 // ---- 64 x 64 diagonal block: Cholesky + inverse ------------------------------------------------
@@ -679,7 +695,7 @@ static int fit_eval_batch(gpemu_fit *f, int nb, const double *ys, const double *
   GP_HIP(hipMemcpyAsync(f->hp, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice, st));
   GP_HIP(hipMemcpyAsync(f->y, hy.data(), sizeof(double) * hy.size(), hipMemcpyHostToDevice, st));
   GP_HIP(hipMemsetAsync(f->info, 0, sizeof(int) * nb, st));
-  hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)Np, (unsigned)nb), dim3(256), 0, st, f->X,
+  hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)((Np + KMAT_ROWS - 1) / KMAT_ROWS), (unsigned)nb), dim3(256), 0, st, f->X,
                      f->hp, f->K, (int)N, (int)Np, f->kind, f->jitter);
   GP_HIP(hipGetLastError());
   GP_TRY(device_cholesky_blocked(f->K, Np, f->Dinv, f->info, st, nb));
@@ -834,7 +850,7 @@ int gpemu_kernel_matrix(int device, int64_t N, int64_t d, const double *X, const
     hp[DPAD] = f->has_const ? std::exp(theta[d]) : 0.0;
     hp[DPAD + 1] = f->has_noise ? std::exp(theta[d + f->has_const]) : 0.0;
     hipError_t e = hipMemcpy(f->hp, hp, sizeof(hp), hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)((f->Np + 255) / 256), (unsigned)f->Np), dim3(256), 0, f->stream,
+    hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)((f->Np + 255) / 256), (unsigned)((f->Np + KMAT_ROWS - 1) / KMAT_ROWS)), dim3(256), 0, f->stream,
                        f->X, f->hp, f->K, (int)N, (int)f->Np, f->kind, jitter);
     if (e == hipSuccess) e = hipStreamSynchronize(f->stream);
     if (e == hipSuccess)
