@@ -45,8 +45,11 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   //   k-major source [k][m]: 32 rows of 64 doubles  -> idx = tid + 256 r: row = idx >> 5, c2 = idx & 31
   //   m-major source [m][k]: 64 rows of 32 doubles  -> idx = tid + 256 r: row = idx >> 4, c2 = idx & 15
   constexpr int NST = GT * GK / 2 / 256;   // 16-byte pieces of an operand tile per thread
-  d2 ra[NST], rb[NST];
-  auto gload = [&](int kt) {
+  // two register stages: the loads of k-tile t + 2 are issued while k-tile t is multiplied and k-tile t + 1 waits in the
+  // other stage for its turn to be written to LDS -- two k-tiles of compute cover a load's trip (with one stage and
+  // K step 16 the matrix pipes were busy 25 % of the time in the batched N = 1000 case)
+  d2 ra0[NST], rb0[NST], ra1[NST], rb1[NST];
+  auto gload = [&](int kt, d2 (&ra)[NST], d2 (&rb)[NST]) {
 #pragma unroll
     for (int r = 0; r < NST; ++r) {
       const int idx = tid + 256 * r;
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       else rb[r] = *reinterpret_cast<const d2 *>(B + (int64_t)(n0 + idx / (GK / 2)) * g.ldb + kt * GK + 2 * (idx % (GK / 2)));
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const d2 (&ra)[NST], const d2 (&rb)[NST]) {
 #pragma unroll
     for (int r = 0; r < NST; ++r) {
       const int idx = tid + 256 * r;
@@ -79,13 +82,14 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   if (g.k_from_n && n0 / GK > kt0) kt0 = n0 / GK;
   if (g.k_to_m && (m0 + GT) / GK < nk) nk = (m0 + GT) / GK;
   if (nk > kt0) {
-    gload(kt0);
-    sstore(0);
+    gload(kt0, ra0, rb0);
+    if (kt0 + 1 < nk) gload(kt0 + 1, ra1, rb1);
+    sstore(0, ra0, rb0);
   }
   __syncthreads();
-  for (int kt = kt0; kt < nk; ++kt) {
-    const int buf = (kt - kt0) & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+  // k-tile kt is in LDS buffer `buf`, k-tile kt + 1 in register stage `nxt`; stage `ld` takes k-tile kt + 2
+  auto ktile = [&](int kt, int buf, d2 (&ra_ld)[NST], d2 (&rb_ld)[NST], const d2 (&ra_nxt)[NST], const d2 (&rb_nxt)[NST]) {
+    if (kt + 2 < nk) gload(kt + 2, ra_ld, rb_ld);
 #pragma unroll
     for (int ks = 0; ks < GK / 4; ++ks) {
       double a[2], b[2];
@@ -105,22 +109,46 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
         for (int ni = 0; ni < 2; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
     }
-    if (kt + 1 < nk) sstore(buf ^ 1);
+    if (kt + 1 < nk) sstore(buf ^ 1, ra_nxt, rb_nxt);
     __syncthreads();
+  };
+  for (int kt = kt0; kt < nk; kt += 2) {
+    // even step: tile kt in buffer 0, tile kt + 1 in stage 1, stage 0 is free (its tile kt is already in LDS)
+    ktile(kt, 0, ra0, rb0, ra1, rb1);
+    if (kt + 1 < nk) ktile(kt + 1, 1, ra1, rb1, ra0, rb0);
   }
   // D[reg] is row (lane >> 4) + 4 * reg, column lane & 15 of each 16 x 16 tile
+  double *cp[2][2][4];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 32 + mi * 16 + lk + 4 * r;
-        const int col = n0 + wn * 32 + ni * 16 + lr;
-        double *c = C + (int64_t)row * g.ldc + col;
-        const double v = g.alpha * acc[mi][ni][r];
-        *c = (g.beta == 0.0) ? v : fma(g.beta, *c, v);
-      }
+      for (int r = 0; r < 4; ++r)
+        cp[mi][ni][r] = C + (int64_t)(m0 + wm * 32 + mi * 16 + lk + 4 * r) * g.ldc + n0 + wn * 32 + ni * 16 + lr;
+  if (g.beta == 0.0) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *cp[mi][ni][r] = g.alpha * acc[mi][ni][r];
+  } else {
+    // all 16 reads of C in flight together (element by element, each behind its own wait, they cost a trip each)
+    double cold[2][2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cold[mi][ni][r] = *cp[mi][ni][r];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *cp[mi][ni][r] = fma(g.beta, cold[mi][ni][r], g.alpha * acc[mi][ni][r]);
+  }
 }
 
 int launch_gemm(const GemmArgs &g, bool a_kmajor, bool b_kmajor, int batch, hipStream_t st) {
