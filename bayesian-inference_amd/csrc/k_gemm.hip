@@ -21,14 +21,23 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int GT = 64;      // tile edge
 constexpr int GK = 16;      // K step (16: 40 KiB of LDS per workgroup, four workgroups per CU)
-constexpr int GSK = 80;     // LDS stride of a k-major tile  [32][80]   ((2*80) % 64 == 32)
-constexpr int GSM = 18;     // LDS stride of an m-major tile [64][18]
+constexpr int GSM = GK + 2; // LDS stride of an m-major tile [T][18]
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+// TW = MFMA tiles per side of a wave's part of C: 2 -> 64 x 64 workgroup tile (32 x 32 per wave), 4 -> 128 x 128
+// (64 x 64 per wave: 8 LDS fragment reads feed 16 MFMAs instead of 4 feeding 4, and a tile moves half the operand bytes
+// per FLOP -- the 64 x 64 tile needs 1 byte per 8 FLOP from L2 / HBM, which bounds it near 30 TF once the operands of a
+// batch stop fitting in cache).  The arithmetic per element of C is the same either way (the k-steps of an MFMA chain
+// run in the same order; the extra k-tiles a 128-row tile covers for half of its rows under a triangular K range
+// multiply exact zeros), so both give the same bits.  TW = 4: M, N multiples of 64 -- the last tile row / column may
+// be half a tile -- and under `lower_only` the upper-right quarter of a diagonal tile is neither computed nor stored.
+template <bool A_KMAJOR, bool B_KMAJOR, int TW>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) double sA[2][GK * GSK];   // either layout fits (16 x 80 >= 64 x 18)
-  __shared__ __attribute__((aligned(16))) double sB[2][GK * GSK];
-  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  constexpr int T = 32 * TW;                 // workgroup tile edge
+  constexpr int SK = T + 16;                 // LDS stride of a k-major tile [GK][T + 16]: (2 * SK) % 64 == 32
+  constexpr int TSZ = (GK * SK > T * GSM) ? GK * SK : T * GSM;
+  __shared__ __attribute__((aligned(16))) double sA[2][TSZ];
+  __shared__ __attribute__((aligned(16))) double sB[2][TSZ];
+  const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
   if (g.lower_only && n0 > m0) return;
   const int z1 = g.batch1 > 0 ? (int)(blockIdx.z % g.batch1) : (int)blockIdx.z;
   const int z2 = g.batch1 > 0 ? (int)(blockIdx.z / g.batch1) : 0;
@@ -37,50 +46,62 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   double *C = g.C + (int64_t)z1 * g.strideC + (int64_t)z2 * g.stride2C;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 15, lk = lane >> 4;
+  // a wave's part of C outside the matrix (half tile at the edge) or above the diagonal of a SYRK tile: nothing to do
+  const bool dead = (m0 + wm * (T / 2) >= g.M) || (n0 + wn * (T / 2) >= g.N) ||
+                    (TW == 4 && g.lower_only && m0 == n0 && wm == 0 && wn == 1);
 
-  // staging: each operand tile is 64 x 32 doubles = 1024 x 16 B -> 4 per thread
-  //   k-major source [k][m]: 32 rows of 64 doubles  -> idx = tid + 256 r: row = idx >> 5, c2 = idx & 31
-  //   m-major source [m][k]: 64 rows of 32 doubles  -> idx = tid + 256 r: row = idx >> 4, c2 = idx & 15
-  constexpr int NST = GT * GK / 2 / 256;   // 16-byte pieces of an operand tile per thread
+  // staging: an operand tile is T x GK doubles; NST 16-byte pieces per thread
+  //   k-major source [k][m]: GK rows of T doubles;  m-major source [m][k]: T rows of GK doubles
+  constexpr int NST = T * GK / 2 / 256;
   // two register stages: the loads of k-tile t + 2 are issued while k-tile t is multiplied and k-tile t + 1 waits in the
-  // other stage for its turn to be written to LDS -- two k-tiles of compute cover a load's trip (with one stage and
-  // K step 16 the matrix pipes were busy 25 % of the time in the batched N = 1000 case)
+  // other stage for its turn to be written to LDS -- two k-tiles of compute cover a load's trip
   d2 ra0[NST], rb0[NST], ra1[NST], rb1[NST];
   auto gload = [&](int kt, d2 (&ra)[NST], d2 (&rb)[NST]) {
 #pragma unroll
     for (int r = 0; r < NST; ++r) {
       const int idx = tid + 256 * r;
-      if (A_KMAJOR) ra[r] = *reinterpret_cast<const d2 *>(A + (int64_t)(kt * GK + (idx >> 5)) * g.lda + m0 + 2 * (idx & 31));
-      else ra[r] = *reinterpret_cast<const d2 *>(A + (int64_t)(m0 + idx / (GK / 2)) * g.lda + kt * GK + 2 * (idx % (GK / 2)));
-      if (B_KMAJOR) rb[r] = *reinterpret_cast<const d2 *>(B + (int64_t)(kt * GK + (idx >> 5)) * g.ldb + n0 + 2 * (idx & 31));
-      else rb[r] = *reinterpret_cast<const d2 *>(B + (int64_t)(n0 + idx / (GK / 2)) * g.ldb + kt * GK + 2 * (idx % (GK / 2)));
+      if (A_KMAJOR) {
+        const int mm = m0 + 2 * (idx % (T / 2));
+        ra[r] = mm < g.M ? *reinterpret_cast<const d2 *>(A + (int64_t)(kt * GK + idx / (T / 2)) * g.lda + mm) : d2{0.0, 0.0};
+      } else {
+        const int mm = m0 + idx / (GK / 2);
+        ra[r] = mm < g.M ? *reinterpret_cast<const d2 *>(A + (int64_t)mm * g.lda + kt * GK + 2 * (idx % (GK / 2))) : d2{0.0, 0.0};
+      }
+      if (B_KMAJOR) {
+        const int nn = n0 + 2 * (idx % (T / 2));
+        rb[r] = nn < g.N ? *reinterpret_cast<const d2 *>(B + (int64_t)(kt * GK + idx / (T / 2)) * g.ldb + nn) : d2{0.0, 0.0};
+      } else {
+        const int nn = n0 + idx / (GK / 2);
+        rb[r] = nn < g.N ? *reinterpret_cast<const d2 *>(B + (int64_t)nn * g.ldb + kt * GK + 2 * (idx % (GK / 2))) : d2{0.0, 0.0};
+      }
     }
   };
   auto sstore = [&](int buf, const d2 (&ra)[NST], const d2 (&rb)[NST]) {
 #pragma unroll
     for (int r = 0; r < NST; ++r) {
       const int idx = tid + 256 * r;
-      if (A_KMAJOR) *reinterpret_cast<d2 *>(&sA[buf][(idx >> 5) * GSK + 2 * (idx & 31)]) = ra[r];
+      if (A_KMAJOR) *reinterpret_cast<d2 *>(&sA[buf][(idx / (T / 2)) * SK + 2 * (idx % (T / 2))]) = ra[r];
       else *reinterpret_cast<d2 *>(&sA[buf][(idx / (GK / 2)) * GSM + 2 * (idx % (GK / 2))]) = ra[r];
-      if (B_KMAJOR) *reinterpret_cast<d2 *>(&sB[buf][(idx >> 5) * GSK + 2 * (idx & 31)]) = rb[r];
+      if (B_KMAJOR) *reinterpret_cast<d2 *>(&sB[buf][(idx / (T / 2)) * SK + 2 * (idx % (T / 2))]) = rb[r];
       else *reinterpret_cast<d2 *>(&sB[buf][(idx / (GK / 2)) * GSM + 2 * (idx % (GK / 2))]) = rb[r];
     }
   };
 
-  d4 acc[2][2];
+  d4 acc[TW][TW];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < TW; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int ni = 0; ni < TW; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
 
   // K range of this tile (whole k-tiles): triangular operands contribute nothing outside it
   int kt0 = 0, nk = g.K / GK;
   if (g.k_from_m) kt0 = m0 / GK;
   if (g.k_from_n && n0 / GK > kt0) kt0 = n0 / GK;
-  if (g.k_to_m && (m0 + GT) / GK < nk) nk = (m0 + GT) / GK;
+  if (g.k_to_m && (m0 + T) / GK < nk) nk = (m0 + T) / GK;
   if (nk > kt0) {
     gload(kt0, ra0, rb0);
     if (kt0 + 1 < nk) gload(kt0 + 1, ra1, rb1);
@@ -90,24 +111,27 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   // k-tile kt is in LDS buffer `buf`, k-tile kt + 1 in register stage `nxt`; stage `ld` takes k-tile kt + 2
   auto ktile = [&](int kt, int buf, d2 (&ra_ld)[NST], d2 (&rb_ld)[NST], const d2 (&ra_nxt)[NST], const d2 (&rb_nxt)[NST]) {
     if (kt + 2 < nk) gload(kt + 2, ra_ld, rb_ld);
+    if (!dead) {
 #pragma unroll
-    for (int ks = 0; ks < GK / 4; ++ks) {
-      double a[2], b[2];
+      for (int ks = 0; ks < GK / 4; ++ks) {
+        double a[TW], b[TW];
+        const int kk = ks * 4 + lk;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int m = wm * 32 + mi * 16 + lr, kk = ks * 4 + lk;
-        a[mi] = A_KMAJOR ? sA[buf][kk * GSK + m] : sA[buf][m * GSM + kk];
+        for (int mi = 0; mi < TW; ++mi) {
+          const int m = wm * (T / 2) + mi * 16 + lr;
+          a[mi] = A_KMAJOR ? sA[buf][kk * SK + m] : sA[buf][m * GSM + kk];
+        }
+#pragma unroll
+        for (int ni = 0; ni < TW; ++ni) {
+          const int n = wn * (T / 2) + ni * 16 + lr;
+          b[ni] = B_KMAJOR ? sB[buf][kk * SK + n] : sB[buf][n * GSM + kk];
+        }
+#pragma unroll
+        for (int mi = 0; mi < TW; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TW; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
       }
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int n = wn * 32 + ni * 16 + lr, kk = ks * 4 + lk;
-        b[ni] = B_KMAJOR ? sB[buf][kk * GSK + n] : sB[buf][n * GSM + kk];
-      }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
     }
     if (kt + 1 < nk) sstore(buf ^ 1, ra_nxt, rb_nxt);
     __syncthreads();
@@ -117,37 +141,32 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     ktile(kt, 0, ra0, rb0, ra1, rb1);
     if (kt + 1 < nk) ktile(kt + 1, 1, ra1, rb1, ra0, rb0);
   }
+  if (dead) return;
   // D[reg] is row (lane >> 4) + 4 * reg, column lane & 15 of each 16 x 16 tile
-  double *cp[2][2][4];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        cp[mi][ni][r] = C + (int64_t)(m0 + wm * 32 + mi * 16 + lk + 4 * r) * g.ldc + n0 + wn * 32 + ni * 16 + lr;
+  auto cptr = [&](int mi, int ni, int r) {
+    return C + (int64_t)(m0 + wm * (T / 2) + mi * 16 + lk + 4 * r) * g.ldc + n0 + wn * (T / 2) + ni * 16 + lr;
+  };
   if (g.beta == 0.0) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < TW; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < TW; ++ni)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) *cp[mi][ni][r] = g.alpha * acc[mi][ni][r];
+        for (int r = 0; r < 4; ++r) *cptr(mi, ni, r) = g.alpha * acc[mi][ni][r];
   } else {
-    // all 16 reads of C in flight together (element by element, each behind its own wait, they cost a trip each)
-    double cold[2][2][4];
+    // the reads of C of a row tile in flight together (element by element, each behind its own wait, they cost a trip each)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < TW; ++mi) {
+      double cold[TW][4];
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < TW; ++ni)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cold[mi][ni][r] = *cp[mi][ni][r];
+        for (int r = 0; r < 4; ++r) cold[ni][r] = *cptr(mi, ni, r);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+      for (int ni = 0; ni < TW; ++ni)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) *cp[mi][ni][r] = fma(g.beta, cold[mi][ni][r], g.alpha * acc[mi][ni][r]);
+        for (int r = 0; r < 4; ++r) *cptr(mi, ni, r) = fma(g.beta, cold[ni][r], g.alpha * acc[mi][ni][r]);
+    }
   }
 }
 
@@ -157,11 +176,23 @@ int launch_gemm(const GemmArgs &g, bool a_kmajor, bool b_kmajor, int batch, hipS
     return GPEMU_ERR_ARG;
   }
   if (g.M == 0 || g.N == 0) return GPEMU_OK;
-  dim3 grid((unsigned)(g.N / GT), (unsigned)(g.M / GT), (unsigned)batch), block(256);
-  if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, 0, st, g);
-  else if (a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, 0, st, g);
-  else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, 0, st, g);
-  else hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, 0, st, g);
+  // 128 x 128 tiles from this size on; 0 = never, the default: with one or two workgroups per CU (74 KiB of LDS, ~200
+  // VGPRs) the big tile hides its LDS and global latencies worse than four co-resident 64 x 64 workgroups do -- batched
+  // N = 1000: 5.2 vs 4.25 ms per 64 problems, N = 5000: 7.8 vs 6.4 ms (GPEMU_GEMM_BIG_MIN=256 to measure)
+  static const int big_min = getenv("GPEMU_GEMM_BIG_MIN") ? atoi(getenv("GPEMU_GEMM_BIG_MIN")) : 0;
+  const bool big = big_min > 0 && g.M >= big_min && g.N >= big_min;
+  const int T = big ? 128 : 64;
+  dim3 grid((unsigned)((g.N + T - 1) / T), (unsigned)((g.M + T - 1) / T), (unsigned)batch), block(256);
+#define GP_LAUNCH_GEMM(AK, BK)                                                                  \
+  do {                                                                                          \
+    if (big) hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, 4>), grid, block, 0, st, g);           \
+    else hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, 2>), grid, block, 0, st, g);               \
+  } while (0)
+  if (a_kmajor && b_kmajor) GP_LAUNCH_GEMM(true, true);
+  else if (a_kmajor && !b_kmajor) GP_LAUNCH_GEMM(true, false);
+  else if (!a_kmajor && b_kmajor) GP_LAUNCH_GEMM(false, true);
+  else GP_LAUNCH_GEMM(false, false);
+#undef GP_LAUNCH_GEMM
   GP_HIP(hipGetLastError());
   return GPEMU_OK;
 }
