@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(const double *__restrict_
 #pragma unroll
   for (int dd = 0; dd < DPAD; ++dd) {
     xl[dd] = (l < N) ? X[l * DPAD + dd] : 0.0;
-    il2[dd] = hp[dd] * hp[dd];
+    il2[dd] = 1.0 / (hp[dd] * hp[dd]);      // once per thread; a division per pair and dimension was 4/5 of this kernel
   }
   const double al = (l < N) ? alpha[l] : 0.0;
   // the summand is symmetric in (j, l): the lower triangle counts twice, Kinv is only read (and only valid) there
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(const double *__restrict_
 #pragma unroll
     for (int dd = 0; dd < DPAD; ++dd) {
       double df = X[j * DPAD + dd] - xl[dd];
-      D[dd] = (df * df) / il2[dd];             // (x - x')^2 / l^2   (skl kernels.py:1574, 1748)
+      D[dd] = (df * df) * il2[dd];             // (x - x')^2 / l^2   (skl kernels.py:1574, 1748)
       r2 += D[dd];
     }
     double f;  // dK_base/dlog l_dd = f * D[dd]
