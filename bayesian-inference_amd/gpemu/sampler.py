@@ -44,6 +44,23 @@ def _next_pow_two(n):
     return i
 
 
+def _rfft(a, n):
+    """Real-input FFT along axis 0, on all host threads where scipy's pocketfft is there."""
+    try:
+        import scipy.fft
+        return scipy.fft.rfft(a, n=n, axis=0, workers=-1)
+    except Exception:
+        return np.fft.rfft(a, n=n, axis=0)
+
+
+def _irfft(a, n):
+    try:
+        import scipy.fft
+        return scipy.fft.irfft(a, n=n, axis=0, workers=-1)
+    except Exception:
+        return np.fft.irfft(a, n=n, axis=0)
+
+
 def function_1d(x):
     """Normalised autocorrelation function of a 1-D series via FFT (emcee.autocorr.function_1d)."""
     x = np.atleast_1d(x)
@@ -65,10 +82,19 @@ def integrated_time(x, c=5, tol=50, quiet=False):
     n_t, n_w, n_d = x.shape
     tau_est = np.empty(n_d)
     windows = np.empty(n_d, dtype=int)
+    n2 = 2 * _next_pow_two(n_t)
+    chunk = max(1, min(n_w, (64 << 20) // (16 * n2)))          # walkers per batched transform (~64 MB of complex128)
     for d in range(n_d):
         f = np.zeros(n_t)
-        for k in range(n_w):
-            f += function_1d(x[:, k, d])
+        for k0 in range(0, n_w, chunk):
+            # function_1d for a block of walkers in one batched real-input FFT over all host threads (emcee transforms
+            # walker by walker with a complex FFT: the same numbers to rounding), added walker by walker in its order
+            xc = x[:, k0:k0 + chunk, d]
+            ft = _rfft(xc - np.mean(xc, axis=0), n2)
+            acf = _irfft(ft * np.conjugate(ft), n2)[:n_t]
+            acf /= acf[0]
+            for k in range(acf.shape[1]):
+                f += acf[:, k]
         f /= n_w
         taus = 2.0 * np.cumsum(f) - 1.0
         m = np.arange(len(taus)) < c * taus
