@@ -58,26 +58,30 @@ struct FrontArgs {
   double *chain_row, *lp_row;          // row of the step the accept completes, or null
   double *reset;                       // gather entries handed back to "not arrived"
   int reset_lo, reset_cnt;
+  int slow_polls;                      // long naps before an exchange is declared lost
   unsigned long long *stamps;          // diagnostic: per-workgroup time stamps (GPEMU_FRONT_STAMPS), else null
 };
 
 // Polls before an exchange is declared lost: GATHER_FAST_POLLS short naps (the normal case: the value is at most a
-// half-step away, ~0.5 ms covers it), then long naps of ~3.5 us up to about half a minute -- ranks can fall that far
-// apart when one of them is held up on the host between two runs (logging, a file write) while the others have
-// already enqueued the next run; a rank that is really gone still ends the wait, so the grid always drains.
+// half-step away, ~0.5 ms covers it), then long naps of ~3.5 us each, `slow_polls` of them (host: peer_timeout_polls(),
+// 5 s unless GPEMU_PEER_TIMEOUT_MS says otherwise).  The ranks enter every run together (the host side puts a barrier
+// in front of gpemu_sampler_run_peer), so what the wait has to absorb is the jitter of the ranks' launch streams, not a
+// host-side hold-up between runs.  A rank that is really gone ends the wait, so the grid always drains; the value
+// returned then is GATHER_LOST -- a NaN payload of its own, so that a lost exchange is not mistaken for a NaN
+// log-probability of the model.
 constexpr int GATHER_FAST_POLLS = 1 << 12;
-constexpr int GATHER_SLOW_POLLS = 1 << 23;
+constexpr unsigned long long GATHER_LOST = 0x7FF8DEADBEEF0002ull;
 
-__device__ __forceinline__ double gather_wait(const double *entry, int *flags) {
+__device__ __forceinline__ unsigned long long gather_wait_bits(const double *entry, int *flags, int slow_polls) {
   const unsigned long long *p = reinterpret_cast<const unsigned long long *>(entry);
   unsigned long long bits;
   int spins = 0;
   for (;;) {
     bits = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (bits != GATHER_EMPTY) break;
-    if (++spins > GATHER_FAST_POLLS + GATHER_SLOW_POLLS) {   // every wave reaches this exit
+    if (++spins > GATHER_FAST_POLLS + slow_polls) {          // every wave reaches this exit
       atomicAdd(flags + 1, 1);
-      bits = 0x7FF8000000000000ull;
+      bits = GATHER_LOST;
       break;
     }
     if (spins <= GATHER_FAST_POLLS) {
@@ -85,11 +89,11 @@ __device__ __forceinline__ double gather_wait(const double *entry, int *flags) {
     } else {
       // once an exchange has been declared lost (by any wave, in this or an earlier launch of the run) nobody waits long
       if ((spins & 255) == 0 && __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-        spins = GATHER_FAST_POLLS + GATHER_SLOW_POLLS;
+        spins = GATHER_FAST_POLLS + slow_polls;
       __builtin_amdgcn_s_sleep(127);
     }
   }
-  return __longlong_as_double((long long)bits);
+  return bits;
 }
 
 // One-off check of the exchange path before a chain depends on it: every rank stores a token (1000 + its rank) into
@@ -120,7 +124,7 @@ __global__ void peer_selftest_kernel(double *const *peers, double *mine, int wor
 // Position (and log-probability) of walker x AFTER the previous half's accept / reject (emcee moves/red_blue.py):
 // unchanged unless x proposed in that half and its proposal was accepted.
 __device__ __forceinline__ void state_after_prev(const FrontArgs &fa, int x, double (&px)[DPAD], double &lp, bool &acc,
-                                                 double &nlp, bool &in_prev) {
+                                                 double &nlp, bool &in_prev, bool *lost = nullptr) {
   in_prev = fa.have_prev && fa.inds_prev[x] == fa.hp;
   double z = 1.0;
   int pj = x;
@@ -132,7 +136,9 @@ __device__ __forceinline__ void state_after_prev(const FrontArgs &fa, int x, dou
     pj = fa.partner_prev[i];
     z = fa.zz_prev[i];
     const double fc = fa.fac_prev[i], lu = fa.logu_prev[i];
-    nlp = gather_wait(fa.gath + i, fa.flags);
+    const unsigned long long bits = gather_wait_bits(fa.gath + i, fa.flags, fa.slow_polls);
+    if (lost) *lost = bits == GATHER_LOST;
+    nlp = __longlong_as_double((long long)bits);
     acc = (fc + nlp - oldlp) > lu;
   }
 #pragma unroll
@@ -204,12 +210,12 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs fa) {
     const int x = (g - fa.nks) * 256 + threadIdx.x;
     if (x < fa.W) {
       double px[DPAD], lp, nlp;
-      bool acc, in_prev;
-      state_after_prev(fa, x, px, lp, acc, nlp, in_prev);
+      bool acc, in_prev, lost = false;
+      state_after_prev(fa, x, px, lp, acc, nlp, in_prev, &lost);
 #pragma unroll
       for (int dd = 0; dd < DPAD; ++dd) fa.Xnext[(int64_t)x * DPAD + dd] = px[dd];
       fa.lpnext[x] = lp;
-      if (in_prev && nlp != nlp) atomicAdd(fa.flags, 1);       // emcee raises on a NaN log-probability
+      if (in_prev && nlp != nlp && !lost) atomicAdd(fa.flags, 1);   // emcee raises on a NaN log-probability
       if (acc) fa.naccept[x] += 1;
       if (fa.chain_row) {
         for (int dd = 0; dd < fa.d; ++dd) fa.chain_row[(int64_t)x * fa.d + dd] = px[dd];
@@ -381,6 +387,14 @@ void front_release(gpemu_sampler *s) {
   s->peer_world = 0;
 }
 
+// Long naps (~3.5 us each: s_sleep 127 = 8128 cycles) a waiter spends before it declares an exchange lost.
+static int peer_timeout_polls() {        // read per launch: a getenv, nothing next to a kernel launch
+  double ms = 5000.0;
+  if (const char *e = getenv("GPEMU_PEER_TIMEOUT_MS")) ms = atof(e);
+  ms = std::min(std::max(ms, 1.0), 60000.0);
+  return (int)(ms * 1000.0 / 3.5);
+}
+
 bool front_eligible(const gpemu_sampler *s) {
   static const bool off = getenv("GPEMU_NO_FUSED") != nullptr;
   if (off || s->groups.size() != 1 || s->nchains != 1) return false;
@@ -466,6 +480,7 @@ static int launch_front(gpemu_sampler *s, const Pending &pv, bool have_next, int
   fa.Xnext = s->Xbuf + (size_t)(s->cur ^ 1) * W * DPAD;
   fa.lpnext = s->lpbuf + (size_t)(s->cur ^ 1) * W;
   fa.naccept = s->naccept; fa.flags = s->flags;
+  fa.slow_polls = peer_timeout_polls();
   if (store_row >= 0) {
     fa.chain_row = s->chain + (size_t)store_row * W * s->d;
     fa.lp_row = s->lpchain + (size_t)store_row * W;
@@ -598,16 +613,18 @@ int front_run(gpemu_sampler *s, int64_t steps, int store_chain, int world, int r
     hipLaunchKernelGGL(gather_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->gather, n,
                        GATHER_EMPTY);
   }
-  rc = sampler_check_nan(s);
-  if (rc != GPEMU_OK) return rc;
-  int lost = 0;
-  GP_HIP(hipMemcpy(&lost, s->flags + 1, sizeof(int), hipMemcpyDeviceToHost));
-  if (lost) {
-    (void)hipMemset(s->flags + 1, 0, sizeof(int));
-    set_error("fused run: %d log-probability exchanges timed out (a rank did not deliver its share)", lost);
+  // a lost exchange first: its walkers carry the GATHER_LOST payload, which must not be reported as a NaN of the model,
+  // and its flag must not outlive this run (every later wait would give up after the fast polls)
+  int fl[2] = {0, 0};
+  GP_HIP(hipMemcpyAsync(fl, s->flags, sizeof(fl), hipMemcpyDeviceToHost, st));
+  GP_HIP(hipStreamSynchronize(st));
+  if (fl[1]) {
+    (void)hipMemsetAsync(s->flags, 0, sizeof(fl), st);
+    (void)hipStreamSynchronize(st);
+    set_error("fused run: %d log-probability exchanges timed out (a rank did not deliver its share)", fl[1]);
     return GPEMU_ERR_STATE;
   }
-  return GPEMU_OK;
+  return sampler_check_nan(s);
 }
 
 }  // namespace gpemu

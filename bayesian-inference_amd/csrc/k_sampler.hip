@@ -683,6 +683,8 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;      // optional
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;   // optional
 };
 static RcclApi g_rccl;
 
@@ -698,6 +700,8 @@ static int load_rccl(const char *path) {
   *(void **)&api.CommDestroy = dlsym(lib, "ncclCommDestroy");
   *(void **)&api.AllGather = dlsym(lib, "ncclAllGather");
   *(void **)&api.GetErrorString = dlsym(lib, "ncclGetErrorString");
+  *(void **)&api.CommCount = dlsym(lib, "ncclCommCount");
+  *(void **)&api.CommUserRank = dlsym(lib, "ncclCommUserRank");
   if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GetErrorString) {
     set_error("%s does not export the RCCL entry points", name);
     dlclose(lib);
@@ -760,8 +764,12 @@ int gpemu_comm_destroy(gpemu_comm *c) {
 
 int gpemu_comm_dims(const gpemu_comm *c, int *rank, int *world) {
   GP_ARG(c, "comm");
-  if (rank) *rank = c->rank;
-  if (world) *world = c->world;
+  // what the communicator itself reports (ncclCommCount / ncclCommUserRank), not what it was asked to be
+  int r = c->rank, w = c->world;
+  if (c->comm && g_rccl.CommCount) GP_RCCL(g_rccl.CommCount(c->comm, &w));
+  if (c->comm && g_rccl.CommUserRank) GP_RCCL(g_rccl.CommUserRank(c->comm, &r));
+  if (rank) *rank = r;
+  if (world) *world = w;
   return GPEMU_OK;
 }
 

@@ -140,6 +140,10 @@ def check(code):
         raise GpemuError(code, lib().gpemu_last_error().decode("utf-8", "replace"))
 
 
+def last_error() -> str:
+    return lib().gpemu_last_error().decode("utf-8", "replace")
+
+
 def device_count() -> int:
     return int(lib().gpemu_device_count())
 

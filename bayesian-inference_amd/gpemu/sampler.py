@@ -138,6 +138,8 @@ class DeviceSampler:
         self.W, self.d = int(n_walkers) * self.n_chains, self.models[0].d
         self.ns = ((self.W + 1) // 2, self.W // 2)
         self.device = self.models[0].device
+        self.last_transport = None       # what the last run_sharded call really took: "peer" / "rccl" / "torch" / "single"
+        self.transport_info = {}         # self-test results, communicator sizes, fall-back reasons
 
     def close(self):
         for h in self.__dict__.pop("_comms", {}).values():
@@ -232,6 +234,7 @@ class DeviceSampler:
 
         def give_up(reason):
             warnings.warn(f"library-owned RCCL communicator unavailable ({reason}); using torch.distributed's all-gather")
+            self.transport_info["rccl_fallback_reason"] = str(reason)
             comms[key] = None
             return None
 
@@ -278,6 +281,9 @@ class DeviceSampler:
             err, good = e, False
         if vote(good):
             comms[key] = comm
+            r_seen, w_seen = C.c_int(-1), C.c_int(-1)
+            L.gpemu_comm_dims(comm, C.byref(r_seen), C.byref(w_seen))
+            self.transport_info["rccl_ranks_seen"] = int(w_seen.value)      # ncclCommCount of the new communicator
             return comm
         if comm is not None:
             L.gpemu_comm_destroy(comm)
@@ -298,8 +304,9 @@ class DeviceSampler:
         where = torch.device("cuda", self.device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
         mine = (C.c_char * 64)()
         ok = 1
+        stage = "ok"
         if L.gpemu_sampler_peer_export(self._h, C.cast(mine, C.c_void_p)) != 0:
-            ok = 0
+            ok, stage = 0, "export: " + _lib.last_error()
         t = torch.tensor(list(mine.raw), dtype=torch.uint8, device=where)
         everyone = torch.zeros(64 * world, dtype=torch.uint8, device=where)
         dist.all_gather_into_tensor(everyone, t, group=group)
@@ -307,16 +314,21 @@ class DeviceSampler:
             raw = bytes(everyone.cpu().tolist())
             buf = C.create_string_buffer(raw, 64 * world)
             if L.gpemu_sampler_peer_import(self._h, int(world), int(rank), C.cast(buf, C.c_void_p)) != 0:
-                ok = 0
+                ok, stage = 0, "import: " + _lib.last_error()
         # the data path itself, before a chain depends on it: every rank stores a token into every rank's buffer and
         # waits (bounded) for all tokens in its own -- a mapping that opens but does not carry stores (or carries them
         # too late) makes the ranks fall back to the collective transports together instead of losing an exchange
         dist.barrier(group=group)
         if ok and L.gpemu_sampler_peer_selftest(self._h) != 0:
-            ok = 0
-        vote = torch.tensor([ok], dtype=torch.int32, device=where)
-        dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=group)
-        cache[key] = bool(int(vote.item()))
+            ok, stage = 0, "selftest: " + _lib.last_error()
+        # every rank's result, for the record (bench.py prints it), and the vote
+        mine_ok = torch.tensor([ok], dtype=torch.int32, device=where)
+        all_ok = torch.zeros(world, dtype=torch.int32, device=where)
+        dist.all_gather_into_tensor(all_ok, mine_ok, group=group)
+        per_rank = [int(v) for v in all_ok.cpu().tolist()]
+        cache[key] = all(v == 1 for v in per_rank)
+        self.transport_info.update(peer_selftest_per_rank=per_rank, peer_ranks_seen=sum(per_rank),
+                                   peer_local_stage=stage, peer_vote=cache[key])
         return cache[key]
 
     def run_sharded(self, steps, store=True, group=None, force=False, emulate_world=None, transport=None):
@@ -334,19 +346,26 @@ class DeviceSampler:
         import torch.distributed as dist
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         if world == 1 and not force:
+            self.last_transport = "single"
             return self.run(steps, store)
         L = _lib.lib()
         dev = torch.device("cuda", self.device)
         on_device = dist.get_backend(group) == "nccl"
         transport = transport or os.environ.get("GPEMU_SHARDED_TRANSPORT", "peer")
+        self.transport_info["requested"] = transport
         if transport == "peer" and not emulate_world:
             if world > 1 and self._peer_ready(group):
+                # the ranks enter every fused run together: all launches of the previous run (their gather-slot
+                # hand-backs included) have completed everywhere before anyone stores into a peer's buffer again
+                dist.barrier(group=group)
+                self.last_transport = "peer"
                 rc = L.gpemu_sampler_run_peer(self._h, int(steps), int(bool(store)))
                 if rc == 1:
                     raise ValueError("Probability function returned NaN")
                 check(rc)
                 return None
             transport = "rccl"
+            self.transport_info["fallback_from_peer"] = True
         elif transport == "peer":
             transport = "rccl"          # the emulation switch lives in gpemu_sampler_run_sharded
         if on_device and transport == "rccl":
@@ -354,11 +373,13 @@ class DeviceSampler:
             if comm is None:
                 transport = "torch"
         if on_device and transport == "rccl":
+            self.last_transport = "rccl"
             rc = L.gpemu_sampler_run_sharded(self._h, comm, int(steps), int(bool(store)), int(emulate_world or 0))
             if rc == 1:
                 raise ValueError("Probability function returned NaN")
             check(rc)
             return None
+        self.last_transport = "torch"
         # a dedicated (non-null) torch stream carries the library's launches AND the collectives, so
         # they are ordered by the stream; torch's default stream has handle 0, which the C ABI reads
         # as "use the handle's own stream"

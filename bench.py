@@ -6,11 +6,13 @@ Workload (BASELINE.json configs[2], "C3"): N_design = 1000, N_obs = 500, 10 PCs,
 stretch-move step = 2 half-ensemble updates = 1024 log-posterior evaluations.  Model state and the
 ensemble are resident in HBM before the timed region; the chain is kept on the device.
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python bench.py [--gpus N --steps K --warmup W]        (N > 1: starts its N ranks itself, as child processes)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1, launcher environment)
 
 With N > 1 the SAME 1024 walkers are sharded over the ranks (strong scaling): each rank evaluates
-its block of every half's proposals and the new log-probabilities are all-gathered with RCCL.
+its block of every half's proposals and the new log-probabilities are exchanged -- timed once with one RCCL
+all-gather per half-step and once with peer stores over xGMI (`transports`); `value` is the faster of the two,
+`transport` names it, `ranks_seen` / `peer_selftest_per_rank` / `fallback_vote` say what the ranks really did.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (trmm_vsq_kernel, the fp64
 triangular GEMM): algorithmic FLOPs per launch (k * N^2 per evaluation, SURVEY 8d, x evaluations per
@@ -188,30 +190,81 @@ def committed_traffic(world):
     return None
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """Reference-form per-walker log_posterior (oracle port, incl. the per-call recomputation of the
-    truncation covariance) over a spawn Pool, one walker per task (ref: mcmc.py:77-85)."""
+def host_description():
+    """What the CPU baseline ran on (core count, CPU model, BLAS vendor / threads, library versions)."""
+    import numpy
+    import scipy
+    info = {"os_cpu_count": os.cpu_count(), "numpy": numpy.__version__, "scipy": scipy.__version__}
+    try:
+        info["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:        # cgroup v2 CPU quota of the container, if any ("max 100000" = none)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        info["cgroup_cpu_quota"] = None if quota == "max" else float(quota) / float(period)
+    except Exception:
+        pass
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                info["cpu_model"] = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    try:
+        from threadpoolctl import threadpool_info
+        info["blas"] = [{k: lib.get(k) for k in ("internal_api", "version", "num_threads", "threading_layer")}
+                        for lib in threadpool_info() if lib.get("user_api") == "blas"]
+    except Exception:
+        pass
+    return info
+
+
+def cpu_baseline(seconds_budget=24.0):
+    """The reference's CPU path beside the GPU number: the oracle's reference-form per-walker
+    log_posterior (kind "port"), one walker per task (ref: mcmc.py:77-85), BLAS threads = 1 per process.
+      value                   spawn pool of all usable cores, truncation covariance recomputed in every call (what the
+                              reference does: ref: emulation.py:214-224 returns None, so :445-448 recomputes it)
+      precomputed_cov         the same pool with the truncation covariance computed once
+      single_process          run A: one process, per-core rate, both variants"""
     import multiprocessing as mp
-    ncores = min(os.cpu_count() or 1, 16)
+    host = host_description()
+    usable = [host.get("os_cpu_count") or 1, host.get("affinity_cpus") or 10 ** 9]
+    if host.get("cgroup_cpu_quota"):
+        usable.append(max(1, int(host["cgroup_cpu_quota"])))
+    ncores = max(1, min(usable))
     ctx = mp.get_context("spawn")
-    per_worker = 2
+
+    def timed(pool, fn, nproc, budget):
+        n = nproc * 2
+        t0 = time.time()
+        pool.map(fn, range(n), chunksize=1)
+        dt = time.time() - t0
+        n = int(max(n, min(20000, n * budget / max(dt, 1e-3))))
+        t0 = time.time()
+        pool.map(fn, range(n), chunksize=max(1, min(4, n // (4 * nproc))))
+        dt = time.time() - t0
+        return n / dt, n
+
     t_setup = time.time()
     with ctx.Pool(ncores, initializer=_cpu_init) as pool:
         pool.map(_cpu_eval, range(ncores))                      # warm-up: builds the model per worker
         t_setup = time.time() - t_setup
-        n = ncores * per_worker
-        t0 = time.time()
-        pool.map(_cpu_eval, range(n), chunksize=1)
-        dt = time.time() - t0
-        # size the timed sample for ~seconds_budget/2 of wall time (>= 10 s of CPU work on >= 2 cores)
-        n = int(max(n, min(20000, n * (seconds_budget / 2) / max(dt, 1e-3))))
-        t0 = time.time()
-        pool.map(_cpu_eval, range(n), chunksize=4)
-        dt = time.time() - t0
-    return {"value": n / dt, "unit": "log-posterior evals/s", "cores": ncores, "kind": "port",
+        rate, n = timed(pool, _cpu_eval, ncores, seconds_budget * 0.35)
+        rate_pre, n_pre = timed(pool, _cpu_eval_pre, ncores, seconds_budget * 0.25)
+    with ctx.Pool(1, initializer=_cpu_init) as pool:
+        pool.map(_cpu_eval, range(1))
+        rate1, n1 = timed(pool, _cpu_eval, 1, seconds_budget * 0.2)
+        rate1_pre, n1_pre = timed(pool, _cpu_eval_pre, 1, seconds_budget * 0.2)
+    return {"value": rate, "unit": "log-posterior evals/s", "cores": ncores, "kind": "port",
             "sample": f"{n} per-walker reference-form evaluations of the C3 workload over a "
-                      f"{ncores}-process spawn pool, BLAS threads = 1 per process "
-                      f"(per-process model build {t_setup:.1f} s not timed)"}
+                      f"{ncores}-process spawn pool, BLAS threads = 1 per process, truncation covariance recomputed in "
+                      f"every call as the reference does (per-process model build {t_setup:.1f} s not timed)",
+            "precomputed_cov": {"value": rate_pre, "sample": f"{n_pre} evaluations, same pool, truncation covariance "
+                                                             "computed once"},
+            "single_process": {"value": rate1, "precomputed_cov_value": rate1_pre, "cores": 1,
+                               "sample": f"{n1} / {n1_pre} evaluations in one process, BLAS threads = 1"},
+            "host": host}
 
 
 _CPU = {}
@@ -228,15 +281,49 @@ def _cpu_init():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import golden_util as GU
     from gpemu import synthetic
+    from oracle import gp_oracle as O
     model, prob, _ = GU.fixed_theta_model(N_DESIGN, N_OBS, N_PC, seed=0)
-    _CPU.update(model=model, prob=prob, X=synthetic.make_walkers(N_WALKERS, seed=1))
+    _CPU.update(model=model, prob=prob, X=synthetic.make_walkers(N_WALKERS, seed=1),
+                cun={"g": O.cov_unexplained(model)})
 
 
-def _cpu_eval(i):
+def _cpu_eval(i, cun=None):
     from oracle import gp_oracle as O
     p = _CPU["prob"]
     x = _CPU["X"][i % N_WALKERS]
-    return float(O.log_posterior(x, {"g": _CPU["model"]}, p["lo"], p["hi"], p["y_exp"], p["y_err"])[0])
+    return float(O.log_posterior(x, {"g": _CPU["model"]}, p["lo"], p["hi"], p["y_exp"], p["y_err"],
+                                 cov_unexpl=cun)[0])
+
+
+def _cpu_eval_pre(i):
+    return _cpu_eval(i, _CPU["cun"])
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher environment: start the N ranks as fresh child processes
+    (torch.distributed.run, one per GPU) BEFORE this process touches a GPU, let them print (rank 0: the JSON line)
+    and return their exit code.  Nothing is re-executed in a process that has initialised HIP."""
+    import socket
+    import subprocess
+    rehearsal = bool(os.environ.get("GPEMU_BENCH_REHEARSAL_WALKERS"))
+    try:
+        import torch
+        ndev = torch.cuda.device_count()          # does not initialise the runtime on this image
+    except Exception:
+        ndev = None
+    if ndev is not None and ndev < args.gpus and not rehearsal:
+        print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the peer transport shares device memory across processes (dmabuf IPC)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -246,10 +333,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fit", action="store_true", help="skip the fit-side legs (fit_c5, fit_c3)")
+    ap.add_argument("--transport", default="both", choices=["both", "peer", "rccl", "torch"],
+                    help="N > 1: how the new log-probabilities are exchanged; 'both' times the RCCL all-gather run and "
+                         "the peer-store run in one invocation and reports the faster as `value`")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: also time 1024 x N walkers (weak scaling), reported under `weak_scaling`")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: time ONE rank's share of an N-GPU step on this GPU (world-1 RCCL gather); "
                          "the printed value is NOT a throughput claim")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate_world:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -257,8 +352,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     if world > 1 or args.emulate_world:
@@ -283,16 +377,6 @@ def main():
                      components=wl["components"], scaler_mean=wl["mean"], scaler_scale=wl["scale"],
                      kernel_kind=0, noise=wl["noise"], cov_unexplained=wl["cun"], device=dev_index)
     dm.likelihood_setup(prob["y_exp"], prob["y_err"], prob["lo"], prob["hi"], 1.0)
-    ds = DeviceSampler([dm], N_WALKERS, a=2.0, seed=1)
-    ds.set_state(synthetic.make_walkers(N_WALKERS, seed=1))
-
-    def run(steps, store=True):
-        if args.emulate_world:
-            ds.run_sharded(steps, store=store, force=True, emulate_world=args.emulate_world)
-        elif world > 1:
-            ds.run_sharded(steps, store=store)
-        else:
-            ds.run(steps, store=store)
 
     def barrier():
         if world > 1:
@@ -300,32 +384,85 @@ def main():
         torch.cuda.synchronize()
         dm.sync()
 
-    ds.reserve(args.warmup + 2 * args.steps)      # chain storage for the warm-up, timed and profiled passes
-    # Untimed pre-warm before the W warm-up steps: the clocks of an idle MI355X take tens of ms of load to
-    # ramp; with a short W the ramp otherwise lands inside the timed region (seen as a bimodal ms_per_step).
-    # Every rank must make the same number of passes (a sharded pass is a collective): rank 0's clock decides.
-    t_pre = time.perf_counter()
-    while True:
-        run(100, store=False)
+    def all_ok(ok):
+        """True on every rank only if every rank succeeded (the ranks take the same branch afterwards)."""
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def timed_pass(ds, n_walkers, transport):
+        """Pre-warm, W warm-up steps, then EXACTLY K timed steps between barrier + synchronize; max over ranks."""
+        def run(steps, store=True):
+            if args.emulate_world:
+                ds.run_sharded(steps, store=store, force=True, emulate_world=args.emulate_world)
+            elif world > 1:
+                ds.run_sharded(steps, store=store, transport=transport)
+            else:
+                ds.run(steps, store=store)
+        # Untimed pre-warm before the W warm-up steps: the clocks of an idle MI355X take tens of ms of load to
+        # ramp; with a short W the ramp otherwise lands inside the timed region (seen as a bimodal ms_per_step).
+        # Every rank must make the same number of passes (a sharded pass is a collective): rank 0's clock decides.
+        t_pre = time.perf_counter()
+        while True:
+            run(100, store=False)
+            barrier()
+            go = time.perf_counter() - t_pre < 0.3
+            if world > 1:
+                flag = torch.tensor([1 if go else 0], dtype=torch.int32, device=coll_dev)
+                dist.broadcast(flag, src=0)
+                go = bool(int(flag.item()))
+            if not go:
+                break
+        run(args.warmup)
         barrier()
-        go = time.perf_counter() - t_pre < 0.3
+        t0 = time.perf_counter()
+        run(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
         if world > 1:
-            flag = torch.tensor([1 if go else 0], dtype=torch.int32, device=coll_dev)
-            dist.broadcast(flag, src=0)
-            go = bool(int(flag.item()))
-        if not go:
-            break
-    run(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    evals = N_WALKERS * args.steps
+            tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return {"ms_per_step": dt / args.steps * 1e3, "value": n_walkers * args.steps / dt, "seconds": dt,
+                "transport_taken": ds.last_transport or "single", "run": run}
+
+    def measure(n_walkers, seed):
+        """One ensemble of `n_walkers`, every requested transport timed on it.  Returns (sampler, results, best)."""
+        X0 = synthetic.make_walkers(n_walkers, seed=seed)
+        ds = DeviceSampler([dm], n_walkers, a=2.0, seed=1)
+        ds.set_state(X0)
+        if world == 1 or args.emulate_world:
+            wanted = ["single"]
+        else:
+            wanted = ["rccl", "peer"] if args.transport == "both" else [args.transport]
+        ds.reserve((args.warmup + args.steps) * len(wanted) + args.steps)   # no hipMalloc inside a timed region
+        results = {}
+        for t in wanted:
+            err = None
+            try:
+                res = timed_pass(ds, n_walkers, None if t == "single" else t)
+            except Exception as e:              # e.g. a lost peer exchange (GPEMU_ERR_STATE on every rank)
+                err, res = repr(e), None
+            if all_ok(err is None):
+                results[t] = res
+            else:
+                results[t] = {"error": err or "another rank failed"}
+                torch.cuda.synchronize()
+                ds.set_state(X0)                # the ensemble of a failed pass is not a valid state
+        ok = {t: r for t, r in results.items() if "error" not in r}
+        best = min(ok, key=lambda t: ok[t]["ms_per_step"]) if ok else None
+        return ds, results, best
+
+    ds, results, best = measure(N_WALKERS, seed=1)
+    if best is None:
+        if rank == 0:
+            print(json.dumps({"metric": "log-posterior evals/sec", "value": None, "n_gpus": world,
+                              "error": {t: r.get("error") for t, r in results.items()}}), flush=True)
+        raise SystemExit(1)
+    headline = results[best]
+    run = headline["run"]
 
     # second pass of the same K steps with HIP events around every launch of the hot kernels
     dm.profile(True)
@@ -347,6 +484,22 @@ def main():
                     "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": committed_traffic(split),
                     "avg_launch_us": avg_s * 1e6, "launches": n_launch,
                     "kstar_avg_launch_us": prof["kstar"][0] / max(prof["kstar"][1], 1) * 1e3}
+    nacc, iters, _ = ds.counts()
+    tinfo = dict(ds.transport_info)
+
+    weak = None
+    if args.weak and world > 1:
+        # weak scaling, clearly NOT the headline: 1024 walkers per GPU (per-rank work as on one GPU)
+        try:
+            dsw, wres, wbest = measure(N_WALKERS * world, seed=5)
+            weak = {"label": "weak scaling: 1024 walkers per GPU; NOT the headline value",
+                    "n_walkers": N_WALKERS * world, "transport": wbest,
+                    "value": wres[wbest]["value"] if wbest else None,
+                    "ms_per_step": wres[wbest]["ms_per_step"] if wbest else None,
+                    "transports": {t: {k: v for k, v in r.items() if k != "run"} for t, r in wres.items()}}
+            dsw.close()
+        except Exception as e:
+            weak = {"error": repr(e)}
 
     predict = None
     if rank == 0:
@@ -371,19 +524,34 @@ def main():
         except Exception as e:  # the baseline is a reported figure; never lose the GPU line over it
             cpu = {"value": None, "error": repr(e)}
 
-    nacc, iters, _ = ds.counts()
     if rank == 0:
-        out = {"metric": "log-posterior evals/sec", "value": evals / dt, "unit": "evals/s",
+        rehearsal = bool(os.environ.get("GPEMU_BENCH_REHEARSAL_WALKERS"))
+        workload = (f"C3: N_design={N_DESIGN} x N_obs={N_OBS}, {N_PC} PCs, d=6, {N_WALKERS}-walker "
+                    "stretch-move MCMC, RBF+White fixed theta")
+        if rehearsal:
+            workload = "REHEARSAL (not the headline ensemble): " + workload
+        ranks_seen = {"torch_distributed": world}
+        if "rccl_ranks_seen" in tinfo:
+            ranks_seen["rccl_communicator"] = tinfo["rccl_ranks_seen"]
+        if "peer_ranks_seen" in tinfo:
+            ranks_seen["peer_selftest"] = tinfo["peer_ranks_seen"]
+        out = {"metric": "log-posterior evals/sec", "value": headline["value"], "unit": "evals/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "ms_per_step": headline["ms_per_step"], "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "emulate_world": args.emulate_world or None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "C3: N_design=1000 x N_obs=500, 10 PCs, d=6, 1024-walker "
-                                      "stretch-move MCMC, RBF+White fixed theta",
+               "config": {"workload": workload,
                           "n_walkers": N_WALKERS, "evals_per_step": N_WALKERS,
                           "parallelism": f"walkers sharded over {world} GPU(s)"},
+               "transport": headline["transport_taken"],
+               "transports": {t: {k: v for k, v in r.items() if k != "run"} for t, r in results.items()},
+               "ranks_seen": ranks_seen,
+               "peer_selftest_per_rank": tinfo.get("peer_selftest_per_rank"),
+               "fallback_vote": {"peer_to_collective": bool(tinfo.get("fallback_from_peer", False)),
+                                 "rccl_to_torch": tinfo.get("rccl_fallback_reason")},
                "acceptance_fraction_mean": float((nacc / max(iters, 1)).mean()),
-               "roofline": roofline, "cpu_baseline": cpu, "gp_predict": predict, "fit_c5": fit_c5, "fit_c3": fit_c3}
-        if os.environ.get("GPEMU_BENCH_REHEARSAL_WALKERS"):
+               "roofline": roofline, "cpu_baseline": cpu, "gp_predict": predict, "fit_c5": fit_c5, "fit_c3": fit_c3,
+               "weak_scaling": weak}
+        if rehearsal:
             out["rehearsal"] = True
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -302,9 +302,11 @@ def loglik_exact(y, cov):
     return -.5 * np.dot(y, alpha) - np.log(L.diagonal()).sum()
 
 
-def log_posterior(X, models: dict, lo, hi, y_exp, y_err, mapping=None):
+def log_posterior(X, models: dict, lo, hi, y_exp, y_err, mapping=None, cov_unexpl=None):
     """ref: log_posterior.py:42-101.  ``models``: {group: GroupModel}; mapping as in merge_groups
-    (None for a single group).  n_samples = number of in-bounds rows (the /n_samples quirk)."""
+    (None for a single group).  n_samples = number of in-bounds rows (the /n_samples quirk).
+    ``cov_unexpl``: {group: F_g x F_g} computed once by the caller; None recomputes the truncation covariance in
+    every call, which is what the reference does (its wrapper ref: emulation.py:214-224 returns None)."""
     X = np.array(X, ndmin=2, dtype=np.float64)
     out = np.zeros(X.shape[0])
     inside = np.all((X > lo) & (X < hi), axis=1)
@@ -312,7 +314,8 @@ def log_posterior(X, models: dict, lo, hi, y_exp, y_err, mapping=None):
     n = np.count_nonzero(inside)
     F = y_exp.shape[0]
     if n > 0:
-        go = {g: predict_group(X[inside], mdl) for g, mdl in models.items()}
+        go = {g: predict_group(X[inside], mdl, None if cov_unexpl is None else cov_unexpl[g])
+              for g, mdl in models.items()}
         pred = next(iter(go.values())) if mapping is None else merge_groups(go, mapping, F)
         dY = pred["central_value"] - y_exp
         cov = np.zeros((n, F, F))

@@ -354,10 +354,11 @@ def test_stacked_chains_equal_separate_chains(W):
 
 
 def test_bench_two_rank_rehearsal(tmp_path):
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed with
-    both ranks on the one GPU of the box over gloo (RCCL refuses two ranks on a device): the N > 1 code path of the
-    bench -- rank-agreed warm-up passes, sharded run through the peer transport, max-over-ranks timing, one JSON line
-    from rank 0."""
+    """Plain `python bench.py --gpus 2` with NO launcher environment (the form the driver used for --gpus 1): bench.py
+    starts its two ranks itself as child processes.  Rehearsed with both ranks on the one GPU of the box over gloo
+    (RCCL refuses two ranks on a device): rank-agreed warm-up passes, the collective run and the peer-store run timed in
+    one invocation, max-over-ranks timing, one JSON line from rank 0 that says which transport ran and how many ranks
+    it saw."""
     import json
     import os
     import subprocess
@@ -368,9 +369,7 @@ def test_bench_two_rank_rehearsal(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPEMU_DIST_BACKEND="gloo", GPEMU_BENCH_REHEARSAL_WALKERS="64")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    port = 29500 + (os.getpid() % 400)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
            "--no-cpu-baseline", "--no-fit"]
     done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-3000:]
@@ -379,7 +378,96 @@ def test_bench_two_rank_rehearsal(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 30 and out["value"] > 0 and out["scaling"] == "strong"
     assert out["rehearsal"] is True and out["config"]["n_walkers"] == 64
+    assert out["config"]["workload"].startswith("REHEARSAL") and "64-walker" in out["config"]["workload"]
     assert 0.1 < out["acceptance_fraction_mean"] < 0.9
+    # both transports were timed; over gloo the collective one is torch.distributed's all-gather
+    tr = out["transports"]
+    assert set(tr) == {"rccl", "peer"} and all("error" not in r for r in tr.values()), tr
+    assert tr["peer"]["transport_taken"] == "peer" and tr["rccl"]["transport_taken"] == "torch"
+    assert out["transport"] in ("peer", "torch")
+    assert out["value"] == max(r["value"] for r in tr.values())
+    assert out["ranks_seen"]["torch_distributed"] == 2 and out["ranks_seen"]["peer_selftest"] == 2
+    assert out["peer_selftest_per_rank"] == [1, 1]
+    assert out["fallback_vote"]["peer_to_collective"] is False
+
+
+def _absent_peer(out_dir):
+    """A rank that maps its exchange buffer and then never runs."""
+    import ctypes as C
+    import os
+    import time
+    from gpemu import _lib
+    from gpemu.sampler import DeviceSampler
+    g, model, dm, _ = _setup()
+    ds = DeviceSampler([dm], 24, seed=7)
+    h = (C.c_char * 64)()
+    _lib.check(_lib.lib().gpemu_sampler_peer_export(ds._h, C.cast(h, C.c_void_p)))
+    with open(os.path.join(out_dir, "handle.tmp"), "wb") as f:
+        f.write(h.raw)
+    os.rename(os.path.join(out_dir, "handle.tmp"), os.path.join(out_dir, "handle.bin"))
+    t0 = time.time()
+    while not os.path.exists(os.path.join(out_dir, "done")) and time.time() - t0 < 120:
+        time.sleep(0.05)
+    ds.close(); dm.close()
+
+
+def test_lost_peer_exchange_ends_in_bounded_time(tmp_path, monkeypatch):
+    """The bound on the in-kernel wait for a peer's log-probabilities, with a deliberately absent peer: rank 0 of a
+    two-rank "world" whose rank 1 exported its buffer and never runs.  The run must come back with GPEMU_ERR_STATE
+    (not a model NaN, not a hang) within the configured time-out, the lost-exchange flag must not outlive the run
+    (it used to make every later wait give up), and the sampler must still work afterwards."""
+    import ctypes as C
+    import os
+    import time
+    import torch.multiprocessing as mp
+    from gpemu import _lib, synthetic
+    from gpemu.sampler import DeviceSampler
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    monkeypatch.setenv("GPEMU_PEER_TIMEOUT_MS", "300")
+    ctx = mp.get_context("spawn")
+    child = ctx.Process(target=_absent_peer, args=(str(tmp_path),))
+    child.start()
+    try:
+        t0 = time.time()
+        while not (tmp_path / "handle.bin").exists():
+            assert time.time() - t0 < 110 and child.is_alive(), "the absent peer never exported its buffer"
+            time.sleep(0.05)
+        theirs = (tmp_path / "handle.bin").read_bytes()
+        g, model, dm, _ = _setup()
+        L = _lib.lib()
+        W = 24
+        X0 = synthetic.make_walkers(W, seed=3, lo=g["lo"], hi=g["hi"])
+        ds = DeviceSampler([dm], W, seed=7)
+        ds.set_state(X0)
+        mine = (C.c_char * 64)()
+        _lib.check(L.gpemu_sampler_peer_export(ds._h, C.cast(mine, C.c_void_p)))
+        both = C.create_string_buffer(mine.raw + theirs, 128)
+        _lib.check(L.gpemu_sampler_peer_import(ds._h, 2, 0, C.cast(both, C.c_void_p)))
+        for attempt in range(2):                      # the second run waits the full bound again: the flag was cleared
+            t0 = time.time()
+            rc = L.gpemu_sampler_run_peer(ds._h, 3, 1)
+            dt = time.time() - t0
+            assert rc == -4, (rc, _lib.last_error())          # GPEMU_ERR_STATE
+            assert "timed out" in _lib.last_error()
+            assert 0.25 < dt < 10.0, dt
+            ds.set_state(X0)
+        # alone again (world 1), the same sampler produces the single-GPU chain
+        ds.reset()
+        _lib.check(L.gpemu_sampler_peer_import(ds._h, 1, 0, C.cast(mine, C.c_void_p)))
+        _lib.check(L.gpemu_sampler_run_peer(ds._h, 5, 1))
+        ref = DeviceSampler([dm], W, seed=7)
+        ref.set_state(X0)
+        # the failed runs advanced the random stream by 6 steps
+        ref.run(6, store=False)
+        ref.set_state(X0)
+        ref.run(5)
+        np.testing.assert_array_equal(ds.get_chain()[0][-5:], ref.get_chain()[0])
+        ds.close(); ref.close(); dm.close()
+    finally:
+        (tmp_path / "done").write_text("x")
+        child.join(60)
+        if child.is_alive():
+            child.kill()
 
 
 def _multigroup_models():
