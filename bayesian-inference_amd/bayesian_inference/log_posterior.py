@@ -86,8 +86,10 @@ def device_models(n_div: float = 1.0):
 
 
 def chains_can_stack(config) -> bool:
-    """Closure chains can share one multi-chain device sampler when there is a single emulation group with few
-    enough PCs for the device's stacked path (the general case runs chain by chain)."""
+    """Closure chains share one multi-chain device sampler for every configuration the device models support (any
+    number of emulation groups, up to 64 PCs each: ``tests/test_gpu_shipped.py`` stacks the shipped three-group shape);
+    what bounds a stacked run is chain memory, which ``mcmc._closure_sub_batches`` handles.  False only for a config
+    without an ``emulators`` block (then there is nothing to run either way)."""
     try:
         groups = config.analysis_config['parameters']['emulators']
     except (KeyError, TypeError):

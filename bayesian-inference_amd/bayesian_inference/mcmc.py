@@ -20,7 +20,7 @@ import yaml
 
 from bayesian_inference import emulation, log_posterior
 from gpemu import dist as gdist
-from gpemu.sampler import EnsembleSampler
+from gpemu.sampler import EnsembleSampler, walkers_independent
 
 logger = logging.getLogger(__name__)
 
@@ -70,7 +70,33 @@ def _best_distinct(sampler, count):
 # run_mcmc(config, closure_index=i) once per validation design point; the chains are independent and share the
 # emulators.  The first call a rank receives runs ALL of that rank's closure chains stacked in one multi-chain
 # device sampler and writes every chain's files; the later calls find their chain done and return.
+#   * only the call for the FIRST index this rank owns starts a batch (the reference's loop starts at 0); it always
+#     reruns, so a second closure pass in the same process -- e.g. after re-fitting the emulators -- produces fresh
+#     files like the reference's; a call for any other index that no batch has produced runs that chain alone;
+#   * a finished index is handed out once: asking for the same index again reruns it;
+#   * the batch is keyed on the emulator files' modification times as well, so chains of older emulators never count.
 _closure_done: "dict[tuple, set]" = {}
+
+
+def _closure_key(config):
+    stamps = []
+    try:
+        for group in config.analysis_config['parameters']['emulators']:
+            path = os.path.join(config.output_dir, f'emulation_group_{group}.pkl')
+            stamps.append((path, os.path.getmtime(path) if os.path.exists(path) else None))
+    except (KeyError, TypeError):
+        pass
+    return (config.output_dir, config.analysis_name, config.parameterization, tuple(stamps))
+
+
+def _closure_sub_batches(config, indices, n_par):
+    """Split ``indices`` so that one stacked run's chain storage (C x steps x W x (d + 1) doubles on the device, and
+    again on the host) stays within GPEMU_CLOSURE_CHAIN_GIB (default 16)."""
+    budget = float(os.environ.get("GPEMU_CLOSURE_CHAIN_GIB", "16")) * 2 ** 30
+    steps = max(config.n_sampling_steps, config.n_burn_steps)
+    per_chain = 8.0 * steps * config.n_walkers * (n_par + 1)
+    n = max(1, int(budget // max(per_chain, 1.0)))
+    return [indices[i:i + n] for i in range(0, len(indices), n)]
 
 
 def _closure_batch_enabled():
@@ -116,7 +142,14 @@ def _run_closure_batch(config, indices):
         return [arr[:, c * n_walk:(c + 1) * n_walk] for c in range(n_ch)]
 
     def advance(X0, steps):
+        # emcee's initial-state checks, per chain (the single-chain path makes them in EnsembleSampler.advance)
+        for c, x0 in enumerate(X0):
+            if not walkers_independent(x0):
+                raise ValueError(f"closure chain {indices[c]}: Initial state has a large condition number. Make sure "
+                                 "that your walkers are linearly independent for the best performance")
         sampler.set_state(np.concatenate(X0))
+        if np.any(np.isnan(sampler.get_state()[1])):
+            raise ValueError("The initial log_prob was NaN")
         done = 0
         while done < steps:
             block = min(config.n_logging_steps - done % config.n_logging_steps, steps - done)
@@ -178,17 +211,22 @@ def run_mcmc(config, closure_index=-1):
     alone = owner is not None          # this rank runs the whole chain by itself
     if closure_index >= 0 and (alone or world == 1) and _closure_batch_enabled() \
             and 'validation_indices' in config.analysis_config:
-        key = (config.output_dir, config.analysis_name, config.parameterization)
+        key = _closure_key(config)
         done = _closure_done.setdefault(key, set())
-        if closure_index in done:
-            logger.info(f'closure test {closure_index}: already run with the stacked chains')
+        owned = _closure_indices(config, 0, rank, world)
+        if owned and closure_index == owned[0] and log_posterior.chains_can_stack(config):
+            for stale in [k for k in _closure_done if k[:3] == key[:3] and k != key]:
+                del _closure_done[stale]
+            done.clear()                      # a new pass: everything reruns, like the reference
+            n_par = len(config.analysis_config['parameterization'][config.parameterization]['names'])
+            for batch in _closure_sub_batches(config, owned, n_par):
+                _run_closure_batch(config, batch)
+                done.update(batch)
+            done.discard(closure_index)
             return
-        indices = [j for j in _closure_indices(config, closure_index, rank, world) if j not in done]
-        if closure_index not in indices:
-            indices.insert(0, closure_index)
-        if log_posterior.chains_can_stack(config):
-            _run_closure_batch(config, indices)
-            done.update(indices)
+        if closure_index in done:
+            done.discard(closure_index)       # handed out once; a repeated request reruns the chain by itself
+            logger.info(f'closure test {closure_index}: already run with the stacked chains')
             return
 
     box = config.analysis_config['parameterization'][config.parameterization]

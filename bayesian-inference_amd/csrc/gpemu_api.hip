@@ -64,6 +64,10 @@ int ensure_workspace(gpemu_model *m, int64_t B) {
   GP_TRY(dev_alloc(&w.logp, need));
   GP_HIP(hipMemsetAsync(w.KS, 0, sizeof(double) * (size_t)(k * m->Npad * need), m->stream));
   GP_HIP(hipMemsetAsync(w.vsq_part, 0, sizeof(double) * (size_t)(k * (m->Npad / 32) * need), m->stream));
+  // the caller's launches may go to ANOTHER stream (a sampler over several groups runs every group on the first
+  // group's stream): the zero fill must have landed before anything writes the new buffers (found by the shipped
+  // three-group golden G7: the fill of groups 2 and 3 raced with their first evaluation and wiped partial sums)
+  GP_HIP(hipStreamSynchronize(m->stream));
   w.Bcap = need;
   return GPEMU_OK;
 }

@@ -69,3 +69,32 @@ class TrivialSort:
 
     def convert(self, group_matrices):
         return group_matrices[self.name]
+
+
+def results_at_golden_theta(g, kernels_active=None, design=None):
+    """Results dict in the reference's schema with our estimator objects at the golden's fitted theta."""
+    from gpemu import estimators as E
+    design = g["design"] if design is None else design
+    import golden_util as GU
+    spec = GU.spec_of(g)
+    k = int(g["n_pc"])
+    d = design.shape[1]
+    scaler = E.StandardScaler()
+    scaler.mean_, scaler.scale_, scaler.var_ = g["scaler_mean"], g["scaler_scale"], g["scaler_var"]
+    pca = E.PCA()
+    pca.components_, pca.explained_variance_ = g["pca_components"], g["pca_explained_variance"]
+    pca.explained_variance_ratio_ = g["pca_explained_variance_ratio"]
+    pca.mean_ = g["pca_mean"] if "pca_mean" in g else np.zeros(g["pca_components"].shape[1])
+    emus = []
+    for i in range(k):
+        th = np.exp(g["theta"][i])
+        kern = E.ARDKernel(spec.kind, th[:d], np.outer(th[:d], [0.01, 100]), nu=spec.nu,
+                           constant_value=th[d] if spec.has_const else None, constant_value_bounds=(1e-3, 1e3),
+                           noise_level=th[d + int(spec.has_const)] if spec.has_noise else None,
+                           noise_level_bounds=(1e-3, 10))
+        gp = E.GaussianProcessRegressor(kern, alpha=float(g["gpr_alpha"]), optimizer=None, copy_X_train=False)
+        gp.fit(design, g["Y_pca_truncated"][:, i])
+        emus.append(gp)
+    return {"PCA": {"pca": pca, "scaler": scaler, "Y_pca_truncated": g["Y_pca_truncated"]}, "emulators": emus}
+
+

@@ -42,6 +42,28 @@ def group_model(g, prefix="", design=None, use_golden_L=True):
                         n_pc=k)
 
 
+def g7_groups(g):
+    """G7 (the reference's shipped three-group shape on its own fixture): group names, the mapping the reference's
+    real sorter learned {observable: (group, slice in the merged matrix, slice in the group matrix)}, and per group
+    the observable block starts inside the group matrix and the group's columns of the merged matrix."""
+    names = [str(n) for n in g["group_names"]]
+    mapping = {}
+    for obs, grp, a, b, c, d in zip(g["map_observables"], g["map_group"], g["map_out_start"], g["map_out_stop"],
+                                    g["map_grp_start"], g["map_grp_stop"]):
+        mapping[str(obs)] = (str(grp), slice(int(a), int(b)), slice(int(c), int(d)))
+    block_start, cols = {}, {}
+    for n in names:
+        mine = sorted((sg.start, sg.stop, so.start) for (grp, so, sg) in mapping.values() if grp == n)
+        block_start[n] = [m[0] for m in mine] + [mine[-1][1]]
+        cols[n] = np.concatenate([np.arange(m[2], m[2] + m[1] - m[0]) for m in mine])
+    return names, mapping, block_start, cols
+
+
+def g7_models(g, use_golden_L=True):
+    return {n: group_model(g, prefix=n + "_", design=g["design"], use_golden_L=use_golden_L)
+            for n in g7_groups(g)[0]}
+
+
 def fixed_theta_model(N, F, k, seed=0, ls_factor=0.5, noise=0.05, jitter=1e-10, kind=O.RBF, nu=np.inf):
     """The C3-style model of SURVEY 8(d): synthetic data, fixed hyper-parameters, built with the
     oracle only (no sklearn) -- regenerates what g4_c3_fixed_theta.npz was produced from."""

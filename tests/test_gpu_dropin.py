@@ -18,29 +18,7 @@ def relerr(a, b):
     return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
 
 
-def _results_at_golden_theta(g, kernels_active, design=None):
-    """Results dict in the reference's schema with our estimator objects at the golden's fitted theta."""
-    from gpemu import estimators as E
-    design = g["design"] if design is None else design
-    spec = GU.spec_of(g)
-    k = int(g["n_pc"])
-    d = design.shape[1]
-    scaler = E.StandardScaler()
-    scaler.mean_, scaler.scale_, scaler.var_ = g["scaler_mean"], g["scaler_scale"], g["scaler_var"]
-    pca = E.PCA()
-    pca.components_, pca.explained_variance_ = g["pca_components"], g["pca_explained_variance"]
-    pca.explained_variance_ratio_, pca.mean_ = g["pca_explained_variance_ratio"], g["pca_mean"]
-    emus = []
-    for i in range(k):
-        th = np.exp(g["theta"][i])
-        kern = E.ARDKernel(spec.kind, th[:d], np.outer(th[:d], [0.01, 100]), nu=spec.nu,
-                           constant_value=th[d] if spec.has_const else None, constant_value_bounds=(1e-3, 1e3),
-                           noise_level=th[d + int(spec.has_const)] if spec.has_noise else None,
-                           noise_level_bounds=(1e-3, 10))
-        gp = E.GaussianProcessRegressor(kern, alpha=float(g["gpr_alpha"]), optimizer=None, copy_X_train=False)
-        gp.fit(design, g["Y_pca_truncated"][:, i])
-        emus.append(gp)
-    return {"PCA": {"pca": pca, "scaler": scaler, "Y_pca_truncated": g["Y_pca_truncated"]}, "emulators": emus}
+_results_at_golden_theta = DU.results_at_golden_theta
 
 
 class _GroupCfg:
@@ -224,6 +202,19 @@ def test_closure_tests_run_stacked(tmp_path, monkeypatch):
         sampler = pickle.load(open(c.sampler_outputfile, "rb"))
         np.testing.assert_array_equal(sampler.get_chain(), out["chain"])
     assert not np.array_equal(pseudo[0], pseudo[1])              # every chain has its own draw
+    # a second pass over the loop reruns everything, like the reference -- here in sub-batches of one chain
+    # (chain-memory budget) -- and a repeated stand-alone request for a chain that was handed out reruns it by itself
+    first_pass = {c.mcmc_outputfile: written[c.mcmc_outputfile]["chain"].copy() for c in cfgs}
+    monkeypatch.setenv("GPEMU_CLOSURE_CHAIN_GIB", "1e-9")
+    assert [len(b) for b in mcmc._closure_sub_batches(cfgs[0], [0, 1, 2], d)] == [1, 1, 1]
+    mcmc.run_mcmc(cfgs[0], closure_index=0)
+    assert all(not np.array_equal(first_pass[c.mcmc_outputfile], written[c.mcmc_outputfile]["chain"]) for c in cfgs)
+    mcmc.run_mcmc(cfgs[1], closure_index=1)
+    mcmc.run_mcmc(cfgs[2], closure_index=2)                      # handed out ...
+    snap = written[cfgs[2].mcmc_outputfile]["chain"].copy()
+    mcmc.run_mcmc(cfgs[2], closure_index=2)                      # ... asked again: runs alone
+    assert not np.array_equal(snap, written[cfgs[2].mcmc_outputfile]["chain"])
+    assert written[cfgs[2].mcmc_outputfile]["chain"].shape == (steps, W, d)
     mcmc._closure_done.clear()
 
 

@@ -1,0 +1,236 @@
+"""-m gpu tests on the reference's SHIPPED analysis shape (golden G7, tests/golden/make_g7_shipped.py): three emulation
+groups with 5 / 11 / 25 principal components, Matern-1.5 + White kernel, alpha 1e-10, on the reference's own fixture,
+merged by the mapping the reference's real SortEmulationGroupObservables learned from the real observables.h5
+(ref: config/jet_substructure.yaml:243-278, emulation.py:289-462, log_posterior.py:42-146).  Everything goes through the
+drop-in modules / the C ABI; the expected values are the reference's own outputs."""
+import os
+
+import numpy as np
+import pytest
+
+import dropin_util as DU
+import golden_util as GU
+from oracle import gp_oracle as O
+from oracle import sampler_oracle as SO
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+
+def relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+class _GroupCfg:
+    def __init__(self, n_pc):
+        self.n_pc = n_pc
+
+
+class _EmuCfg:
+    def __init__(self, groups, sorter):
+        self.emulation_groups_config = groups
+        self.sort_observables_in_matrix = sorter
+
+
+def _sub(g, name):
+    sub = {k[len(name) + 1:]: v for k, v in g.items() if k.startswith(name + "_")}
+    sub.update(design=g["design"], gpr_alpha=g["gpr_alpha"])
+    return sub
+
+
+def _shipped():
+    """G7 through the drop-in classes: results dicts at the reference's fitted theta, the drop-in sorter."""
+    from bayesian_inference import emulation
+    g = GU.load("g7_shipped_config")
+    names, mapping, block_start, cols = GU.g7_groups(g)
+    sorter = emulation.SortEmulationGroupObservables(mapping, tuple(int(v) for v in g["map_shape"]))
+    res = {n: DU.results_at_golden_theta(_sub(g, n)) for n in names}
+    cfgs = {n: _GroupCfg(int(g[n + "_n_pc"])) for n in names}
+    return g, names, mapping, res, _EmuCfg(cfgs, sorter)
+
+
+def test_shipped_fit_side_at_identical_theta():
+    """Device factorisation at the reference's fitted hyper-parameters, every PC of every group: alpha_, L_, LML and its
+    gradient (ref: emulation.py:169-172 -> skl _gpr.py:225-365, 537-652)."""
+    g, names, mapping, res, emu_cfg = _shipped()
+    for n in names:
+        emus = res[n]["emulators"]
+        assert len(emus) == {"pi0_group": 5, "pion_group": 11, "charged_group": 25}[n]
+        for i, e in enumerate(emus):
+            assert relerr(e.alpha_, g[n + "_alpha"][i]) < 1e-6
+            chk = np.array([e.L_.sum(), (e.L_ ** 2).sum(), np.abs(e.L_).max()])
+            np.testing.assert_allclose(chk, g[n + "_L_checksum"][i], rtol=1e-8)
+            lml, grad = e.log_marginal_likelihood(g[n + "_theta"][i], eval_gradient=True)
+            assert abs(lml - g[n + "_lml_at_theta"][i]) <= 1e-8 * max(1.0, abs(lml))
+            assert np.max(np.abs(grad - g[n + "_grad_at_theta"][i])) <= 1e-6 * max(1.0, np.max(np.abs(grad)))
+        assert relerr(emus[0].L_, g[n + "_L"][0]) < 1e-9
+
+
+def test_shipped_merged_predict_and_log_posterior():
+    """emulation.predict merged over the three groups and log_posterior in the reference's three calling forms."""
+    from bayesian_inference import emulation, log_posterior
+    g, names, mapping, res, emu_cfg = _shipped()
+    Xq = g["Xq"]
+    for n in names:
+        cu = emulation.compute_emulator_group_cov_unexplained(emu_cfg.emulation_groups_config[n], res[n])
+        assert relerr(cu, g[n + "_cov_unexplained"]) < 1e-11
+    merged = emulation.predict(Xq, emu_cfg, emulation_group_results=res)
+    assert merged["central_value"].shape == (24, 215) and merged["cov"].shape == (24, 215, 215)
+    assert relerr(merged["central_value"], g["merged_central_value"]) < TOL
+    assert relerr(merged["cov"][0], g["merged_cov_first"]) < TOL
+    assert relerr(np.stack([np.diag(c) for c in merged["cov"]]), g["merged_cov_diag"]) < TOL
+    # blocks of different observables are zero, also inside one group (ref: emulation.py:370-388)
+    a, b = mapping["2760__PbPb__hadron__pt_ch_alice____0-5"][1], mapping["2760__PbPb__hadron__pt_ch_alice____5-10"][1]
+    assert np.all(merged["cov"][:, a, b] == 0.0)
+    one = emulation.predict(Xq[:1], emu_cfg, emulation_group_results=res)
+    assert relerr(one["cov"][0], g["merged1_cov"]) < TOL
+    log_posterior.initialize_pool_variables(g["lo"], g["hi"], emu_cfg, res, {"y": g["y_exp"], "y_err": g["y_err"]}, None)
+    per = np.array([log_posterior.log_posterior(Xq[i])[0] for i in range(Xq.shape[0])])
+    np.testing.assert_allclose(per, g["logpost_per_walker"], rtol=TOL)
+    np.testing.assert_allclose(log_posterior.log_posterior(Xq), g["logpost_batched"], rtol=TOL)
+    mixed = log_posterior.log_posterior(g["X_mixed"])
+    assert np.array_equal(np.isneginf(mixed), np.isneginf(g["logpost_mixed"]))
+    fin = np.isfinite(mixed)
+    np.testing.assert_allclose(mixed[fin], g["logpost_mixed"][fin], rtol=TOL)
+    # the reference form on the device (materialised covariance, F x F Cholesky per walker) agrees as well
+    from gpemu.model import EXACT
+    total = np.zeros(Xq.shape[0])
+    for dm in log_posterior.device_models(n_div=1.0):
+        total += dm.logpost(Xq, mode=EXACT)
+    np.testing.assert_allclose(total, g["logpost_per_walker"], rtol=TOL)
+    log_posterior.initialize_pool_variables(None, None, None, None, None, None)
+
+
+def _device_models(g, names, block_start, cols, y=None):
+    models = GU.g7_models(g)
+    y = g["y_exp"] if y is None else np.asarray(y)
+    dms = []
+    for n in names:
+        dm = GU.device_model(models[n])
+        dm.likelihood_setup(y[..., cols[n]], g["y_err"][cols[n]], g["lo"], g["hi"], 1.0, block_start=block_start[n])
+        dms.append(dm)
+    return models, dms
+
+
+@pytest.mark.parametrize("W", [24, 200])
+def test_shipped_device_sampler_equals_oracle_chain(W):
+    """The device stretch move over the three groups (k = 25 takes the LDS likelihood variant) against the CPU
+    restatement fed the reference-form merged log-posterior: same chain, step for step.  W = 200 is the shipped
+    ensemble of the jet analyses (ref: config/jet_substructure.yaml:231)."""
+    from gpemu import synthetic
+    from gpemu.sampler import DeviceSampler
+    g = GU.load("g7_shipped_config")
+    names, mapping, block_start, cols = GU.g7_groups(g)
+    models, dms = _device_models(g, names, block_start, cols)
+
+    def oracle_lp(X):
+        return np.array([O.log_posterior(x, models, g["lo"], g["hi"], g["y_exp"], g["y_err"], mapping)[0]
+                         for x in np.atleast_2d(X)])
+    steps = 6 if W == 24 else 2
+    X0 = synthetic.make_walkers(W, seed=11, lo=g["design"].min(0), hi=g["design"].max(0))
+    ds = DeviceSampler(dms, W, seed=2026)
+    ds.set_state(X0)
+    np.testing.assert_allclose(ds.get_state()[1], oracle_lp(X0), rtol=TOL)
+    ds.run(steps)
+    chain, lps = ds.get_chain()
+    ochain, olps, onacc = SO.run(X0, oracle_lp, SO.PhiloxStream(2026), steps)
+    np.testing.assert_allclose(chain, ochain, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(lps, olps, rtol=TOL)
+    np.testing.assert_array_equal(ds.counts()[0], onacc)
+    ds.close()
+    for dm in dms:
+        dm.close()
+
+
+def test_shipped_stacked_closure_chains_equal_separate_chains():
+    """Closure chains on the shipped shape (ref: steer_analysis.py:168-183): C chains stacked in one multi-chain sampler
+    over the three groups, every chain on its own pseudo-data vector, are the chains C separate samplers produce."""
+    from gpemu import synthetic
+    from gpemu.sampler import DeviceSampler
+    g = GU.load("g7_shipped_config")
+    names, mapping, block_start, cols = GU.g7_groups(g)
+    C, W, steps = 4, 30, 6
+    rng = np.random.default_rng(5)
+    ys = g["y_exp"][None, :] + g["y_err"][None, :] * rng.normal(size=(C, g["y_exp"].size))
+    seeds = [900 + 7 * c for c in range(C)]
+    X0 = np.concatenate([synthetic.make_walkers(W, seed=60 + c, lo=g["design"].min(0), hi=g["design"].max(0))
+                         for c in range(C)])
+    models, dms = _device_models(g, names, block_start, cols, y=ys)
+    ms = DeviceSampler(dms, W, seeds=seeds)
+    ms.set_state(X0)
+    lp0 = ms.get_state()[1]
+    ms.run(2)
+    ms.run(steps - 2)
+    chain, lps = ms.get_chain()
+    nacc = ms.counts()[0]
+    ms.close()
+    for c in range(C):
+        for n, dm in zip(names, dms):
+            dm.likelihood_setup(ys[c][cols[n]], g["y_err"][cols[n]], g["lo"], g["hi"], 1.0, block_start=block_start[n])
+        one = DeviceSampler(dms, W, seed=seeds[c])
+        one.set_state(X0[c * W:(c + 1) * W])
+        np.testing.assert_array_equal(one.get_state()[1], lp0[c * W:(c + 1) * W])
+        one.run(steps)
+        c1, l1 = one.get_chain()
+        np.testing.assert_array_equal(chain[:, c * W:(c + 1) * W], c1)
+        np.testing.assert_array_equal(lps[:, c * W:(c + 1) * W], l1)
+        np.testing.assert_array_equal(nacc[c * W:(c + 1) * W], one.counts()[0])
+        one.close()
+    for dm in dms:
+        dm.close()
+
+
+def _sharded_shipped_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gpemu import synthetic
+    from gpemu.sampler import DeviceSampler
+    g = GU.load("g7_shipped_config")
+    names, mapping, block_start, cols = GU.g7_groups(g)
+    models, dms = _device_models(g, names, block_start, cols)
+    W = 26
+    ds = DeviceSampler(dms, W, seed=77)
+    ds.set_state(synthetic.make_walkers(W, seed=12, lo=g["design"].min(0), hi=g["design"].max(0)))
+    ds.run_sharded(3)
+    ds.run_sharded(4)
+    chain, lps = ds.get_chain()
+    np.save(os.path.join(out_dir, f"chain_{rank}.npy"), chain)
+    np.save(os.path.join(out_dir, f"lp_{rank}.npy"), lps)
+    with open(os.path.join(out_dir, f"transport_{rank}.txt"), "w") as f:
+        f.write(str(ds.last_transport))
+    dist.barrier()
+    dist.destroy_process_group()
+    ds.close()
+    for dm in dms:
+        dm.close()
+
+
+def test_shipped_two_rank_sharded_run_equals_single(tmp_path, monkeypatch):
+    """The walker-sharded run of the shipped shape on two ranks (two processes on the one GPU, gloo rendezvous): both
+    ranks hold the single-GPU chain, bit for bit."""
+    import torch.multiprocessing as mp
+    from gpemu import synthetic
+    from gpemu.sampler import DeviceSampler
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    port = 29800 + (os.getpid() % 150)
+    mp.spawn(_sharded_shipped_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    c0, c1 = np.load(tmp_path / "chain_0.npy"), np.load(tmp_path / "chain_1.npy")
+    np.testing.assert_array_equal(c0, c1)
+    np.testing.assert_array_equal(np.load(tmp_path / "lp_0.npy"), np.load(tmp_path / "lp_1.npy"))
+    assert (tmp_path / "transport_0.txt").read_text() == (tmp_path / "transport_1.txt").read_text()
+    g = GU.load("g7_shipped_config")
+    names, mapping, block_start, cols = GU.g7_groups(g)
+    models, dms = _device_models(g, names, block_start, cols)
+    W = 26
+    ds = DeviceSampler(dms, W, seed=77)
+    ds.set_state(synthetic.make_walkers(W, seed=12, lo=g["design"].min(0), hi=g["design"].max(0)))
+    ds.run(7)
+    chain, lps = ds.get_chain()
+    np.testing.assert_array_equal(chain, c0)
+    np.testing.assert_array_equal(lps, np.load(tmp_path / "lp_0.npy"))
+    ds.close()
+    for dm in dms:
+        dm.close()

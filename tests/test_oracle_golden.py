@@ -137,6 +137,62 @@ def test_multigroup_lowrank_blocks_equal_reference_merge():
     np.testing.assert_allclose(total, g["logpost_per_walker"], rtol=1e-9)
 
 
+def test_shipped_three_group_configuration_g7():
+    """G7: the reference run end to end on its own fixture in the shape of its shipped analysis -- three emulation
+    groups with 5 / 11 / 25 PCs, Matern-1.5 + White, merged by the real SortEmulationGroupObservables through the real
+    data_IO (ref: config/jet_substructure.yaml:243-278; tests/golden/make_g7_shipped.py).  The oracle at the
+    reference's fitted theta reproduces the factors, the merged prediction and the log-posterior in all three calling
+    forms; the low-rank block form (what the device evaluates) equals the reference's value."""
+    g = GU.load("g7_shipped_config")
+    names, mapping, block_start, cols = GU.g7_groups(g)
+    assert [int(g[n + "_n_pc"]) for n in names] == [5, 11, 25]
+    assert int(g["map_shape"][1]) == 215 and len(mapping) == 16
+    X = g["design"]
+    for n in names:                                   # fit-side parity at identical theta, every PC of every group
+        spec = GU.spec_of(g, n + "_")
+        assert spec.kind == O.MATERN and spec.nu == 1.5 and spec.has_noise and not spec.has_const
+        mean, scale, var = O.scaler_fit(g[n + "_Y"])
+        np.testing.assert_allclose(mean, g[n + "_scaler_mean"], rtol=1e-14, atol=0)
+        np.testing.assert_allclose(scale, g[n + "_scaler_scale"], rtol=1e-14, atol=0)
+        pca = O.pca_fit((g[n + "_Y"] - mean) / scale)
+        k = int(g[n + "_n_pc"])
+        assert np.array_equal(pca["flip_argmax"][:k], g[n + "_flip_argmax"][:k])
+        assert relerr(pca["Y_pca"][:, :k], g[n + "_Y_pca_truncated"]) < 1e-9
+        for i in range(k):
+            gp = O.gp_fit_at_theta(X, g[n + "_Y_pca_truncated"][:, i], g[n + "_theta"][i], spec, 1e-10)
+            assert relerr(gp.alpha, g[n + "_alpha"][i]) < 1e-7
+            chk = np.array([gp.L.sum(), (gp.L ** 2).sum(), np.abs(gp.L).max()])
+            np.testing.assert_allclose(chk, g[n + "_L_checksum"][i], rtol=1e-9)
+            lml, grad = O.lml_and_grad(X, g[n + "_Y_pca_truncated"][:, i], g[n + "_theta"][i], spec, 1e-10)
+            assert abs(lml - g[n + "_lml_at_theta"][i]) <= 1e-8 * max(1.0, abs(lml))
+            assert np.max(np.abs(grad - g[n + "_grad_at_theta"][i])) <= 1e-6 * max(1.0, np.max(np.abs(grad)))
+    models = GU.g7_models(g)
+    for n in names:
+        assert relerr(O.cov_unexplained(models[n]), g[n + "_cov_unexplained"]) < RTOL
+    Xq = g["Xq"]
+    merged = O.merge_groups({n: O.predict_group(Xq, m) for n, m in models.items()}, mapping, 215)
+    assert relerr(merged["central_value"], g["merged_central_value"]) < RTOL
+    assert relerr(merged["cov"][0], g["merged_cov_first"]) < RTOL
+    assert relerr(np.stack([np.diag(c) for c in merged["cov"]]), g["merged_cov_diag"]) < RTOL
+    one = O.merge_groups({n: O.predict_group(Xq[:1], m) for n, m in models.items()}, mapping, 215)
+    assert relerr(one["cov"][0], g["merged1_cov"]) < RTOL
+    lo, hi, ye, yr = g["lo"], g["hi"], g["y_exp"], g["y_err"]
+    np.testing.assert_allclose(O.log_posterior(Xq, models, lo, hi, ye, yr, mapping), g["logpost_batched"], rtol=1e-8)
+    per = np.array([O.log_posterior(Xq[i], models, lo, hi, ye, yr, mapping)[0] for i in range(Xq.shape[0])])
+    np.testing.assert_allclose(per, g["logpost_per_walker"], rtol=1e-8)
+    mixed = O.log_posterior(g["X_mixed"], models, lo, hi, ye, yr, mapping)
+    assert np.array_equal(np.isneginf(mixed), np.isneginf(g["logpost_mixed"])) and np.isneginf(mixed).sum() == 3
+    fin = np.isfinite(mixed)
+    np.testing.assert_allclose(mixed[fin], g["logpost_mixed"][fin], rtol=1e-8)
+    # the device's form: per group, per observable block, low rank (k = 25 > 16 takes the LDS likelihood variant there)
+    total = np.zeros(Xq.shape[0])
+    for n in names:
+        m, v = O.gp_predict_all(Xq, models[n])
+        sts = O.lowrank_setup_blocks(models[n], ye[cols[n]], yr[cols[n]], block_start[n], n_div=1)
+        total += np.array([O.loglik_lowrank_blocks(m[i], v[i], sts) for i in range(Xq.shape[0])])
+    np.testing.assert_allclose(total, g["logpost_per_walker"], rtol=1e-9)
+
+
 def test_c3_fixed_theta_golden():
     """C3 shape (N=1000, F=500, k=10): factors regenerated by the oracle from the seed."""
     g = GU.load("g4_c3_fixed_theta")
