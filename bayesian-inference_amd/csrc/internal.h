@@ -64,11 +64,22 @@ struct gpemu_model {
   void *sched_items = nullptr; // TrmmItem[sched_workers][sched_max_items]
   int *sched_cnt = nullptr;    // [sched_workers]
   int sched_ncb = -1, sched_max_items = 0, sched_workers = 0;
+  int sched_cap = 0;           // worker cap the current schedule was built for
+  struct SchedEntry { int ncb, cap; void *items; int *cnt; int max_items, workers; };
+  std::vector<SchedEntry> sched_cache;   // every schedule built so far (sched_items / sched_cnt point into one of them)
+  int worker_limit = 0;        // > 0: persistent kernels are scheduled for this many workers (a CU-masked stream)
+  // CU-partitioned predict pipeline (gpemu_predict_full_dev): the GP stage of chunk i + 1 on one set of CUs while the
+  // covariance writer of chunk i streams to HBM from the others
+  hipStream_t split_gp = nullptr, split_wr = nullptr;
+  int split_gp_per_xcd = 0, split_wr_per_xcd = 0;   // CUs per XCD of split_gp (first bits) / split_wr (last bits)
+  std::vector<hipEvent_t> split_ev;
+  double *pf_mean = nullptr, *pf_var = nullptr;   // [pf_cap][k] GP mean / variance of a whole predict batch
+  int64_t pf_cap = 0;
   int64_t vsq_nrb = 0;         // row blocks of partial ||W k_*||^2 the triangular GEMM writes
   // schedule of the small-batch triangular GEMM (k_trmm_small.hip) for the current number of 32-column blocks
   void *sm_items = nullptr;
   int *sm_cnt = nullptr;
-  int sm_ncb = -1, sm_max_items = 0, sm_workers = 0;
+  int sm_ncb = -1, sm_max_items = 0, sm_workers = 0, sm_cap = 0;
   int kernel_kind = 0;
   double nu = 0;
   int has_const = 0, has_noise = 0;
@@ -152,6 +163,9 @@ struct ProposeArgs {
   const int *partner = nullptr;   // [n] walker index of the complementary-set member drawn for proposal i
   double *factors = nullptr;      // [n] out: (d - 1) log zz
   int n = 0, d = 0;
+  // enabled == 0 and raw != nullptr: the queries come as caller rows [n][d] (gpemu_gp_predict / predict_full); the
+  // kernel pads them to [..][DPAD] on the fly and stores the padded rows once (what pad_queries_kernel used to do)
+  const double *raw = nullptr;
 };
 
 int ensure_workspace(gpemu_model *m, int64_t B);
@@ -162,7 +176,6 @@ int launch_kstar(gpemu_model *m, int64_t B, double *dXq_padded, hipStream_t st, 
 int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st);
 int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st);   // B <= 128; GPEMU_ERR_UNSUPPORTED if the shape does not fit
 int launch_reduce_mean_var(gpemu_model *m, int64_t B, double *dmean, double *dvar, hipStream_t st);
-int launch_pad_queries(gpemu_model *m, int64_t B, const double *dX, hipStream_t st);
 int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq_padded, double *dout,
                           int accumulate, hipStream_t st, const AcceptArgs *aa = nullptr);
 int logpost_padded(gpemu_model *m, int64_t B, double *dXq, double *dout, int accumulate,

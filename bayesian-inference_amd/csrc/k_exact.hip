@@ -183,15 +183,300 @@ __global__ __launch_bounds__(256) void predict_full_rows_kernel(
   }
 }
 
-int launch_predict_full(gpemu_model *m, int64_t B, double n_div, double *dcv, double *dcov, hipStream_t st) {
+// Matrix-core form of the covariance writer (k <= 16, F even).  The VALU forms above spend 10 fp64 FMAs and nine LDS
+// reads per output element in every lane: fine when all 256 CUs share an HBM-bound job, but only ~30 GB/s per CU, so
+// the writer cannot be confined to the few CUs an HBM-write-bound kernel really needs (a store-only kernel reaches
+// 5.2 TB/s on 64 CUs, profiles/r03_cu_mask_probe.txt) while the GP stage of the next chunk uses the rest.  Here
+//     cov_b = U diag(var_b) U^T + C,   U = diag(s) S_k^T  (F x k),   C = (C_unexpl / n_div) o (s s^T)
+// is a rank-k product on v_mfma_f64_16x16x4_f64: the B fragments (U for the wave's columns) and the accumulator inputs
+// (C) stay in registers across the workgroup's samples, the A fragment of a sample is U scaled by its variances: three
+// multiplies per lane and sample, no LDS.  A wave owns 16 rows x 128 columns; a 32-column block is computed as TWO MFMA
+// tiles holding its even and its odd columns, so a lane ends up with (row, column 2c) and (row, column 2c + 1).
+// Written straight from the accumulator layout a wave-instruction would cover 256 bytes in each of 4 rows, and rows of
+// 8 F bytes are not 128-byte aligned: pieces of 256 or 512 bytes reach 3.3 TB/s on this part where 1 KiB contiguous
+// per wave-instruction reaches 5.4 (profiles/r03_cu_mask_probe.txt).  So the workgroup's 16 x F block of a sample --
+// contiguous in memory and line aligned when F <= 512 -- is staged in LDS in its memory order and stored flat: every
+// wave-instruction writes 1 KiB of whole cache lines.
+typedef double d4x __attribute__((ext_vector_type(4)));
+
+// GP mean / variance of a sample and PC either from arrays [B][k] or -- arrays null -- summed on the fly from the GP
+// stage's partial sums exactly as reduce_mean_var_kernel does (same order, same clipping: skl _gpr.py:479-494, ref:
+// emulation.py:499), so that emulation.predict needs no reduction launch
+struct GpParts {
+  const double *mean, *var;                 // [B][k] or null
+  const double *mean_part, *vsq_part, *kdiag;
+  int nchunk, nrb;
+};
+__device__ __forceinline__ double gp_var_of(const GpParts &g, int64_t b, int p, int k) {
+  if (g.var) return g.var[b * k + p];
+  double vs = 0.0;
+  for (int r = 0; r < g.nrb; ++r) vs += g.vsq_part[(b * k + p) * g.nrb + r];
+  double v = g.kdiag[p] - vs;
+  if (v < 0.0) v = 0.0;
+  const double sd = sqrt(v);
+  return sd * sd;
+}
+__device__ __forceinline__ double gp_mean_of(const GpParts &g, int64_t b, int p, int k) {
+  if (g.mean) return g.mean[b * k + p];
+  double mu = 0.0;
+  for (int c = 0; c < g.nchunk; ++c) mu += g.mean_part[(b * k + p) * g.nchunk + c];
+  return mu;
+}
+
+constexpr int PM_NB = 16;      // samples per work item (PM_NB * 16 <= 512 threads stage its variances)
+
+// Persistent: one 512-thread workgroup per CU of the stream it runs on (the grid is the worker count), each walking a
+// contiguous range of (row block, group of PM_NB samples) items, row block major, so its constants change once or
+// twice.  The LDS block is double buffered and the loop is software pipelined: a wave issues the MFMAs of sample i,
+// then -- while the matrix pipe works -- reads sample i - 1's finished block from the other buffer and stores it to
+// memory, then writes its accumulators into this sample's buffer: ONE barrier per sample, and the matrix pipe, the LDS
+// and the store path of a CU are busy at the same time.
+template <int KS, int CBW, int DBG = 0>   // k-steps of 4: k <= 4 KS; CBW 32-column blocks per wave (2: 8 waves, 1: 16 waves)
+__global__ __launch_bounds__(1024 / CBW) void predict_cov_mfma_kernel(
+    GpParts gp, const double *__restrict__ comp, const double *__restrict__ sscale,
+    const double *__restrict__ cun, double *__restrict__ cov, int64_t B, int F, int k, double inv_ndiv, int ngroups,
+    int total_items) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tile_sz = 16 * F;
+  double *vstage = smem + 2 * tile_sz;           // [PM_NB][4 KS]: the item's variances (0 beyond k)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, c = lane & 15;
+  constexpr int NT = 1024 / CBW;                 // threads
+  const int gbase = wave * 32 * CBW;             // a wave owns 16 rows x 32 CBW columns (F <= 512: one column pass)
+  const int t0 = (int)((int64_t)total_items * blockIdx.x / gridDim.x);
+  const int t1 = (int)((int64_t)total_items * (blockIdx.x + 1) / gridDim.x);
+  // lane (q, c): A[i = c][kk = q], B[kk = q][n = c]; D[reg] = (row q + 4 reg, column c)
+  double ua[KS], ub[CBW][2][KS];
+  d4x ci[CBW][2];
+  double dbg_acc = 0.0;
+  int cur_rb = -1, buf = 0, pend_n = 0;          // pend_n = 0: nothing staged yet
+  double *pend_dst = cov;
+  double vnext = 0.0;                            // thread i: entry i of the next item's [PM_NB][4 KS] variances
+  if (t0 < t1 && (int)threadIdx.x < PM_NB * 4 * KS) {
+    const int grp0 = t0 % ngroups, ib = threadIdx.x / (4 * KS), p = threadIdx.x - ib * 4 * KS;
+    const int64_t b = (int64_t)grp0 * PM_NB + ib;
+    vnext = (b < B && p < k) ? gp_var_of(gp, b, p, k) : 0.0;
+  }
+#pragma unroll 1
+  for (int t = t0; t < t1; ++t) {
+    const int rb = t / ngroups, grp = t - rb * ngroups;
+    const int f0 = rb * 16;
+    if (rb != cur_rb) {
+      cur_rb = rb;
+      // all loads first (they are independent), the arithmetic afterwards
+      const int fa = f0 + c;
+      double ra[KS], rbv[CBW][2][KS], rc[CBW][2][4], sf[4], sg[CBW][2];
+      const double sfa = fa < F ? sscale[fa] : 0.0;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int p = 4 * s + q;
+        ra[s] = (fa < F && p < k) ? comp[(int64_t)p * F + fa] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sf[i] = (f0 + q + 4 * i < F) ? sscale[f0 + q + 4 * i] : 0.0;
+#pragma unroll
+      for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int g = gbase + 32 * cb + 2 * c + tt;
+          sg[cb][tt] = g < F ? sscale[g] : 0.0;
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            const int p = 4 * s + q;
+            rbv[cb][tt][s] = (g < F && p < k) ? comp[(int64_t)p * F + g] : 0.0;
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int f = f0 + q + 4 * i;
+            rc[cb][tt][i] = (f < F && g < F) ? cun[(int64_t)f * F + g] : 0.0;
+          }
+        }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) ua[s] = ra[s] * sfa;
+#pragma unroll
+      for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+          for (int s = 0; s < KS; ++s) ub[cb][tt][s] = rbv[cb][tt][s] * sg[cb][tt];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ci[cb][tt][i] = rc[cb][tt][i] * inv_ndiv * (sf[i] * sg[cb][tt]);
+        }
+    }
+    // this item's variances, fetched while the previous item was being processed (a global load here would sit on the
+    // critical path of every item); the previous item's have been consumed: every wave has passed its last barrier
+    const int64_t bb0 = (int64_t)grp * PM_NB;
+    if ((int)threadIdx.x < PM_NB * 4 * KS) vstage[threadIdx.x] = vnext;
+    __syncthreads();
+    if (t + 1 < t1 && (int)threadIdx.x < PM_NB * 4 * KS) {
+      const int grp1 = (t + 1) % ngroups, ib = threadIdx.x / (4 * KS), p = threadIdx.x - ib * 4 * KS;
+      const int64_t b = (int64_t)grp1 * PM_NB + ib;
+      vnext = (b < B && p < k) ? gp_var_of(gp, b, p, k) : 0.0;
+    }
+    const int nflat = (F - f0 < 16 ? F - f0 : 16) * F;           // doubles of the block that exist
+#pragma unroll 1
+    for (int ib = 0; ib < PM_NB; ++ib) {
+      const int64_t b = bb0 + ib;
+      if (b >= B) break;
+      double a[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) a[s] = ua[s] * vstage[ib * 4 * KS + 4 * s + q];
+      // One instruction stream per wave, issued in order: an MFMA occupies the SIMD's matrix pipe for 64 cycles, so
+      // everything else is placed BETWEEN the MFMAs (the scheduling barriers keep the compiler from regrouping):
+      // the LDS reads of the previous sample's block, its 1 KiB-per-instruction global stores, and the LDS writes
+      // of this sample's first column block all issue in the shadow of the matrix pipe.
+      const double *src = smem + (buf ^ 1) * tile_sz;
+      double *tile = smem + buf * tile_sz;
+      constexpr int NP = 8 * CBW / 2;        // 16-byte pieces per thread and block: 8 (512 threads) or 4 (1024)
+      d2x st8[4];                            // four 16-byte pieces in flight between LDS and memory
+      d4x d[CBW][2];
+#pragma unroll
+      for (int cb = 0; cb < CBW; ++cb) { d[cb][0] = ci[cb][0]; d[cb][1] = ci[cb][1]; }
+      const int e0 = 2 * (int)threadIdx.x;
+#define PM_MFMA(CB, T, S) do { if (DBG == 4) d[CB][T][0] += a[S] * ub[CB][T][S]; else d[CB][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[S], ub[CB][T][S], d[CB][T], 0, 0, 0); } while (0)
+#define PM_READ(J) st8[(J) & 3] = *reinterpret_cast<const d2x *>(src + e0 + 2 * NT * (J))   /* unconditional: stays inside the LDS allocation */
+#define PM_STORE(J) do { if (e0 + 2 * NT * (J) < pend_n) *reinterpret_cast<d2x *>(pend_dst + e0 + 2 * NT * (J)) = st8[(J) & 3]; } while (0)
+#define PM_WRITE(CB, I) do { const int g_ = gbase + 32 * (CB) + 2 * c; if (DBG == 3) { dbg_acc += d[CB][0][I] + d[CB][1][I]; } else if (g_ < F) *reinterpret_cast<d2x *>(tile + (q + 4 * (I)) * F + g_) = d2x{d[CB][0][I], d[CB][1][I]}; } while (0)
+#define PM_FENCE() __builtin_amdgcn_sched_barrier(0)
+      if (DBG == 1) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { d[0][0][0] += a[s]; d[CBW - 1][1][0] += ub[0][0][s] + ub[CBW - 1][1][s]; }
+#pragma unroll
+        for (int h = 0; h < NP / 4; ++h) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) PM_READ(4 * h + j);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) PM_STORE(4 * h + j);
+        }
+      } else {
+        // MFMA mi of 2 CBW KS (column block 0 first); fillers: pieces 4h..4h+3 are read after MFMAs 4h, 4h + 1 and
+        // stored after 4h + 2, 4h + 3; column block 0's LDS writes (CBW = 2) after MFMAs WR0.. (its last MFMA is
+        // 2 KS - 1)
+        constexpr int NM = 2 * CBW * KS;
+        constexpr int WR0 = (2 * KS + 1 > NP) ? 2 * KS + 1 : NP;
+#pragma unroll
+        for (int mi = 0; mi < NM; ++mi) {
+          const int cb = mi / (2 * KS), s = (mi % (2 * KS)) / 2, tt = mi % 2;
+          PM_MFMA(cb, tt, s);
+          PM_FENCE();
+          if (mi < NP) {
+            const int h = mi / 4, r = mi % 4;      // half h: reads at r = 0, 1, stores at r = 2, 3
+            if (r < 2) { PM_READ(4 * h + 2 * r); PM_READ(4 * h + 2 * r + 1); }
+            else { PM_STORE(4 * h + 2 * (r - 2)); PM_STORE(4 * h + 2 * (r - 2) + 1); }
+          } else if (CBW == 2 && mi >= WR0 && mi < WR0 + 4) { PM_WRITE(0, mi - WR0); }
+          PM_FENCE();
+        }
+        // what did not fit between the MFMAs (few k-steps), in the same order
+#pragma unroll
+        for (int sl = 0; sl < NP; ++sl) {
+          if (sl >= NM) {
+            const int h = sl / 4, r = sl % 4;
+            if (r < 2) { PM_READ(4 * h + 2 * r); PM_READ(4 * h + 2 * r + 1); }
+            else { PM_STORE(4 * h + 2 * (r - 2)); PM_STORE(4 * h + 2 * (r - 2) + 1); }
+          }
+        }
+        if (CBW == 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (WR0 + i >= NM) PM_WRITE(0, i);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) PM_WRITE(CBW - 1, i);
+#undef PM_MFMA
+#undef PM_READ
+#undef PM_STORE
+#undef PM_WRITE
+#undef PM_FENCE
+      if (DBG != 3) __syncthreads();
+      pend_dst = cov + (int64_t)b * F * F + (int64_t)f0 * F;
+      pend_n = DBG >= 2 ? 0 : nflat;
+      buf ^= 1;
+    }
+  }
+  {
+    const double *src = smem + (buf ^ 1) * tile_sz;
+    for (int e = 2 * (int)threadIdx.x; e < pend_n; e += 2 * NT)
+      *reinterpret_cast<d2x *>(pend_dst + e) = *reinterpret_cast<const d2x *>(src + e);
+  }
+  if (DBG >= 2 && smem[lane] + dbg_acc == -1.2345e300) pend_dst[0] = 0.0;
+}
+
+// central value (ref: emulation.py:508-509) for the matrix-core writer: cv[b][g] = (sum_p mean[b][p] S[p][g]) s_g + mean_g
+__global__ __launch_bounds__(256) void central_value_kernel(GpParts gp, const double *__restrict__ comp,
+                                                            const double *__restrict__ smean, const double *__restrict__ sscale,
+                                                            double *__restrict__ cv, int64_t B, int F, int k) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= F) return;
+  double cg[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) cg[p] = p < k ? comp[(int64_t)p * F + g] : 0.0;
+  const double sg = sscale[g], mg = smean[g];
+  for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+      if (p < k) sacc = fma(gp_mean_of(gp, b, p, k), cg[p], sacc);
+    cv[b * F + g] = sacc * sg + mg;
+  }
+}
+
+int launch_predict_full(gpemu_model *m, int64_t B, double n_div, double *dcv, double *dcov, hipStream_t st,
+                        const double *dmean, const double *dvar) {
   const int F = (int)m->F, k = (int)m->k;
-  const double *dmean = m->ws.mean, *dvar = m->ws.var;
   dim3 grid((unsigned)((F + PF_TG - 1) / PF_TG), (unsigned)((F + PF_TF - 1) / PF_TF),
             (unsigned)((B + PF_NB - 1) / PF_NB));
   size_t shm = sizeof(double) * (size_t)(k * (PF_TF + PF_TG) + k);
   // 16-byte stores need every row start of dcov 16-byte aligned: F even and an aligned base
   const bool pair = F % 2 == 0 && (reinterpret_cast<uintptr_t>(dcov) & 15) == 0;
   const size_t shm_rows = sizeof(double) * (size_t)(k * (PR_ROWS + PR_COLS) + k * PF_NB);
+  const bool no_mfma = getenv("GPEMU_PREDICT_VALU") != nullptr;   // the VALU writer, for comparison (read per call)
+  const GpParts parts{dmean, dvar, m->ws.mean_part, m->ws.vsq_part, m->kdiag, m->ws.cur_nchunk, m->ws.cur_nrb};
+  if (pair && k <= 16 && F <= 512 && !no_mfma) {
+    const int nrow = (F + 15) / 16, ngroups = (int)((B + PM_NB - 1) / PM_NB), total = nrow * ngroups;
+    const int ncu = (m->worker_limit > 0 && m->worker_limit < m->num_cu) ? m->worker_limit : m->num_cu;
+    const int workers = std::min(ncu, total);
+    const size_t shm_pm = sizeof(double) * (2 * 16 * (size_t)F + PM_NB * 16);
+    // 16 waves x 32 columns (GPEMU_PM_CBW=2: 8 waves x 64 columns, within 1 % on the whole chip, slower on a share)
+    static const int pm_cbw = getenv("GPEMU_PM_CBW") ? atoi(getenv("GPEMU_PM_CBW")) : 1;
+#define GP_LAUNCH_PM2(KSV, CB, DB)                                                                                 \
+  do {                                                                                                             \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      GP_HIP(hipFuncSetAttribute((const void *)predict_cov_mfma_kernel<KSV, CB, DB>,                               \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));                        \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    hipLaunchKernelGGL((predict_cov_mfma_kernel<KSV, CB, DB>), dim3((unsigned)workers), dim3(1024 / CB), shm_pm,   \
+                       st, parts, m->comp, m->sscale, m->cunexpl, dcov, B, F, k, 1.0 / n_div, ngroups, total);     \
+  } while (0)
+#define GP_LAUNCH_PM(KSV, DB)                                                                                      \
+  do {                                                                                                             \
+    if (pm_cbw == 2) GP_LAUNCH_PM2(KSV, 2, DB);                                                                    \
+    else GP_LAUNCH_PM2(KSV, 1, DB);                                                                                \
+  } while (0)
+    static const int pm_dbg = getenv("GPEMU_PM_DBG") ? atoi(getenv("GPEMU_PM_DBG")) : 0;
+    if (pm_dbg == 1) GP_LAUNCH_PM(3, 1);
+    else if (pm_dbg == 2) GP_LAUNCH_PM(3, 2);
+    else if (pm_dbg == 3) GP_LAUNCH_PM(3, 3);
+    else if (pm_dbg == 4) GP_LAUNCH_PM(3, 4);
+    else if (k <= 4) GP_LAUNCH_PM(1, 0);
+    else if (k <= 8) GP_LAUNCH_PM(2, 0);
+    else if (k <= 12) GP_LAUNCH_PM(3, 0);
+    else GP_LAUNCH_PM(4, 0);
+#undef GP_LAUNCH_PM2
+#undef GP_LAUNCH_PM
+    hipLaunchKernelGGL(central_value_kernel, dim3((unsigned)((F + 255) / 256), (unsigned)std::min<int64_t>(B, 256)), dim3(256),
+                       0, st, parts, m->comp, m->smean, m->sscale, dcv, B, F, k);
+    GP_HIP(hipGetLastError());
+    return GPEMU_OK;
+  }
+  if (!dmean || !dvar) {         // the VALU forms read arrays
+    const int rc_red = launch_reduce_mean_var(m, B, m->ws.mean, m->ws.var, st);
+    if (rc_red != GPEMU_OK) return rc_red;
+    dmean = m->ws.mean;
+    dvar = m->ws.var;
+  }
   if (shm_rows <= 64 * 1024) {   // whole rows per workgroup: contiguous store streams
     dim3 g2((unsigned)((F + PR_COLS - 1) / PR_COLS), (unsigned)((F + PR_ROWS - 1) / PR_ROWS),
             (unsigned)((B + PF_NB - 1) / PF_NB));

@@ -25,23 +25,6 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------
-__global__ void pad_queries_kernel(const double *__restrict__ X, double *__restrict__ Xq, int64_t B,
-                                   int64_t Bcap, int d) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Bcap * DPAD) return;
-  int64_t b = idx / DPAD;
-  int dd = (int)(idx % DPAD);
-  Xq[idx] = (b < B && dd < d) ? X[b * d + dd] : 0.0;
-}
-
-int launch_pad_queries(gpemu_model *m, int64_t B, const double *dX, hipStream_t st) {
-  int64_t n = m->ws.Bcap * DPAD;
-  hipLaunchKernelGGL(pad_queries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dX,
-                     m->ws.Xq, B, m->ws.Bcap, (int)m->d);
-  GP_HIP(hipGetLastError());
-  return GPEMU_OK;
-}
-
 // ------------------------------------------------------------------------------------------
 // base kernel value from the squared scaled distance r2 (skl kernels.py:1564-1565, 1715-1733)
 template <int KIND>  // 0 rbf, 1 matern 0.5, 2 matern 1.5, 3 matern 2.5
@@ -108,6 +91,16 @@ __global__ __launch_bounds__(256) void kstar_kernel(
 #pragma unroll
       for (int dd = 0; dd < DPAD; ++dd) Xq[b * DPAD + dd] = xq[dd];
       if (live) pa.factors[b] = (pa.d - 1.0) * log(z);
+    }
+#pragma unroll
+    for (int dd = 0; dd < DPAD; ++dd) xq[dd] = xq[dd] * inv_ls[p * DPAD + dd];
+  } else if (pa.raw) {
+    // caller rows [n][d]: padded on the fly, the padded row stored once
+#pragma unroll
+    for (int dd = 0; dd < DPAD; ++dd) xq[dd] = (b < pa.n && dd < pa.d) ? pa.raw[b * pa.d + dd] : 0.0;
+    if (chunk == 0 && p == 0 && wave == 0) {
+#pragma unroll
+      for (int dd = 0; dd < DPAD; ++dd) Xq[b * DPAD + dd] = xq[dd];
     }
 #pragma unroll
     for (int dd = 0; dd < DPAD; ++dd) xq[dd] = xq[dd] * inv_ls[p * DPAD + dd];
@@ -876,7 +869,8 @@ static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &
       }
   }
   std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.cost > b.cost; });
-  nworkers = m->num_cu < (int)items.size() ? m->num_cu : (int)items.size();
+  const int ncu = (m->worker_limit > 0 && m->worker_limit < m->num_cu) ? m->worker_limit : m->num_cu;
+  nworkers = ncu < (int)items.size() ? ncu : (int)items.size();
   std::vector<std::vector<TrmmItem>> per(nworkers);
   std::vector<double> load(nworkers, 0.0);
   // XCD-aware placement.  Workgroups are dispatched round-robin over the 8 XCDs (worker w runs on XCD w % 8),
@@ -887,7 +881,7 @@ static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &
   // that L2 -- and LPT runs within each XCD's workers.  Otherwise: plain LPT over all workers.
   const int nxcd = 8, ngroups = k * ncb;
   static const bool xcd_aware = getenv("GPEMU_TRMM_NO_XCD") == nullptr;
-  if (xcd_aware && nworkers == m->num_cu && nworkers % nxcd == 0 && ngroups % nxcd == 0) {
+  if (xcd_aware && nworkers == ncu && nworkers % nxcd == 0 && ngroups % nxcd == 0) {
     const int gper = ngroups / nxcd;
     for (const It &x : items) {
       const int g = x.it.p * ncb + x.it.col0 / TILE;
@@ -974,25 +968,32 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
     prof_pair(m, 0, pe0, prof_mark(m, st));
     return GPEMU_OK;
   }
-  if (m->sched_ncb != ncb) {
-    std::vector<TrmmItem> flat;
-    std::vector<int> cnt;
-    int max_items = 0, nworkers = 0;
-    build_trmm_schedule(m, ncb, flat, cnt, max_items, nworkers);
-    if (max_items > TRMM_MAX_ITEMS) {
-      set_error("triangular GEMM schedule needs %d items per worker (limit %d): batch too large for one launch",
-                max_items, TRMM_MAX_ITEMS);
-      return GPEMU_ERR_UNSUPPORTED;
+  const int cap = (m->worker_limit > 0 && m->worker_limit < m->num_cu) ? m->worker_limit : m->num_cu;
+  if (m->sched_ncb != ncb || m->sched_cap != cap) {
+    const gpemu_model::SchedEntry *hit = nullptr;
+    for (const auto &e : m->sched_cache)
+      if (e.ncb == ncb && e.cap == cap) hit = &e;
+    if (!hit) {
+      std::vector<TrmmItem> flat;
+      std::vector<int> cnt;
+      int max_items = 0, nworkers = 0;
+      build_trmm_schedule(m, ncb, flat, cnt, max_items, nworkers);
+      if (max_items > TRMM_MAX_ITEMS) {
+        set_error("triangular GEMM schedule needs %d items per worker (limit %d): batch too large for one launch",
+                  max_items, TRMM_MAX_ITEMS);
+        return GPEMU_ERR_UNSUPPORTED;
+      }
+      // schedules are kept (a few KB each): launches in flight keep reading the one they were given
+      gpemu_model::SchedEntry e{ncb, cap, nullptr, nullptr, max_items, nworkers};
+      GP_HIP(hipMalloc(&e.items, sizeof(TrmmItem) * flat.size()));
+      GP_HIP(hipMalloc((void **)&e.cnt, sizeof(int) * cnt.size()));
+      GP_HIP(hipMemcpy(e.items, flat.data(), sizeof(TrmmItem) * flat.size(), hipMemcpyHostToDevice));
+      GP_HIP(hipMemcpy(e.cnt, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice));
+      m->sched_cache.push_back(e);
+      hit = &m->sched_cache.back();
     }
-    GP_HIP(hipStreamSynchronize(st));
-    (void)hipFree(m->sched_items);
-    (void)hipFree(m->sched_cnt);
-    m->sched_items = nullptr; m->sched_cnt = nullptr; m->sched_ncb = -1;
-    GP_HIP(hipMalloc(&m->sched_items, sizeof(TrmmItem) * flat.size()));
-    GP_HIP(hipMalloc((void **)&m->sched_cnt, sizeof(int) * cnt.size()));
-    GP_HIP(hipMemcpy(m->sched_items, flat.data(), sizeof(TrmmItem) * flat.size(), hipMemcpyHostToDevice));
-    GP_HIP(hipMemcpy(m->sched_cnt, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice));
-    m->sched_ncb = ncb; m->sched_max_items = max_items; m->sched_workers = nworkers;
+    m->sched_items = hit->items; m->sched_cnt = hit->cnt;
+    m->sched_ncb = ncb; m->sched_cap = cap; m->sched_max_items = hit->max_items; m->sched_workers = hit->workers;
   }
   const int pe0 = prof_mark(m, st);
   static const bool use_dma = getenv("GPEMU_TRMM_NO_DMA") == nullptr;   // register-staged variant kept for comparison

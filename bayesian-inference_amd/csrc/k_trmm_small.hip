@@ -205,12 +205,13 @@ static void build_small_schedule(const gpemu_model *m, int ncb, std::vector<Smal
       for (int cb = 0; cb < ncb; ++cb) items.push_back({nt + ov, SmallItem{p, rb, cb * ST_N, 0}, p * ncb + cb});
   }
   std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.cost > b.cost; });
-  nworkers = m->num_cu < (int)items.size() ? m->num_cu : (int)items.size();
+  const int ncu = (m->worker_limit > 0 && m->worker_limit < m->num_cu) ? m->worker_limit : m->num_cu;
+  nworkers = ncu < (int)items.size() ? ncu : (int)items.size();
   std::vector<std::vector<SmallItem>> per(nworkers);
   std::vector<double> load(nworkers, 0.0);
   const int nxcd = 8, ngroups = k * ncb;
   static const bool xcd_aware = getenv("GPEMU_TRMM_NO_XCD") == nullptr;
-  const bool use_xcd = xcd_aware && nworkers == m->num_cu && nworkers % nxcd == 0 && ngroups >= nxcd;
+  const bool use_xcd = xcd_aware && nworkers == ncu && nworkers % nxcd == 0 && ngroups >= nxcd;
   const int whole = use_xcd ? (ngroups / nxcd) * nxcd : 0;     // groups [0, whole) live on one XCD each
   const int gper = use_xcd ? ngroups / nxcd : 1;
   for (const It &x : items) {
@@ -244,7 +245,8 @@ int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st) {
   Workspace &w = m->ws;
   const int nrb = (int)(m->Npad / ST_M);
   const int ncb = (int)(round_up(B, ST_N) / ST_N);
-  if (m->sm_ncb != ncb) {
+  const int cap = (m->worker_limit > 0 && m->worker_limit < m->num_cu) ? m->worker_limit : m->num_cu;
+  if (m->sm_ncb != ncb || m->sm_cap != cap) {
     std::vector<SmallItem> flat;
     std::vector<int> cnt;
     int max_items = 0, nworkers = 0;
@@ -258,7 +260,7 @@ int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st) {
     GP_HIP(hipMalloc((void **)&m->sm_cnt, sizeof(int) * cnt.size()));
     GP_HIP(hipMemcpy(m->sm_items, flat.data(), sizeof(SmallItem) * flat.size(), hipMemcpyHostToDevice));
     GP_HIP(hipMemcpy(m->sm_cnt, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice));
-    m->sm_ncb = ncb; m->sm_max_items = max_items; m->sm_workers = nworkers;
+    m->sm_ncb = ncb; m->sm_cap = cap; m->sm_max_items = max_items; m->sm_workers = nworkers;
   }
   w.cur_nrb = nrb;
   static const int dbg = getenv("GPEMU_SMALL_DBG") ? atoi(getenv("GPEMU_SMALL_DBG")) : 0;   // ablation switches

@@ -198,3 +198,34 @@ def test_pca_shape_sweep(N, F):
     Ys = (Y - mean) / scale
     rec = out["Y_pca"] @ out["components"] + out["pca_mean"]
     assert np.max(np.abs(rec - Ys)) < 1e-10 * max(1.0, np.max(np.abs(Ys)))
+
+
+@pytest.mark.parametrize("name,B", [("g2_rbf_noise", 300), ("g1_matern15_noise", 1027)])
+def test_predict_full_writer_forms_agree(name, B, monkeypatch):
+    """emulation.predict's covariance (ref: emulation.py:504-548) by the three device forms -- the matrix-core writer
+    (default for even F <= 512, k <= 16), the VALU writer it replaced (GPEMU_PREDICT_VALU) and the CU-partitioned
+    pipeline kept as a measured negative (GPEMU_PREDICT_SPLIT) -- against the oracle's per-sample loops, at batch sizes
+    that are no multiple of a sample group, a row block or a pipeline chunk."""
+    from gpemu import synthetic
+    g = GU.load(name)
+    model = GU.group_model(g)
+    dm = GU.device_model(model)
+    X = synthetic.make_walkers(B, seed=9, lo=g["lo"], hi=g["hi"])
+    ref = O.predict_group(X[:40], model, O.cov_unexplained(model) * (40.0 / B))     # / n_samples quirk: n = B
+    out = {}
+    for form, env in (("mfma", {}), ("valu", {"GPEMU_PREDICT_VALU": "1"}),
+                      ("pipeline", {"GPEMU_PREDICT_SPLIT": "16", "GPEMU_PREDICT_CHUNK": "128"})):
+        for key in ("GPEMU_PREDICT_VALU", "GPEMU_PREDICT_SPLIT", "GPEMU_PREDICT_CHUNK"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        cv, cov = dm.predict_full(X, n_div=float(B))
+        out[form] = (cv, cov)
+        scale = np.max(np.abs(ref["cov"]))
+        assert np.max(np.abs(cv[:40] - ref["central_value"])) < 1e-10 * np.max(np.abs(ref["central_value"])), form
+        assert np.max(np.abs(cov[:40] - ref["cov"])) < 1e-10 * scale, form
+        assert np.all(cov == np.swapaxes(cov, 1, 2)) or np.max(np.abs(cov - np.swapaxes(cov, 1, 2))) < 1e-13 * scale
+    for form in ("valu", "pipeline"):
+        np.testing.assert_allclose(out[form][0], out["mfma"][0], rtol=1e-12, atol=1e-13 * np.max(np.abs(out["mfma"][0])))
+        np.testing.assert_allclose(out[form][1], out["mfma"][1], rtol=1e-11, atol=1e-13 * np.max(np.abs(out["mfma"][1])))
+    dm.close()
