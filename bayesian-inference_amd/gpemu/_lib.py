@@ -121,6 +121,10 @@ def lib():
     """Load libgpemu.so once; raise if it has not been built."""
     global _lib
     if _lib is None:
+        # Sharing device memory across processes (the peer transport of the walker-sharded run: hipIpcGetMemHandle /
+        # hipIpcOpenMemHandle of the exchange buffers, and RCCL itself) needs dmabuf IPC on hosts whose driver has no
+        # legacy IPC: the runtime reads this when it initialises, i.e. before the first HIP call of the process.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         _preload_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise GpemuError(-100, f"{LIB_PATH} not found: build it with "

@@ -9,11 +9,15 @@ without scikit-learn.  All arithmetic runs on the device through libgpemu; there
 from __future__ import annotations
 
 import math
+import logging
 import os
+import time
 import warnings
 from operator import itemgetter
 
 import numpy as np
+
+logger = logging.getLogger(__name__)
 
 from . import fit as _fit
 from .model import DeviceModel
@@ -524,11 +528,15 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
         finally:
             evaluator.leave()
 
+    t_fit = time.perf_counter()
     try:
         if n_threads > 1 and optimise and _setulb_driver_ok():
             # one host thread drives all L-BFGS-B runs through the routine's reverse-communication interface
+            driver = "lockstep (scipy.optimize._lbfgsb.setulb, one host thread)"
             optima = _lockstep_minimise(shared, [(columns[i], starts[i][j]) for i, j in tasks], kk.bounds, n_threads)
         else:
+            driver = ("sequential (scipy.optimize.minimize)" if n_threads == 1 else
+                      f"threads ({n_threads} x scipy.optimize.minimize meeting in a lock-step evaluator)")
             with concurrent.futures.ThreadPoolExecutor(max_workers=n_threads) as pool:
                 optima = list(pool.map(run_start, tasks))
         per_gp = [[] for _ in range(k_gp)]
@@ -538,8 +546,16 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
             gprs[i]._adopt(shared, X, columns[i], per_gp[i])
     finally:
         n_eval = sum(h.n_evaluations for h in handles)
+        t_lib = sum(h.seconds_in_library for h in handles)
         for h in handles:
             h.close()
+    t_fit = time.perf_counter() - t_fit
+    # which L-BFGS-B driver ran (the fast one depends on a private scipy routine's signature) and where the time went
+    logger.info(f"fit_gps: {len(tasks)} L-BFGS-B runs for {k_gp} GPs, {n_eval} LML evaluations, driver: {driver}; "
+                f"{t_fit:.2f} s of which {t_lib:.2f} s inside libgpemu (device), {t_fit - t_lib:.2f} s in the optimiser "
+                f"on the host")
     for g in gprs:
         g.n_lml_evaluations_ = n_eval          # of the whole group fit (all GPs and restarts)
+        g.fit_driver_ = driver
+        g.fit_seconds_ = (t_fit, t_lib)        # (whole group fit, inside the library)
     return gprs

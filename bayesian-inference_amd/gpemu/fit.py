@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -32,6 +33,7 @@ class DeviceFit:
                                           float(jitter)))
         self._h = h
         self.n_evaluations = 0          # log-marginal-likelihood evaluations run through this handle
+        self.seconds_in_library = 0.0   # wall time inside the (synchronous) C calls: upload, launch chain, download
 
     def close(self):
         if getattr(self, "_h", None):
@@ -55,7 +57,10 @@ class DeviceFit:
         val = C.c_double()
         grad = np.empty(self.n_theta) if eval_gradient else None
         self.n_evaluations += 1
-        self._check(_lib.lib().gpemu_fit_lml(self._h, ptr(y), ptr(theta), self.n_theta, C.byref(val), ptr(grad)))
+        t0 = time.perf_counter()
+        rc = _lib.lib().gpemu_fit_lml(self._h, ptr(y), ptr(theta), self.n_theta, C.byref(val), ptr(grad))
+        self.seconds_in_library += time.perf_counter() - t0
+        self._check(rc)
         return (val.value, grad) if eval_gradient else val.value
 
     def lml_batch(self, ys, thetas, eval_gradient=True):
@@ -71,7 +76,10 @@ class DeviceFit:
         grad = np.empty((n, self.n_theta)) if eval_gradient else None
         info = np.zeros(n, dtype=np.int32)
         self.n_evaluations += n
-        check(_lib.lib().gpemu_fit_lml_batch(self._h, n, ptr(ys), ptr(thetas), self.n_theta, ptr(lml), ptr(grad), ptr(info)))
+        t0 = time.perf_counter()
+        rc = _lib.lib().gpemu_fit_lml_batch(self._h, n, ptr(ys), ptr(thetas), self.n_theta, ptr(lml), ptr(grad), ptr(info))
+        self.seconds_in_library += time.perf_counter() - t0
+        check(rc)
         return lml, grad, info
 
     def factor(self, y, theta):

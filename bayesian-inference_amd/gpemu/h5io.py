@@ -55,7 +55,7 @@ def _as_array(value):
     return arr if arr.flags.c_contiguous else arr.copy(order="C")       # (ascontiguousarray would turn 0-d into 1-d)
 
 
-def _datatype_message(dt):
+def _datatype_message(dt, utf8=False):
     if dt.kind == "f":
         size = dt.itemsize
         ebits, mbits, bias = {2: (5, 10, 15), 4: (8, 23, 127), 8: (11, 52, 1023)}[size]
@@ -65,7 +65,8 @@ def _datatype_message(dt):
         return (bytes([0x10, 0x08 if dt.kind == "i" else 0x00, 0, 0]) + struct.pack("<I", dt.itemsize) +
                 struct.pack("<HH", 0, dt.itemsize * 8))
     if dt.kind == "S":
-        return bytes([0x13, 0x01, 0, 0]) + struct.pack("<I", dt.itemsize)          # null padded, ASCII
+        # null padded; character set ASCII, or UTF-8 (bits 4-7 = 1) when the data hold non-ASCII bytes
+        return bytes([0x13, 0x11 if utf8 else 0x01, 0, 0]) + struct.pack("<I", dt.itemsize)
     raise TypeError(dt)
 
 
@@ -98,7 +99,8 @@ class _Writer:
         space = struct.pack("<BBB5x", 1, rank, 0) + b"".join(struct.pack("<Q", n) for n in arr.shape)
         # the array's own memory is written to the file later: no copy of a (possibly 500 MB) chain
         raw = memoryview(arr if arr.flags.c_contiguous else np.ascontiguousarray(arr)).cast("B") if arr.size else b""
-        msgs = [_message(0x0001, space), _message(0x0003, _datatype_message(arr.dtype), flags=1),
+        utf8 = arr.dtype.kind == "S" and arr.size > 0 and bool((np.frombuffer(arr.tobytes(), dtype=np.uint8) >= 0x80).any())
+        msgs = [_message(0x0001, space), _message(0x0003, _datatype_message(arr.dtype, utf8), flags=1),
                 _message(0x0005, bytes([2, 2, 2, 1]) + struct.pack("<I", 0), flags=1)]
         hdr_len = 16 + sum(len(m) for m in msgs) + 8 + 24
         addr = self.alloc(hdr_len)
@@ -234,7 +236,9 @@ class _Reader:
 
     def heap_name(self, heap_addr, off):
         seg = self.u("<Q", heap_addr + self.base + 24)[0] + self.base
-        end = self.b.index(b"\0", seg + off)
+        end = self.b.find(b"\0", seg + off)
+        if end < 0:
+            raise ValueError("corrupt local heap (unterminated name)")
         return bytes(self.b[seg + off:end]).decode("utf-8")
 
     def symbol_nodes(self, btree_addr):
@@ -320,12 +324,12 @@ class _Reader:
             if cls == 1:
                 addr, _size = struct.unpack_from("<QQ", layout, 2)
                 if addr == _UNDEF:
-                    raw = b"\0" * nbytes
+                    src, off = b"\0" * nbytes, 0
                 else:
-                    raw = self.b[addr + self.base:addr + self.base + nbytes]
+                    src, off = self.b, addr + self.base
             elif cls == 0:
                 csize = struct.unpack_from("<H", layout, 2)[0]
-                raw = layout[4:4 + csize][:nbytes]
+                src, off = layout[4:4 + csize][:nbytes], 0
             else:
                 raise NotImplementedError("chunked datasets are not supported by the built-in reader; install h5py")
         elif layout[0] in (1, 2):
@@ -333,10 +337,13 @@ class _Reader:
             if cls != 1:
                 raise NotImplementedError("only contiguous datasets are supported for layout versions 1-2")
             addr = struct.unpack_from("<Q", layout, 8)[0]
-            raw = self.b[addr + self.base:addr + self.base + nbytes]
+            src, off = self.b, addr + self.base
         else:
             raise NotImplementedError(f"data layout message version {layout[0]}")
-        arr = np.frombuffer(bytes(raw), dtype=dtype, count=count).reshape(shape)
+        if off + nbytes > len(src):
+            raise ValueError("dataset extends past the end of the file")
+        # a view on the mapped file, then ONE copy into memory the caller owns (byte order made native on the way)
+        arr = np.frombuffer(src, dtype=dtype, count=count, offset=off).reshape(shape)
         arr = arr.astype(dtype.newbyteorder("="), copy=True)
         if dtype.kind == "S" and arr.shape == ():
             return arr[()].decode("utf-8", "replace")
@@ -347,9 +354,13 @@ class _Reader:
 
 
 def _read_native(path):
+    """The file is mapped, not read: a 574 MB mcmc.h5 then costs its datasets once, not three times."""
+    import mmap
     with open(path, "rb") as f:
-        buf = f.read()
-    return _Reader(buf).read()
+        if os.fstat(f.fileno()).st_size == 0:
+            raise ValueError("not an HDF5 file (empty)")
+        with mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as buf:
+            return _Reader(buf).read()
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -386,8 +397,16 @@ def _h5py_read(h5py, group):
     return out
 
 
-def dicttoh5(treedict, h5file, **_ignored):
-    """``silx.io.dictdump.dicttoh5`` for the cases the reference needs: the file is (over)written."""
+def dicttoh5(treedict, h5file, h5path="/", mode="w", **_ignored):
+    """``silx.io.dictdump.dicttoh5`` for the cases the reference needs (ref: data_IO.py:232): the whole file is
+    (over)written from its root.  silx's other modes -- appending to a file, writing below a sub-path -- are refused
+    rather than silently turned into an overwrite."""
+    if h5path not in ("/", "", None):
+        raise NotImplementedError(f"dicttoh5(h5path={h5path!r}): only the file's root is supported by gpemu.h5io")
+    if mode not in ("w", "w-", "x"):
+        raise NotImplementedError(f"dicttoh5(mode={mode!r}): only (over)writing a whole file is supported by gpemu.h5io")
+    if mode in ("w-", "x") and os.path.exists(os.fspath(h5file)):
+        raise FileExistsError(os.fspath(h5file))
     h5py = _h5py()
     if h5py is not None:
         with h5py.File(h5file, "w") as f:

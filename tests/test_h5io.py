@@ -107,3 +107,28 @@ def test_reference_data_io_tests_pass_through_the_shim(tmp_path):
                           text=True, timeout=600)
     assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-2000:]
     assert " passed" in done.stdout and "failed" not in done.stdout
+
+
+def test_unsupported_silx_modes_are_refused_and_utf8_round_trips(tmp_path):
+    """``dicttoh5`` must not turn silx's append / sub-path modes into a silent overwrite; non-ASCII strings
+    carry the UTF-8 character-set flag and come back unchanged; reading maps the file instead of copying it."""
+    import pytest
+    from gpemu import h5io
+    path = tmp_path / "t.h5"
+    tree = {"label": "q̂/T³ — ünïcode", "plain": "ascii", "x": np.arange(6.0).reshape(2, 3), "g": {"n": np.int64(3)}}
+    h5io.dicttoh5(tree, str(path))
+    back = h5io.h5todict(str(path))
+    assert back["label"] == tree["label"] and back["plain"] == "ascii"
+    np.testing.assert_array_equal(back["x"], tree["x"])
+    assert back["x"].flags.owndata or back["x"].base is None or not hasattr(back["x"].base, "closed")
+    assert int(back["g"]["n"]) == 3
+    raw = path.read_bytes()
+    assert bytes([0x13, 0x11]) in raw and bytes([0x13, 0x01]) in raw      # one UTF-8 and one ASCII string datatype
+    with pytest.raises(NotImplementedError):
+        h5io.dicttoh5(tree, str(path), mode="a")
+    with pytest.raises(NotImplementedError):
+        h5io.dicttoh5(tree, str(path), h5path="/sub/group")
+    with pytest.raises(FileExistsError):
+        h5io.dicttoh5(tree, str(path), mode="w-")
+    h5io.dicttoh5({"x": np.zeros(2)}, str(path), h5path="/", mode="w")       # the reference's call
+    assert set(h5io.h5todict(str(path))) == {"x"}
