@@ -1,9 +1,10 @@
 // Fused stretch-move run: TWO launches per half-step instead of four plus a collective.
 //
-// Replaces, for a single emulation group with k <= 16 PCs, the per-half-step chain
+// Replaces, for up to 8 emulation groups of up to 64 PCs each (the shipped analysis has three, with 5 / 11 / 25 PCs:
+// ref: config/jet_substructure.yaml:243-278), the per-half-step chain
 //     kstar (+proposal) -> triangular GEMM -> likelihood -> [all-gather] -> accept
 // of k_sampler.hip (ref: mcmc.py:77-107 -> emcee RedBlueMove / StretchMove, the pool.map over walkers) by
-//     front kernel  ->  triangular GEMM
+//     front kernel  ->  triangular GEMM (one per group)
 // where ONE front launch does, for the half-step BEFORE the one it opens:
 //     (A) the low-rank log-likelihood of this rank's share of that half's proposals (a few workgroups, first);
 //     (B) the exchange: each new log-probability is stored -- one 8-byte system-scope store per value and rank --
@@ -27,14 +28,27 @@ namespace gpemu {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-struct FrontArgs {
-  // GP model: cross-kernel of the half being opened
+constexpr int FRONT_MAX_GROUPS = 8;
+
+struct FrontGroup {
+  // cross-kernel of the half being opened
   const double *Xs, *inv_ls, *constv, *alpha;
   double *KS, *mean_part_next;
+  // likelihood of the half before
+  const double *mean_part_prev, *vsq_part, *kdiag, *G, *g0, *scal;
   int64_t N, Npad, Bcap;
-  int has_const, kind, k, d, W;
-  int nchunk, ncolblk;                 // cross-kernel workgroups: (column block, row chunk, PC), nkstar of them
-  int nkstar, nks;                     // nks = max(nkstar, likelihood workgroups): the state workgroups follow
+  int has_const, kind, k;
+  int nchunk, wg0;                     // this group's cross-kernel workgroups: [wg0, wg0 + ncolblk * nchunk * k)
+  int nchunk_prev, nrb_prev, nblk;
+};
+
+struct FrontArgs {
+  FrontGroup grp[FRONT_MAX_GROUPS];
+  int ngroups;
+  int lds_k;                           // largest k > 16 among the groups (0: none): that likelihood's matrix is in LDS
+  int d, W;
+  int ncolblk;                         // cross-kernel workgroups per group: (column block, row chunk, PC)
+  int nkstar, nks;                     // all groups' / nks = max(nkstar, likelihood workgroups): the state workgroups follow
   // the half being opened: this rank's share of its proposals (pointers already offset to the share)
   int have_next, next_cnt;
   const int *idx_next, *partner_next;
@@ -44,8 +58,7 @@ struct FrontArgs {
   int have_prev, hp, prev_n, prev_lo, prev_cnt, n_llwg;
   const int *inds_prev, *pos_prev, *partner_prev;   // [W], [W], [prev_n]
   const double *zz_prev, *fac_prev, *logu_prev;     // [prev_n]
-  const double *Xq_prev, *mean_part_prev, *vsq_part, *kdiag, *G, *g0, *scal, *lo, *hi;
-  int nchunk_prev, nrb_prev, nblk;
+  const double *Xq_prev, *lo, *hi;
   const double *gath;                  // this rank's gather slot of that half: [prev_n]
   double *const *peers;                // every rank's gather buffer
   int world;
@@ -154,21 +167,32 @@ __device__ __forceinline__ void state_after_prev(const FrontArgs &fa, int x, dou
   lp = acc ? nlp : oldlp;
 }
 
+// one group's low-rank log-likelihood of proposal b (a wave per proposal), k <= 16: the arithmetic of
+// loglik_lowrank_kernel<KMAX>
 template <int KMAX>
-__device__ __forceinline__ double front_loglik(const FrontArgs &fa, int64_t b, int lane) {
+__device__ __forceinline__ double front_loglik(const FrontGroup &gr, bool inside, int64_t b, int lane) {
   double gpre[KMAX];
 #pragma unroll
-  for (int q = 0; q < KMAX; ++q) gpre[q] = (q < fa.k && lane < fa.k) ? fa.G[q * fa.k + lane] : 0.0;
-  const double gl_pre = (lane < fa.k) ? fa.g0[lane] : 0.0;
-  const double sc0_pre = fa.scal[0], sc1_pre = fa.scal[1];
-  bool in = true;
-  if (lane < fa.d) in = (fa.Xq_prev[b * DPAD + lane] > fa.lo[lane]) && (fa.Xq_prev[b * DPAD + lane] < fa.hi[lane]);
-  const bool inside = __all(in);
+  for (int q = 0; q < KMAX; ++q) gpre[q] = (q < gr.k && lane < gr.k) ? gr.G[q * gr.k + lane] : 0.0;
+  const double gl_pre = (lane < gr.k) ? gr.g0[lane] : 0.0;
+  const double sc0_pre = gr.scal[0], sc1_pre = gr.scal[1];
   double mu, sd;
-  walker_mean_sd<16>(fa.mean_part_prev, fa.vsq_part, fa.kdiag, nullptr, nullptr, b, fa.Bcap, fa.k, fa.nchunk_prev,
-                     fa.nrb_prev, lane, mu, sd);
-  return walker_loglik_lowrank<KMAX>(inside, mu, sd, gpre, gl_pre, sc0_pre, sc1_pre, fa.G, fa.g0, fa.scal, fa.k,
-                                     fa.nblk, lane);
+  walker_mean_sd<16>(gr.mean_part_prev, gr.vsq_part, gr.kdiag, nullptr, nullptr, b, gr.Bcap, gr.k, gr.nchunk_prev,
+                     gr.nrb_prev, lane, mu, sd);
+  return walker_loglik_lowrank<KMAX>(inside, mu, sd, gpre, gl_pre, sc0_pre, sc1_pre, gr.G, gr.g0, gr.scal, gr.k,
+                                     gr.nblk, lane);
+}
+
+// 16 < k <= 64: the arithmetic of loglik_lowrank_lds_kernel, the wave's k x (k + 1) matrix in `M`
+__device__ __forceinline__ double front_loglik_lds(const FrontGroup &gr, bool inside, int64_t b, int lane, double *M) {
+  double mu, sd;
+  if (gr.k <= 32)
+    walker_mean_sd<32>(gr.mean_part_prev, gr.vsq_part, gr.kdiag, nullptr, nullptr, b, gr.Bcap, gr.k, gr.nchunk_prev,
+                       gr.nrb_prev, lane, mu, sd);
+  else
+    walker_mean_sd<64>(gr.mean_part_prev, gr.vsq_part, gr.kdiag, nullptr, nullptr, b, gr.Bcap, gr.k, gr.nchunk_prev,
+                       gr.nrb_prev, lane, mu, sd);
+  return walker_loglik_lowrank_lds(inside, mu, sd, gr.G, gr.g0, gr.scal, gr.k, gr.nblk, lane, M, gr.k + 1);
 }
 
 // rows of K_*^T for this wave's RPW training rows and the workgroup's 64 query columns (kstar_kernel's loop)
@@ -200,6 +224,7 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs fa) {
   __shared__ double s_al[4 * RPW];
   __shared__ double s_eff[2][64][DPAD];
   __shared__ double red[4][64];
+  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];   // [4 waves][lds_k (lds_k + 1)]: likelihood, k > 16
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = blockIdx.x;
@@ -229,11 +254,17 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs fa) {
     return;
   }
 
-  // ---- cross-kernel workgroups ----
-  const int cb = g % fa.ncolblk;
-  const int rest = g / fa.ncolblk;
-  const int chunk = rest % fa.nchunk;
-  const int p = rest / fa.nchunk;
+  // ---- cross-kernel workgroups: (group, PC, row chunk, column block) ----
+  int gi = 0;
+#pragma unroll
+  for (int t = 1; t < FRONT_MAX_GROUPS; ++t)
+    if (t < fa.ngroups && g >= fa.grp[t].wg0) gi = t;
+  const FrontGroup &gk = fa.grp[gi];
+  const int gl = g - gk.wg0;
+  const int cb = gl % fa.ncolblk;
+  const int rest = gl / fa.ncolblk;
+  const int chunk = rest % gk.nchunk;
+  const int p = rest / gk.nchunk;
   const int64_t b = (int64_t)cb * 64 + lane;
   const int64_t jb0 = (int64_t)chunk * (4 * RPW);
 
@@ -244,24 +275,34 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs fa) {
   double al_stage = 0.0;
   const bool does_kstar = fa.have_next && g < fa.nkstar;
   if (does_kstar) {
-    const d2 *xsrc = reinterpret_cast<const d2 *>(fa.Xs + ((int64_t)p * fa.Npad + jb0) * DPAD);
+    const d2 *xsrc = reinterpret_cast<const d2 *>(gk.Xs + ((int64_t)p * gk.Npad + jb0) * DPAD);
 #pragma unroll
     for (int t = 0; t < PER_T; ++t) {
       const int idx = threadIdx.x + 256 * t;
       stage[t] = (idx < NPAIR) ? xsrc[idx] : d2{0.0, 0.0};
     }
-    if (threadIdx.x < 4 * RPW) al_stage = fa.alpha[(int64_t)p * fa.Npad + jb0 + threadIdx.x];
+    if (threadIdx.x < 4 * RPW) al_stage = gk.alpha[(int64_t)p * gk.Npad + jb0 + threadIdx.x];
   }
 
   // (A) + (B): likelihood of the previous half's proposals of this rank (first workgroups), stored to every rank
   if (fa.have_prev && g < fa.n_llwg) {
     const int i = g * 4 + wave;
     if (i < fa.prev_cnt) {
-      double total;
-      if (fa.k <= 4) total = front_loglik<4>(fa, i, lane);
-      else if (fa.k <= 8) total = front_loglik<8>(fa, i, lane);
-      else if (fa.k <= 12) total = front_loglik<12>(fa, i, lane);
-      else total = front_loglik<16>(fa, i, lane);
+      bool in = true;
+      if (lane < fa.d) in = (fa.Xq_prev[(int64_t)i * DPAD + lane] > fa.lo[lane]) && (fa.Xq_prev[(int64_t)i * DPAD + lane] < fa.hi[lane]);
+      const bool inside = __all(in);
+      // the groups' log-likelihoods, added in the order the single-GPU run accumulates them (lp_g + sum so far)
+      double total = 0.0;
+      for (int t = 0; t < fa.ngroups; ++t) {
+        const FrontGroup &gr = fa.grp[t];
+        double lp;
+        if (gr.k <= 4) lp = front_loglik<4>(gr, inside, i, lane);
+        else if (gr.k <= 8) lp = front_loglik<8>(gr, inside, i, lane);
+        else if (gr.k <= 12) lp = front_loglik<12>(gr, inside, i, lane);
+        else if (gr.k <= 16) lp = front_loglik<16>(gr, inside, i, lane);
+        else lp = front_loglik_lds(gr, inside, i, lane, dyn_lds + (size_t)wave * fa.lds_k * (fa.lds_k + 1));
+        total = (t == 0) ? lp : lp + total;
+      }
       if (lane < fa.world)
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(fa.peers[lane] + fa.slot_off + fa.prev_lo + i),
                            (unsigned long long)__double_as_longlong(total), __ATOMIC_RELAXED,
@@ -311,31 +352,31 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs fa) {
       }
       xq[dd] = v;
     }
-    if (chunk == 0 && p == 0 && wave == 0) {
+    if (gi == 0 && chunk == 0 && p == 0 && wave == 0) {
 #pragma unroll
       for (int dd = 0; dd < DPAD; ++dd) fa.Xq_next[b * DPAD + dd] = xq[dd];
     }
 #pragma unroll
-    for (int dd = 0; dd < DPAD; ++dd) xq[dd] = xq[dd] * fa.inv_ls[p * DPAD + dd];
+    for (int dd = 0; dd < DPAD; ++dd) xq[dd] = xq[dd] * gk.inv_ls[p * DPAD + dd];
   }
-  const double c = fa.has_const ? fa.constv[p] : 0.0;
+  const double c = gk.has_const ? gk.constv[p] : 0.0;
 
   const int64_t jbase = jb0 + wave * RPW;
   const double *xs = s_xs + wave * RPW * DPAD;
   const double *al = s_al + wave * RPW;
-  double *ks = fa.KS + ((int64_t)p * fa.Npad + jbase) * fa.Bcap + b;
+  double *ks = gk.KS + ((int64_t)p * gk.Npad + jbase) * gk.Bcap + b;
   double macc;
-  switch (fa.kind) {
-    case 0: macc = front_kstar_rows<0, RPW>(xq, xs, al, s_tab, c, jbase, fa.N, ks, fa.Bcap); break;
-    case 1: macc = front_kstar_rows<1, RPW>(xq, xs, al, s_tab, c, jbase, fa.N, ks, fa.Bcap); break;
-    case 2: macc = front_kstar_rows<2, RPW>(xq, xs, al, s_tab, c, jbase, fa.N, ks, fa.Bcap); break;
-    default: macc = front_kstar_rows<3, RPW>(xq, xs, al, s_tab, c, jbase, fa.N, ks, fa.Bcap); break;
+  switch (gk.kind) {
+    case 0: macc = front_kstar_rows<0, RPW>(xq, xs, al, s_tab, c, jbase, gk.N, ks, gk.Bcap); break;
+    case 1: macc = front_kstar_rows<1, RPW>(xq, xs, al, s_tab, c, jbase, gk.N, ks, gk.Bcap); break;
+    case 2: macc = front_kstar_rows<2, RPW>(xq, xs, al, s_tab, c, jbase, gk.N, ks, gk.Bcap); break;
+    default: macc = front_kstar_rows<3, RPW>(xq, xs, al, s_tab, c, jbase, gk.N, ks, gk.Bcap); break;
   }
   red[wave][lane] = macc;
   __syncthreads();
   if (wave == 0) {
     const double sum = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    fa.mean_part_next[(b * fa.k + p) * fa.nchunk + chunk] = sum;
+    gk.mean_part_next[(b * gk.k + p) * gk.nchunk + chunk] = sum;
   }
   if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 4] = __builtin_amdgcn_s_memrealtime();
 }
@@ -395,12 +436,44 @@ static int peer_timeout_polls() {        // read per launch: a getenv, nothing n
   return (int)(ms * 1000.0 / 3.5);
 }
 
+// Workgroups of a front launch wait on each other (the state and cross-kernel workgroups on the likelihood workgroups
+// of every rank), so all of them must be resident at once: LDS per workgroup (static ~20 KB + the k > 16 likelihood's
+// matrices) and 4 waves each bound how many fit on a CU.
+static int front_lds_k(const gpemu_sampler *s) {
+  int lds_k = 0;
+  for (const gpemu_model *m : s->groups)
+    if (m->k > 16) lds_k = std::max(lds_k, (int)m->k);
+  return lds_k;
+}
+static int64_t front_capacity(const gpemu_sampler *s) {
+  const int lds_k = front_lds_k(s);
+  const int64_t lds = 20 * 1024 + (int64_t)4 * 8 * lds_k * (lds_k + 1);
+  const int64_t per_cu = std::min<int64_t>(8, (160 * 1024) / lds);
+  return per_cu * s->groups[0]->num_cu;
+}
+// workgroups a front launch needs for `cnt` proposals of this rank
+static int64_t front_grid(const gpemu_sampler *s, int64_t cnt) {
+  const int rows_per_wg = cnt <= 256 ? 32 : 128;
+  const int64_t ncolblk = ((cnt <= 64) ? 64 : round_up(cnt, TILE)) / 64;
+  int64_t nkstar = 0;
+  for (const gpemu_model *m : s->groups) nkstar += ncolblk * (m->Npad / rows_per_wg) * m->k;
+  const int64_t n_llwg = (s->ns[0] + 3) / 4;                  // at most: the whole half on one rank
+  return std::max(nkstar, std::min<int64_t>(n_llwg, (cnt + 3) / 4 + 1)) + (s->W + 255) / 256 + 1;
+}
+
 bool front_eligible(const gpemu_sampler *s) {
   static const bool off = getenv("GPEMU_NO_FUSED") != nullptr;
-  if (off || s->groups.size() != 1 || s->nchains != 1) return false;
-  const gpemu_model *m = s->groups[0];
-  if (m->k > 16 || s->W > 2048) return false;       // every workgroup of a launch must be resident (they wait on each other)
+  if (off || s->groups.empty() || (int)s->groups.size() > FRONT_MAX_GROUPS || s->nchains != 1) return false;
+  for (const gpemu_model *m : s->groups)
+    if (m->k > 64 || m->device != s->groups[0]->device) return false;
   return true;
+}
+
+// can `cnt` proposals per rank and half run fused (every workgroup resident)?
+static bool front_fits(const gpemu_sampler *s, int64_t cnt) { return front_grid(s, std::max<int64_t>(cnt, 1)) <= front_capacity(s); }
+
+bool front_eligible_for(const gpemu_sampler *s, int world) {
+  return front_eligible(s) && front_fits(s, (s->ns[0] + world - 1) / std::max(world, 1));
 }
 
 struct Pending {                    // the half whose likelihood / accept is still to be done
@@ -408,7 +481,7 @@ struct Pending {                    // the half whose likelihood / accept is sti
   int h = 0;
   size_t slot = 0;                  // randomness ring slot of its step
   int64_t lo = 0, cnt = 0;
-  int nchunk = 0, nrb = 0;
+  int nchunk[FRONT_MAX_GROUPS] = {0}, nrb[FRONT_MAX_GROUPS] = {0};   // per group: chunks / row blocks of its partial sums
   int parity = 0;                   // which q2 / mean_part buffer its proposals and partial means are in
 };
 
@@ -420,25 +493,42 @@ static void share_of(const gpemu_sampler *s, int h, int world, int rank, int64_t
 
 static int launch_front(gpemu_sampler *s, const Pending &pv, bool have_next, int h, int64_t lo, int64_t cnt,
                         int world, bool emulate, int store_row, Pending &out) {
-  gpemu_model *m = s->groups[0];
-  Workspace &w = m->ws;
+  gpemu_model *m0 = s->groups[0];
   hipStream_t st = s->stream;
   const int64_t W = s->W;
+  const int ng = (int)s->groups.size();
   FrontArgs fa;
   memset(&fa, 0, sizeof(fa));
   const int parity = (int)(s->front_count & 1);
-  fa.Xs = m->Xs; fa.inv_ls = m->inv_ls; fa.constv = m->constv; fa.alpha = m->alpha;
-  fa.KS = w.KS;
-  fa.mean_part_next = parity ? w.mean_part2 : w.mean_part;
-  fa.N = m->N; fa.Npad = m->Npad; fa.Bcap = w.Bcap;
-  fa.has_const = m->has_const; fa.k = (int)m->k; fa.d = (int)s->d; fa.W = (int)W;
-  fa.kind = 0;
-  if (m->kernel_kind == GPEMU_KERNEL_MATERN) fa.kind = (m->nu == 0.5) ? 1 : (m->nu == 1.5 ? 2 : 3);
+  fa.ngroups = ng;
+  fa.lds_k = front_lds_k(s);
+  fa.d = (int)s->d; fa.W = (int)W;
   const bool small = cnt <= 256;
   const int rows_per_wg = small ? 32 : 128;
-  fa.nchunk = (int)(m->Npad / rows_per_wg);
   const int64_t ncols = (cnt <= 64) ? 64 : round_up(cnt, TILE);
   fa.ncolblk = (int)(ncols / 64);
+  int wg = 0;
+  for (int g = 0; g < ng; ++g) {
+    gpemu_model *m = s->groups[g];
+    Workspace &w = m->ws;
+    FrontGroup &fg = fa.grp[g];
+    fg.Xs = m->Xs; fg.inv_ls = m->inv_ls; fg.constv = m->constv; fg.alpha = m->alpha;
+    fg.KS = w.KS;
+    fg.mean_part_next = parity ? w.mean_part2 : w.mean_part;
+    fg.N = m->N; fg.Npad = m->Npad; fg.Bcap = w.Bcap;
+    fg.has_const = m->has_const; fg.k = (int)m->k;
+    fg.kind = 0;
+    if (m->kernel_kind == GPEMU_KERNEL_MATERN) fg.kind = (m->nu == 0.5) ? 1 : (m->nu == 1.5 ? 2 : 3);
+    fg.nchunk = (int)(m->Npad / rows_per_wg);
+    fg.wg0 = wg;
+    if (have_next) wg += fa.ncolblk * fg.nchunk * fg.k;
+    if (pv.have) {
+      fg.mean_part_prev = pv.parity ? w.mean_part2 : w.mean_part;
+      fg.vsq_part = w.vsq_part; fg.kdiag = m->kdiag; fg.G = m->G; fg.g0 = m->g0; fg.scal = m->scal;
+      fg.nchunk_prev = pv.nchunk[g]; fg.nrb_prev = pv.nrb[g]; fg.nblk = (int)m->nblk;
+    }
+  }
+  fa.nkstar = wg;
   fa.have_next = have_next ? 1 : 0;
   if (have_next) {
     const size_t o2 = s->step_counter % RNG_RING * 2 * W;
@@ -462,10 +552,7 @@ static int launch_front(gpemu_sampler *s, const Pending &pv, bool have_next, int
     fa.fac_prev = s->fac + o2 + pv.h * W;
     fa.logu_prev = s->logu + o2 + pv.h * W;
     fa.Xq_prev = s->q2 + (size_t)pv.parity * s->qcap * DPAD;
-    fa.mean_part_prev = pv.parity ? w.mean_part2 : w.mean_part;
-    fa.vsq_part = w.vsq_part; fa.kdiag = m->kdiag; fa.G = m->G; fa.g0 = m->g0; fa.scal = m->scal;
-    fa.lo = m->lo; fa.hi = m->hi;
-    fa.nchunk_prev = pv.nchunk; fa.nrb_prev = pv.nrb; fa.nblk = (int)m->nblk;
+    fa.lo = m0->lo; fa.hi = m0->hi;
     // the previous half's values live in slot (front_count - 1) % GATHER_SLOTS
     const int slot = (int)((s->front_count + GATHER_SLOTS - 1) % GATHER_SLOTS);
     fa.slot_off = (int64_t)slot * s->ns[0];
@@ -473,7 +560,6 @@ static int launch_front(gpemu_sampler *s, const Pending &pv, bool have_next, int
     fa.peers = s->peers;
     fa.world = emulate ? 1 : world;
   }
-  fa.nkstar = have_next ? fa.ncolblk * fa.nchunk * fa.k : 0;
   fa.nks = std::max(fa.nkstar, fa.n_llwg);
   fa.Xcur = s->Xbuf + (size_t)s->cur * W * DPAD;
   fa.lpcur = s->lpbuf + (size_t)s->cur * W;
@@ -509,11 +595,25 @@ static int launch_front(gpemu_sampler *s, const Pending &pv, bool have_next, int
     GP_HIP(hipMemset(dstamps, 0, sizeof(unsigned long long) * 8 * 4096));
   }
   fa.stamps = (stamp_path && grid.x <= 4096) ? dstamps : nullptr;
-  const int pe0 = prof_mark(m, st);
-  if (small) hipLaunchKernelGGL((front_kernel<8>), grid, block, 0, st, fa);
-  else hipLaunchKernelGGL((front_kernel<32>), grid, block, 0, st, fa);
+  const size_t dyn = sizeof(double) * 4 * (size_t)fa.lds_k * (fa.lds_k + 1);
+  if (dyn > 40 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      GP_HIP(hipFuncSetAttribute((const void *)front_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+      GP_HIP(hipFuncSetAttribute((const void *)front_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+      attr_set = true;
+    }
+  }
+  if ((int64_t)grid.x > front_capacity(s)) {
+    set_error("fused front launch of %u workgroups exceeds what can be resident at once (%lld)", grid.x,
+              (long long)front_capacity(s));
+    return GPEMU_ERR_UNSUPPORTED;
+  }
+  const int pe0 = prof_mark(m0, st);
+  if (small) hipLaunchKernelGGL((front_kernel<8>), grid, block, dyn, st, fa);
+  else hipLaunchKernelGGL((front_kernel<32>), grid, block, dyn, st, fa);
   GP_HIP(hipGetLastError());
-  prof_pair(m, 1, pe0, prof_mark(m, st));
+  prof_pair(m0, 1, pe0, prof_mark(m0, st));
   if (fa.stamps && ++stamp_calls == 400) {
     GP_HIP(hipStreamSynchronize(st));
     std::vector<unsigned long long> hst(8 * (size_t)grid.x);
@@ -538,17 +638,20 @@ static int launch_front(gpemu_sampler *s, const Pending &pv, bool have_next, int
   out = Pending();
   if (have_next) {
     out.have = true; out.h = h; out.slot = s->step_counter % RNG_RING;
-    out.lo = lo; out.cnt = cnt; out.nchunk = fa.nchunk; out.parity = parity;
-    w.cur_nchunk = fa.nchunk;
+    out.lo = lo; out.cnt = cnt; out.parity = parity;
+    for (int g = 0; g < ng; ++g) {
+      out.nchunk[g] = fa.grp[g].nchunk;
+      s->groups[g]->ws.cur_nchunk = fa.grp[g].nchunk;
+    }
   }
   s->front_count += 1;
   return GPEMU_OK;
 }
 
 int front_run(gpemu_sampler *s, int64_t steps, int store_chain, int world, int rank, bool emulate) {
-  gpemu_model *m = s->groups[0];
   hipStream_t st = s->stream;
-  if (!m->lik_ready) { set_error("gpemu_likelihood_setup has not been called"); return GPEMU_ERR_STATE; }
+  for (gpemu_model *m : s->groups)
+    if (!m->lik_ready) { set_error("gpemu_likelihood_setup has not been called"); return GPEMU_ERR_STATE; }
   int rc = ensure_gather(s);
   if (rc != GPEMU_OK) return rc;
   if (world == 1 || emulate) {
@@ -560,8 +663,15 @@ int front_run(gpemu_sampler *s, int64_t steps, int store_chain, int world, int r
   }
   int64_t lo[2], cnt[2];
   for (int h = 0; h < 2; ++h) share_of(s, h, world, emulate ? 0 : rank, lo[h], cnt[h]);
-  rc = ensure_workspace(m, std::max<int64_t>(std::max(cnt[0], cnt[1]), 1));
-  if (rc != GPEMU_OK) return rc;
+  if (!front_fits(s, std::max(cnt[0], cnt[1]))) {
+    set_error("the fused run cannot keep every workgroup of a launch resident for %lld proposals per rank over %d group(s)",
+              (long long)std::max(cnt[0], cnt[1]), (int)s->groups.size());
+    return GPEMU_ERR_UNSUPPORTED;
+  }
+  for (gpemu_model *m : s->groups) {
+    rc = ensure_workspace(m, std::max<int64_t>(std::max(cnt[0], cnt[1]), 1));
+    if (rc != GPEMU_OK) return rc;
+  }
   if (emulate) {
     // proposals nobody evaluates carry -inf (rejected); the share that IS evaluated starts as "not arrived"
     const int64_t n = GATHER_SLOTS * s->ns[0];
@@ -587,9 +697,11 @@ int front_run(gpemu_sampler *s, int64_t steps, int store_chain, int world, int r
       if (cnt[h] > 0) {
         rc = launch_front(s, pend, true, h, lo[h], cnt[h], world, emulate, row, next);
         if (rc != GPEMU_OK) return rc;
-        rc = launch_trmm_vsq(m, cnt[h], st);
-        if (rc != GPEMU_OK) return rc;
-        next.nrb = m->ws.cur_nrb;
+        for (size_t g = 0; g < s->groups.size(); ++g) {
+          rc = launch_trmm_vsq(s->groups[g], cnt[h], st);
+          if (rc != GPEMU_OK) return rc;
+          next.nrb[g] = s->groups[g]->ws.cur_nrb;
+        }
       } else {
         // this rank has no proposal in this half (more ranks than proposals): likelihood / accept only
         rc = launch_front(s, pend, false, h, 0, 0, world, emulate, row, next);
@@ -652,6 +764,11 @@ int gpemu_sampler_peer_export(gpemu_sampler *s, char *handle_out64) {
 int gpemu_sampler_peer_import(gpemu_sampler *s, int world, int rank, const char *handles) {
   GP_ARG(s && handles && world >= 1 && world <= 64 && rank >= 0 && rank < world, "world / rank / handles");
   GP_HIP(hipSetDevice(s->device));
+  if (!front_eligible_for(s, world)) {
+    set_error("the fused run cannot take this sampler at %d rank(s): at most %d groups of at most 64 PCs, one chain, and "
+              "every workgroup of a launch resident at once", world, FRONT_MAX_GROUPS);
+    return GPEMU_ERR_UNSUPPORTED;
+  }
   int rc = ensure_gather(s);
   if (rc != GPEMU_OK) return rc;
   GP_HIP(hipStreamSynchronize(s->stream));
@@ -708,7 +825,7 @@ int gpemu_sampler_run_peer(gpemu_sampler *s, int64_t steps, int store_chain) {
   GP_ARG(s && steps >= 0, "sampler / steps");
   GP_HIP(hipSetDevice(s->device));
   if (!front_eligible(s)) {
-    set_error("the fused run needs one emulation group with at most 16 PCs and at most 2048 walkers");
+    set_error("the fused run needs at most %d emulation groups of at most 64 PCs, one chain", FRONT_MAX_GROUPS);
     return GPEMU_ERR_UNSUPPORTED;
   }
   if (s->peer_world < 1) { set_error("gpemu_sampler_peer_import has not been called"); return GPEMU_ERR_STATE; }

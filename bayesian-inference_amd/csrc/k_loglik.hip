@@ -240,59 +240,7 @@ __global__ __launch_bounds__(256) void loglik_lowrank_lds_kernel(
   double mu, sd;
   if (k <= 32) walker_mean_sd<32>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
   else walker_mean_sd<64>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
-  double total = -INFINITY;
-  if (inside) {
-    total = 0.0;
-    for (int o = 0; o < nblk; ++o) {
-      const double *Go = G + (int64_t)o * k * k;
-      double h = 0.0, gl = (lane < k) ? g0[(int64_t)o * k + lane] : 0.0;
-      for (int q = 0; q < k; ++q) {
-        double gq = (lane < k) ? Go[q * k + lane] : 0.0;
-        h = fma(gq, __shfl(mu, q), h);
-        double sq = __shfl(sd, q);
-        if (lane < k) M[lane * ldm + q] = ((lane == q) ? 1.0 : 0.0) + sd * gq * sq;
-      }
-      h += gl;
-      double t = (lane < k) ? mu * (h + gl) : 0.0;
-      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-      const double quadA = t + scal[2 * o];
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      double logdiag = 0.0;
-      for (int j = 0; j < k; ++j) {
-        double piv = sqrt(M[j * ldm + j]);
-        __builtin_amdgcn_wave_barrier();
-        if (lane == j) {
-          M[j * ldm + j] = piv;
-          logdiag = log(piv);
-        }
-        if (lane > j && lane < k) M[lane * ldm + j] = M[lane * ldm + j] / piv;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane > j && lane < k) {
-          double lij = M[lane * ldm + j];
-          for (int c = j + 1; c <= lane; ++c) M[lane * ldm + c] -= lij * M[c * ldm + j];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-      double y = (lane < k) ? sd * h : 0.0;
-      for (int j = 0; j < k; ++j) {
-        double zj = __shfl(y, j) / M[j * ldm + j];
-        if (lane == j) y = zj;
-        if (lane > j && lane < k) y = fma(-M[lane * ldm + j], zj, y);
-      }
-      double ww = (lane < k) ? y * y : 0.0;
-      double ldsum = logdiag;
-      for (int off = 32; off > 0; off >>= 1) {
-        ww += __shfl_xor(ww, off);
-        ldsum += __shfl_xor(ldsum, off);
-      }
-      total += -0.5 * (quadA - ww) - 0.5 * (scal[2 * o + 1] + 2.0 * ldsum);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
+  const double total = walker_loglik_lowrank_lds(inside, mu, sd, G, g0, scal, k, nblk, lane, M, ldm);
   finish_walker(total, out, b, d, lane, accumulate, aa, load_accept_operands(Xq, b, lane, aa));
 }
 

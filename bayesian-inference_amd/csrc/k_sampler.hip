@@ -544,7 +544,7 @@ int gpemu_sampler_run(gpemu_sampler *s, int64_t steps, int store_chain) {
   // front kernel runs its likelihood and cross-kernel phases back to back); GPEMU_FUSED_SINGLE=1 takes the
   // two-launch form of the sharded run instead (same chain).
   static const bool fused_single = getenv("GPEMU_FUSED_SINGLE") != nullptr;
-  if (fused_single && front_eligible(s)) return front_run(s, steps, store_chain, 1, 0, false);
+  if (fused_single && front_eligible_for(s, 1)) return front_run(s, steps, store_chain, 1, 0, false);
   if (store_chain) GP_TRY(ensure_chain(s, s->chain_len + steps));
   for (int64_t it = 0; it < steps; ++it) {
     GP_TRY(launch_rng(s, st, steps - it));
@@ -797,7 +797,7 @@ int gpemu_sampler_run_sharded(gpemu_sampler *s, gpemu_comm *c, int64_t steps, in
   GP_HIP(hipSetDevice(s->device));
   hipStream_t st = s->stream;
   const int world = c->world;
-  if (emulate_world > 0 && front_eligible(s)) return front_run(s, steps, store_chain, emulate_world, 0, true);
+  if (emulate_world > 0 && front_eligible_for(s, emulate_world)) return front_run(s, steps, store_chain, emulate_world, 0, true);
   const int split = emulate_world > 0 ? emulate_world : world;
   int64_t lo[2], hi[2];
   for (int h = 0; h < 2; ++h) {

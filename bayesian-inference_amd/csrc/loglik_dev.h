@@ -173,4 +173,67 @@ __device__ __forceinline__ double walker_loglik_lowrank(bool inside, double mu, 
   return total;
 }
 
+// General k (17..64), the k x k matrix of the walker in LDS (`M`, leading dimension `ldm` >= k + 1, private to the
+// wave): the arithmetic of loglik_lowrank_lds_kernel, shared with the fused front kernel so that a sharded run
+// reproduces the single-GPU chain bit for bit.
+__device__ __forceinline__ double walker_loglik_lowrank_lds(bool inside, double mu, double sd,
+                                                            const double *__restrict__ G, const double *__restrict__ g0,
+                                                            const double *__restrict__ scal, int k, int nblk, int lane,
+                                                            double *M, int ldm) {
+  double total = -INFINITY;
+  if (inside) {
+    total = 0.0;
+    for (int o = 0; o < nblk; ++o) {
+      const double *Go = G + (int64_t)o * k * k;
+      double h = 0.0, gl = (lane < k) ? g0[(int64_t)o * k + lane] : 0.0;
+      for (int q = 0; q < k; ++q) {
+        double gq = (lane < k) ? Go[q * k + lane] : 0.0;
+        h = fma(gq, __shfl(mu, q), h);
+        double sq = __shfl(sd, q);
+        if (lane < k) M[lane * ldm + q] = ((lane == q) ? 1.0 : 0.0) + sd * gq * sq;
+      }
+      h += gl;
+      double t = (lane < k) ? mu * (h + gl) : 0.0;
+      for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+      const double quadA = t + scal[2 * o];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      double logdiag = 0.0;
+      for (int j = 0; j < k; ++j) {
+        double piv = sqrt(M[j * ldm + j]);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == j) {
+          M[j * ldm + j] = piv;
+          logdiag = log(piv);
+        }
+        if (lane > j && lane < k) M[lane * ldm + j] = M[lane * ldm + j] / piv;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane > j && lane < k) {
+          double lij = M[lane * ldm + j];
+          for (int c = j + 1; c <= lane; ++c) M[lane * ldm + c] -= lij * M[c * ldm + j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      double y = (lane < k) ? sd * h : 0.0;
+      for (int j = 0; j < k; ++j) {
+        double zj = __shfl(y, j) / M[j * ldm + j];
+        if (lane == j) y = zj;
+        if (lane > j && lane < k) y = fma(-M[lane * ldm + j], zj, y);
+      }
+      double ww = (lane < k) ? y * y : 0.0;
+      double ldsum = logdiag;
+      for (int off = 32; off > 0; off >>= 1) {
+        ww += __shfl_xor(ww, off);
+        ldsum += __shfl_xor(ldsum, off);
+      }
+      total += -0.5 * (quadA - ww) - 0.5 * (scal[2 * o + 1] + 2.0 * ldsum);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  return total;
+}
+
 }  // namespace gpemu

@@ -71,6 +71,7 @@ int sampler_check_nan(gpemu_sampler *s);
 // k_front.hip
 void front_release(gpemu_sampler *s);                         // frees the gather buffer and the peer mappings
 bool front_eligible(const gpemu_sampler *s);
+bool front_eligible_for(const gpemu_sampler *s, int world);   // ... and a rank's share of a `world`-rank run fits on the chip
 // `steps` stretch-move steps with two launches per half-step (fused front kernel + triangular GEMM); world / rank:
 // how the proposing half is split (world = 1: everything here); emulate: evaluate rank 0's share of a `world`-rank job
 int front_run(gpemu_sampler *s, int64_t steps, int store_chain, int world, int rank, bool emulate);

@@ -335,9 +335,10 @@ class DeviceSampler:
         """Same chain as ``run`` (every rank draws identical randomness); rank r evaluates its
         block of each half's proposals and the log-probabilities are exchanged.
 
-        transport "peer" (default where it applies: one emulation group, <= 16 PCs, <= 2048 walkers): two
-        launches per half-step, every new log-probability stored straight into all ranks' memory (xGMI peer
-        stores, no collective): ``gpemu_sampler_run_peer``.  transport "rccl" (backend "nccl"): the loop runs
+        transport "peer" (default where it applies: up to 8 emulation groups of up to 64 PCs, launches that fit
+        on the chip at once): a front launch + one triangular GEMM per group per half-step, every new
+        log-probability stored straight into all ranks' memory (xGMI peer stores, no collective):
+        ``gpemu_sampler_run_peer``.  transport "rccl" (backend "nccl"): the loop runs
         inside the library on its own RCCL communicator with one all-gather per half-step
         (``gpemu_sampler_run_sharded``).  transport "torch": per-phase calls with torch.distributed's all-gather
         (staged through the host on non-nccl backends).  GPEMU_SHARDED_TRANSPORT overrides the default.

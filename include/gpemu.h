@@ -254,9 +254,13 @@ int gpemu_sampler_peer_selftest(gpemu_sampler *s);
  * log-probability (8 bytes) straight into every rank's buffer.  Setup: each rank exports a 64-byte IPC handle of its
  * buffer (gpemu_sampler_peer_export), the ranks exchange the handles by any means (torch.distributed all_gather),
  * and each imports all of them (handles[world*64], its own entry is ignored).  gpemu_sampler_run_peer then runs
- * `steps` stretch-move steps with TWO launches per half-step and no RCCL call; same chain as gpemu_sampler_run on
- * every rank.  Needs one emulation group with <= 16 PCs and <= 2048 walkers (else GPEMU_ERR_UNSUPPORTED: use
- * gpemu_sampler_run_sharded).  Replaces ref: mcmc.py:77-85 (the pool.map over walkers). */
+ * `steps` stretch-move steps with one front launch + one triangular GEMM per emulation group per half-step and no RCCL
+ * call; same chain as gpemu_sampler_run on every rank.  Takes up to 8 emulation groups of up to 64 PCs each, one chain,
+ * as long as every workgroup of a front launch can be resident at once for the rank's share of the proposals (else
+ * GPEMU_ERR_UNSUPPORTED from the export / import: use gpemu_sampler_run_sharded).  The ranks must enter every call
+ * together (a barrier on the host side): a peer's stores may arrive as soon as it has started.  A peer that does not
+ * deliver within GPEMU_PEER_TIMEOUT_MS (5000) ends the run with GPEMU_ERR_STATE on every rank.
+ * Replaces ref: mcmc.py:77-85 (the pool.map over walkers). */
 int gpemu_sampler_peer_export(gpemu_sampler *s, char *handle_out64);
 int gpemu_sampler_peer_import(gpemu_sampler *s, int world, int rank, const char *handles);
 int gpemu_sampler_run_peer(gpemu_sampler *s, int64_t steps, int store_chain);

@@ -279,6 +279,42 @@ def test_fused_run_world1_equals_three_launch_run():
     dm.close()
 
 
+def test_fused_run_world1_multigroup_and_lds_likelihood():
+    """The fused two-launch half-step over several emulation groups, one of them with more than 16 PCs (its likelihood
+    factorises in LDS): golden G7, the reference's shipped shape (k = 5 / 11 / 25).  Same chain as the three-launch run,
+    bit for bit, also across calls and for an odd ensemble."""
+    import ctypes as C
+    from gpemu import _lib, synthetic
+    from gpemu.sampler import DeviceSampler
+    g = GU.load("g7_shipped_config")
+    names, mapping, block_start, cols = GU.g7_groups(g)
+    models = GU.g7_models(g)
+    dms = []
+    for n in names:
+        dm = GU.device_model(models[n])
+        dm.likelihood_setup(g["y_exp"][cols[n]], g["y_err"][cols[n]], g["lo"], g["hi"], 1.0, block_start=block_start[n])
+        dms.append(dm)
+    L = _lib.lib()
+    for W in (24, 201):
+        X0 = synthetic.make_walkers(W, seed=4, lo=g["design"].min(0), hi=g["design"].max(0))
+        a = DeviceSampler(dms, W, seed=9)
+        a.set_state(X0)
+        a.run(7)
+        b = DeviceSampler(dms, W, seed=9)
+        b.set_state(X0)
+        h = (C.c_char * 64)()
+        _lib.check(L.gpemu_sampler_peer_export(b._h, C.cast(h, C.c_void_p)))
+        _lib.check(L.gpemu_sampler_peer_import(b._h, 1, 0, C.cast(h, C.c_void_p)))
+        for n in (3, 4):
+            _lib.check(L.gpemu_sampler_run_peer(b._h, n, 1))
+        np.testing.assert_array_equal(a.get_chain()[0], b.get_chain()[0])
+        np.testing.assert_array_equal(a.get_chain()[1], b.get_chain()[1])
+        np.testing.assert_array_equal(a.counts()[0], b.counts()[0])
+        a.close(); b.close()
+    for dm in dms:
+        dm.close()
+
+
 def test_device_sampler_posterior_moments_vs_host_stretch_move():
     """Statistical check of the device sampler beyond step equality: the posterior of the G1 emulator sampled (a) by
     the device sampler (Philox randomness, fused kernels) and (b) by the host stretch move -- an independent
@@ -481,18 +517,26 @@ def _multigroup_models():
     return g, dms
 
 
-def _sharded_multigroup_worker(rank, world, port, out_dir):
+def _sharded_multigroup_worker(rank, world, port, out_dir, fused):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if not fused:
+        os.environ["GPEMU_NO_FUSED"] = "1"       # read once per process by the library: set before its first use
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gpemu.sampler import DeviceSampler
     g, dms = _multigroup_models()
     ds = DeviceSampler(dms, 16, seed=21)
     ds.set_state(g["Xq"])
-    ds.run_sharded(6)                          # default transport: two groups are outside the fused run's limits
-    assert ds._peer_ok and not any(ds._peer_ok.values()), "the ranks should have agreed NOT to take the peer transport"
+    ds.run_sharded(4)                          # default transport
+    ds.run_sharded(2)
+    if fused:
+        assert ds.last_transport == "peer" and all(ds._peer_ok.values()), "two groups should take the fused peer run"
+    else:
+        assert ds.last_transport == "torch" and not any(ds._peer_ok.values()), \
+            "the ranks should have agreed NOT to take the peer transport"
+        assert ds.transport_info.get("fallback_from_peer") is True
     chain, lps = ds.get_chain()
     np.save(os.path.join(out_dir, f"chain_{rank}.npy"), chain)
     np.save(os.path.join(out_dir, f"lp_{rank}.npy"), lps)
@@ -503,15 +547,17 @@ def _sharded_multigroup_worker(rank, world, port, out_dir):
         dm.close()
 
 
-def test_sharded_multigroup_falls_back_together(tmp_path):
-    """Two emulation groups (the shipped analysis has three) are outside the fused two-launch run: with the default
-    transport both ranks agree to leave the peer path and exchange through torch.distributed; the chain is the
-    single-GPU chain of the same sampler, bit for bit."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_sharded_multigroup_two_ranks(tmp_path, fused):
+    """Two emulation groups (the shipped analysis has three) on two ranks.  fused: the peer transport takes several
+    groups (round 3: one front launch + one triangular GEMM per group per half-step).  not fused (GPEMU_NO_FUSED): both
+    ranks agree to leave the peer path and exchange through torch.distributed.  Either way the chain is the single-GPU
+    chain of the same sampler, bit for bit."""
     import os
     import torch.multiprocessing as mp
     from gpemu.sampler import DeviceSampler
-    port = 29300 + (os.getpid() % 200)
-    mp.spawn(_sharded_multigroup_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 29300 + (os.getpid() % 200) + (3 if fused else 0)
+    mp.spawn(_sharded_multigroup_worker, args=(2, port, str(tmp_path), fused), nprocs=2, join=True)
     c0, c1 = np.load(tmp_path / "chain_0.npy"), np.load(tmp_path / "chain_1.npy")
     np.testing.assert_array_equal(c0, c1)
     g, dms = _multigroup_models()

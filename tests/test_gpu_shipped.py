@@ -220,7 +220,8 @@ def test_shipped_two_rank_sharded_run_equals_single(tmp_path, monkeypatch):
     c0, c1 = np.load(tmp_path / "chain_0.npy"), np.load(tmp_path / "chain_1.npy")
     np.testing.assert_array_equal(c0, c1)
     np.testing.assert_array_equal(np.load(tmp_path / "lp_0.npy"), np.load(tmp_path / "lp_1.npy"))
-    assert (tmp_path / "transport_0.txt").read_text() == (tmp_path / "transport_1.txt").read_text()
+    # three groups, one with 25 PCs: the fused peer run takes them since round 3
+    assert (tmp_path / "transport_0.txt").read_text() == (tmp_path / "transport_1.txt").read_text() == "peer"
     g = GU.load("g7_shipped_config")
     names, mapping, block_start, cols = GU.g7_groups(g)
     models, dms = _device_models(g, names, block_start, cols)
