@@ -175,6 +175,14 @@ def _run_closure_batch(config, indices):
     advance([state[c * n_walk:(c + 1) * n_walk] for c in range(n_ch)], config.n_sampling_steps)
     chain, lps = sampler.get_chain()
     nacc, iters, _ = sampler.counts()
+    # every chain's autocorrelation time from the chain as it sits on the device (its own walkers only)
+    taus = []
+    for c in range(n_ch):
+        try:
+            taus.append(sampler.integrated_time(w0=c * n_walk, nw=n_walk))
+        except Exception as err:
+            logger.info(f'No autocorrelation time (closure {indices[c]}): {err}')
+            taus.append(None)
     sampler.close()
 
     validation_design = io.design_array_from_h5(config.output_dir, filename='observables.h5', validation_set=True)
@@ -185,11 +193,7 @@ def _run_closure_batch(config, indices):
         one._cache = (per_chain(chain)[c].copy(), per_chain(lps)[c].copy(),
                       nacc[c * n_walk:(c + 1) * n_walk].copy(), iters)
         one._frozen = True
-        try:
-            tau = one.get_autocorr_time()
-        except Exception as err:
-            logger.info(f'No autocorrelation time (closure {j}): {err}')
-            tau = None
+        tau = taus[c]
         results = {'chain': one.get_chain(), 'acceptance_fraction': one.acceptance_fraction,
                    'log_prob': one.get_log_prob(), 'autocorrelation_time': tau,
                    'design_point': validation_design[j], 'experimental_pseudodata': datas[c]}
@@ -285,12 +289,32 @@ def run_mcmc(config, closure_index=-1):
         validation_design = io.design_array_from_h5(config.output_dir, filename='observables.h5', validation_set=True)
         results['design_point'] = validation_design[closure_index]
         results['experimental_pseudodata'] = data
+    # the two big outputs -- mcmc.h5 (ref: mcmc.py:125) and the pickled sampler (ref: mcmc.py:131-132), ~0.5 GB each at
+    # the shipped length -- are written side by side: the file writes release the interpreter lock
     logger.info(f'Writing {config.mcmc_outputfile}')
-    io.write_dict_to_h5(results, config.mcmc_output_dir, 'mcmc.h5', verbose=True)
-
     pickle_path = Path(config.sampler_outputfile)
     pickle_path.parent.mkdir(parents=True, exist_ok=True)
-    pickle_path.write_bytes(pickle.dumps(sampler))
+
+    def write_pickle():
+        with open(pickle_path, 'wb') as handle:
+            pickle.dump(sampler, handle, protocol=pickle.HIGHEST_PROTOCOL)     # streamed: no 0.5 GB bytes object first
+
+    import threading
+    failure = []
+
+    def guarded():
+        try:
+            write_pickle()
+        except BaseException as err:     # re-raised in the caller's thread
+            failure.append(err)
+    side = threading.Thread(target=guarded, name='gpemu-sampler-pickle')
+    side.start()
+    try:
+        io.write_dict_to_h5(results, config.mcmc_output_dir, 'mcmc.h5', verbose=True)
+    finally:
+        side.join()
+    if failure:
+        raise failure[0]
     logger.info('MCMC finished.')
 
 

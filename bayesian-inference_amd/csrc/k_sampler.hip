@@ -440,6 +440,7 @@ int gpemu_sampler_destroy(gpemu_sampler *s) {
   (void)hipFree(s->zz); (void)hipFree(s->logu); (void)hipFree(s->rint); (void)hipFree(s->q);
   (void)hipFree(s->factors); (void)hipFree(s->newlp); (void)hipFree(s->naccept); (void)hipFree(s->flags);
   (void)hipFree(s->chain); (void)hipFree(s->lpchain);
+  (void)hipFree(s->acf_part); (void)hipFree(s->acf_acf); (void)hipFree(s->acf_mean); (void)hipFree(s->acf_acf0);
   for (int h = 0; h < 2; ++h) { (void)hipFree(s->gmine[h]); (void)hipFree(s->gfull[h]); }
   delete s;
   return GPEMU_OK;

@@ -61,6 +61,10 @@ struct gpemu_sampler {
   std::vector<void *> peer_opened;   // IPC mappings to close
   int peer_world = 0, peer_rank = 0;
   uint64_t front_count = 0;    // fused launches so far (gather slot and buffer parity)
+  // autocorrelation estimate (k_acf.hip): scratch kept between the lag blocks of one estimate
+  double *acf_part = nullptr, *acf_acf = nullptr, *acf_mean = nullptr, *acf_acf0 = nullptr;
+  size_t acf_part_bytes = 0;
+  int64_t acf_first = -1, acf_n = -1;
 };
 
 namespace gpemu {

@@ -76,6 +76,7 @@ _SIGNATURES = {
                                               C.c_void_p, C.c_int]),
     "gpemu_sampler_get_chain": (C.c_int, [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p]),
     "gpemu_sampler_get_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "gpemu_sampler_acf": (C.c_int, [C.c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, C.c_void_p]),
     "gpemu_sampler_reserve_chain": (C.c_int, [C.c_void_p, c_i64]),
     "gpemu_sampler_begin_step": (C.c_int, [C.c_void_p]),
     "gpemu_sampler_half_propose_eval": (C.c_int, [C.c_void_p, C.c_int, c_i64, c_i64, C.c_void_p]),

@@ -204,6 +204,61 @@ class DeviceSampler:
         check(_lib.lib().gpemu_sampler_get_chain(self._h, int(first), int(n), ptr(chain), ptr(lp)))
         return chain, lp
 
+    def acf_block(self, lag0, n_lags, first=0, n=None, w0=0, nw=None):
+        """Walker-averaged normalised autocorrelation function, lags [lag0, lag0 + n_lags), of the chain stored on
+        the device: (n_lags, d).  ``lag0`` a multiple of 16, the first block of an estimate at 0."""
+        _, _, cl = self.counts()
+        n = cl - first if n is None else n
+        nw = self.W - w0 if nw is None else nw
+        f = np.empty((int(n_lags), self.d))
+        check(_lib.lib().gpemu_sampler_acf(self._h, int(first), int(n), int(w0), int(nw), int(lag0), int(n_lags), ptr(f)))
+        return f
+
+    def integrated_time(self, first=0, n=None, w0=0, nw=None, c=5, tol=50, quiet=False, block=256):
+        """emcee.autocorr.integrated_time of the stored chain (rows [first, first + n), walkers [w0, w0 + nw)) WITHOUT
+        bringing it to the host: the lag products are formed on the device, ``block`` lags at a time, until Sokal's
+        window (the first M with M >= c tau(M)) has closed for every parameter -- a few hundred lags instead of FFTs over
+        the whole chain.  Same estimate as ``gpemu.sampler.integrated_time`` (rounding apart)."""
+        _, _, cl = self.counts()
+        n_t = int(cl - first if n is None else n)
+        d = self.d
+        tau_est = np.full(d, np.nan)
+        windows = np.full(d, -1, dtype=int)
+        run = np.zeros(d)                    # cumulative sum of f so far
+        lag0 = 0
+        while lag0 < n_t and np.any(windows < 0):
+            nl = int(min(block, n_t - lag0))
+            f = self.acf_block(lag0, nl, first=first, n=n_t, w0=w0, nw=nw)
+            cs = run[None, :] + np.cumsum(f, axis=0)
+            taus = 2.0 * cs - 1.0
+            if lag0 == 0:
+                tau_first = taus[0].copy()
+            idx = lag0 + np.arange(nl)
+            for dd in range(d):
+                if windows[dd] >= 0:
+                    continue
+                closed = ~(idx < c * taus[:, dd])           # NaN compares False: the window "closes" at once, as in emcee
+                if np.any(closed):
+                    m = int(np.argmax(closed))
+                    windows[dd] = lag0 + m
+                    tau_est[dd] = taus[m, dd]
+                elif lag0 + nl >= n_t:
+                    # never closed: emcee's auto_window takes np.argmin of an all-True mask, i.e. window 0 and
+                    # tau = taus[0] = 1 (which then fails the tol test: the short-chain AutocorrError)
+                    windows[dd] = 0
+                    tau_est[dd] = tau_first[dd]
+            run = cs[-1]
+            lag0 += nl
+            block = min(block * 2, 4096)
+        flag = tol * tau_est > n_t
+        if np.any(flag) and not quiet:
+            msg = ("The chain is shorter than {0} times the integrated autocorrelation time for {1} "
+                   "parameter(s). Use this estimate with caution and run a longer chain!\n"
+                   ).format(tol, np.sum(flag))
+            msg += "N/{0} = {1:.0f};\ntau: {2}".format(tol, n_t / tol, tau_est)
+            raise AutocorrError(tau_est, msg)
+        return tau_est
+
     # -- multi-GPU: one process per GPU, the ensemble replicated, proposals sharded -------------
     def _rccl_comm_agreed(self, group):
         """RCCL communicator owned by the library (one per sampler and process group), bootstrapped through
@@ -694,6 +749,13 @@ class EnsembleSampler:
         return nacc / float(max(it, 1))
 
     def get_autocorr_time(self, discard=0, thin=1, **kwargs):
+        # the chain still lives on the device: estimate there (no FFTs over a 500 MB host copy); GPEMU_ACF_HOST=1 or a
+        # thinned / unpickled sampler takes the host routine
+        if (self._impl is not None and getattr(self, "_device", False) and thin == 1 and not self.__dict__.get("_frozen")
+                and not os.environ.get("GPEMU_ACF_HOST")):
+            kw = {k: kwargs[k] for k in ("c", "tol", "quiet") if k in kwargs}
+            if set(kwargs) <= {"c", "tol", "quiet"}:
+                return self._impl.integrated_time(first=int(discard), **kw)
         return thin * integrated_time(self.get_chain(discard=discard, thin=thin), **kwargs)
 
     # -- pickling (ref: mcmc.py:131-132 pickles the sampler) --------------------------------------

@@ -211,6 +211,14 @@ int gpemu_sampler_get_chain(gpemu_sampler *s, int64_t first, int64_t n, double *
                             double *logp_out);
 int gpemu_sampler_get_counts(gpemu_sampler *s, int64_t *naccepted /*[W]*/, int64_t *iterations,
                              int64_t *chain_len);
+/* Walker-averaged normalised autocorrelation function of the stored chain rows [first, first + n_steps), walkers
+ * [w0, w0 + nw) (a chain of a stacked sampler), lags [lag0, lag0 + n_lags): f_out[n_lags][d],
+ *     f[l][dd] = 1/nw sum_w acf_(w,dd)[l] / acf_(w,dd)[0],  acf[l] = sum_t (x[t] - mean)(x[t + l] - mean),
+ * i.e. emcee.autocorr.function_1d averaged as emcee.autocorr.integrated_time does (emcee 3.1.x, third party; call
+ * site ref: mcmc.py:111-119 sampler.get_autocorr_time()).  The host asks for blocks of lags (lag0 a multiple of 16,
+ * the first block at lag0 = 0) until Sokal's window closes, so the chain never has to leave HBM for it. */
+int gpemu_sampler_acf(gpemu_sampler *s, int64_t first, int64_t n_steps, int64_t w0, int64_t nw, int64_t lag0,
+                      int64_t n_lags, double *f_out);
 /* Phases of one step for the multi-GPU driver: every rank holds the whole ensemble and draws the
  * same randomness; rank r evaluates proposals [lo, hi) of the half (the log-probabilities land in
  * dnewlp_slice[0 .. hi-lo), typically the caller's all-gather input) and the ranks all-gather them

@@ -43,6 +43,17 @@ def main(out_dir):
             note(self)
         return real_write_bytes(self, data)
     Path.write_bytes = logging_write_bytes
+    # the production chain's sampler pickle is streamed with pickle.dump(sampler, handle)
+    import pickle as real_pickle
+    import types
+    proxy = types.SimpleNamespace(**{n: getattr(real_pickle, n) for n in dir(real_pickle) if not n.startswith("__")})
+
+    def logging_dump(obj, handle, *a, **k):
+        if os.path.basename(getattr(handle, "name", "")) == "mcmc_sampler.pkl":
+            note(handle.name)
+        return real_pickle.dump(obj, handle, *a, **k)
+    proxy.dump = logging_dump
+    mcmc.pickle = proxy
 
     import yaml
     path = os.path.join(out_dir, "analysis.yaml")          # written by the test before the launch

@@ -570,3 +570,64 @@ def test_sharded_multigroup_two_ranks(tmp_path, fused):
     ds.close()
     for dm in dms:
         dm.close()
+
+
+def test_device_autocorrelation_time_equals_host_estimator():
+    """emcee's integrated autocorrelation time (emcee/autocorr.py, call site ref: mcmc.py:111-119) estimated from the
+    chain as it sits on the device -- direct lag products, a block of lags at a time until Sokal's window closes --
+    against the host routine (FFT over the whole chain; itself tested on AR(1) series in test_sampler_host.py): same
+    windows, same tau to 1e-10; also for a sub-range of steps, one chain of a stacked sampler, and the short-chain
+    error path."""
+    from gpemu import synthetic
+    from gpemu import sampler as S
+    g, model, dm, _ = _setup()
+    W, steps = 64, 3000
+    ds = S.DeviceSampler([dm], W, seed=5)
+    ds.set_state(synthetic.make_walkers(W, seed=2, lo=g["lo"], hi=g["hi"]))
+    ds.run(300, store=False)
+    ds.run(steps)
+    chain, _ = ds.get_chain()
+    host = S.integrated_time(chain, quiet=True)
+    dev = ds.integrated_time(quiet=True)
+    assert np.all(np.isfinite(host)) and np.all(host > 1.0)
+    np.testing.assert_allclose(dev, host, rtol=1e-10)
+    # the blocks of f themselves against emcee's function_1d, walker by walker
+    f = ds.acf_block(0, 48)
+    ref = np.stack([np.mean([S.function_1d(chain[:, w, dd])[:48] for w in range(W)], axis=0) for dd in range(dm.d)], axis=1)
+    np.testing.assert_allclose(f, ref, rtol=0, atol=1e-12)
+    # a sub-range of the steps (discard) and a small lag block size (several blocks until the window closes)
+    np.testing.assert_allclose(ds.integrated_time(first=500, quiet=True, block=16),
+                               S.integrated_time(chain[500:], quiet=True), rtol=1e-10)
+    # too short a chain: emcee's AutocorrError with the estimate attached
+    with pytest.raises(S.AutocorrError) as err:
+        ds.integrated_time(first=0, n=200)
+    np.testing.assert_allclose(err.value.tau, S.integrated_time(chain[:200], quiet=True), rtol=1e-9)
+    # a chain so short that the window never closes: emcee's auto_window then answers window 0, tau = 1.  (A walker that
+    # never moved in the range makes its series 0 / 0: NaN here, rounding residue in the FFT routine -- not compared.)
+    checked = 0
+    for n_short in (12, 24, 40):
+        moved = np.all(np.any(chain[:n_short] != chain[0], axis=0))
+        if not moved:
+            assert not np.any(np.isfinite(ds.integrated_time(first=0, n=n_short, quiet=True)))
+            continue
+        np.testing.assert_allclose(ds.integrated_time(first=0, n=n_short, quiet=True),
+                                   S.integrated_time(chain[:n_short], quiet=True), rtol=1e-10)
+        with pytest.raises(S.AutocorrError):
+            ds.integrated_time(first=0, n=n_short)
+        checked += 1
+    assert checked >= 1
+    # through the emcee facade: the device path is taken while the chain is on the device
+    ds.close()
+    # one chain of a stacked sampler: its own walkers only
+    C = 3
+    ys = g["y_exp"][None, :] + 0.05 * np.random.default_rng(1).normal(size=(C, g["y_exp"].size))
+    dm.likelihood_setup(ys, g["y_err"], g["lo"], g["hi"], 1.0)
+    ms = S.DeviceSampler([dm], 32, seeds=[3, 4, 5])
+    ms.set_state(np.concatenate([synthetic.make_walkers(32, seed=30 + c, lo=g["lo"], hi=g["hi"]) for c in range(C)]))
+    ms.run(1500)
+    mc, _ = ms.get_chain()
+    for c in range(C):
+        np.testing.assert_allclose(ms.integrated_time(w0=32 * c, nw=32, quiet=True),
+                                   S.integrated_time(mc[:, 32 * c:32 * (c + 1)], quiet=True), rtol=1e-10)
+    ms.close()
+    dm.close()
