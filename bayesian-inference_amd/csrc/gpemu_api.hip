@@ -300,7 +300,9 @@ int gpemu_model_destroy(gpemu_model *m) {
   for (const gpemu_model::LikEntry &en : m->lik_cache) { hipFree(en.G); hipFree(en.g0); hipFree(en.scal); }
   hipFree(m->exact_scratch);
   hipFree(m->blk_start); hipFree(m->blk_of);
-  for (const gpemu_model::SchedEntry &en : m->sched_cache) { hipFree(en.items); hipFree(en.cnt); }
+  for (const gpemu_model::SchedEntry &en : m->sched_cache) {
+    hipFree(en.items); hipFree(en.cnt); hipFree(en.qitems); hipFree(en.qn); hipFree(en.qcnt);
+  }
   hipFree(m->sm_items); hipFree(m->sm_cnt);
   free_workspace(m->ws);
   hipFree(m->pf_mean); hipFree(m->pf_var);

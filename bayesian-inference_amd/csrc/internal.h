@@ -65,7 +65,12 @@ struct gpemu_model {
   int *sched_cnt = nullptr;    // [sched_workers]
   int sched_ncb = -1, sched_max_items = 0, sched_workers = 0;
   int sched_cap = 0;           // worker cap the current schedule was built for
-  struct SchedEntry { int ncb, cap; void *items; int *cnt; int max_items, workers; };
+  int sched_cur = -1;          // index of the current schedule in sched_cache
+  struct SchedEntry {
+    int ncb, cap; void *items; int *cnt; int max_items, workers;
+    // work-queue form (trmm_vsq_dyn_kernel): per-XCD item lists, list lengths, two sets of per-XCD counters
+    void *qitems = nullptr; int *qn = nullptr; unsigned int *qcnt = nullptr; int qmax = 0; unsigned launches = 0;
+  };
   std::vector<SchedEntry> sched_cache;   // every schedule built so far (sched_items / sched_cnt point into one of them)
   int worker_limit = 0;        // > 0: persistent kernels are scheduled for this many workers (a CU-masked stream)
   // CU-partitioned predict pipeline (gpemu_predict_full_dev): the GP stage of chunk i + 1 on one set of CUs while the

@@ -716,6 +716,285 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Work-queue form of trmm_vsq_dma_kernel<true> (round 3).  The static LPT schedule balances the k-tile COUNT per worker
+// to +-1, but the workers do not run equally fast -- the XCDs' mean finish times differ by 1.6 us and single workers by
+// more (in-kernel stamps: finish 84.4 ... 91.3 us around a median of 87.5, profiles/r03_trmm_balance.txt) -- and the
+// launch ends with its slowest worker.  Here every XCD's items sit in ONE list in LPT order (the same items, the same
+// XCD placement) and its workers draw from it: the first item of a worker is its index in the list, every further one
+// comes from a per-XCD counter.  The fetch costs the k-tile pipeline nothing: an atomic add and, one k-tile later, a load
+// of the item, issued by lane 0 of wave 0 right after a k-tile barrier, i.e. BEFORE that k-tile's six LDS-direct loads --
+// vmcnt counts in order, so the hand-placed s_waitcnt vmcnt(6) of the next barrier ("all but my six newest") covers them;
+// items land in an 8-entry LDS ring, up to five ahead of the compute cursor, so neither the load cursor (two k-tiles
+// ahead) nor the compute cursor ever waits for one.  Every item is computed exactly once by whoever
+// draws it and writes its own output slot: the results do not depend on the assignment (chains stay bit-identical).
+typedef int i4q __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512, 1) void trmm_vsq_dyn_kernel(   // one workgroup per CU (144 KiB of LDS): no need to squeeze into 128 VGPRs
+    const double *__restrict__ Wt, const double *__restrict__ KS, double *__restrict__ out,
+    const TrmmItem *__restrict__ qitems, const int *__restrict__ qn, unsigned int *__restrict__ qcnt, int qset, int qmax,
+    int workers_per_xcd, int64_t Npad, int64_t Bcap, int k, int nrb, unsigned long long *__restrict__ stamps) {
+  constexpr bool INTERLEAVE = true;
+  constexpr int BUFD = KT * TM + KT * TILE;            // one k-tile: [W tile | K_*^T tile], 48 KiB
+  __shared__ __attribute__((aligned(16))) double L0[BUFD];
+  __shared__ __attribute__((aligned(16))) double L1[BUFD];
+  __shared__ __attribute__((aligned(16))) double L2[BUFD];
+  __shared__ double red[2][TILE];
+  __shared__ TrmmItem s_items[8];           // ring: item j of this worker at j & 7; p < 0 = the list is exhausted
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 15, lk = lane >> 4;
+
+  if (stamps && tid == 0) stamps[blockIdx.x * 16] = __builtin_amdgcn_s_memrealtime();
+  const int xcd = blockIdx.x & 7, wx = blockIdx.x >> 3;       // workgroups are dispatched round-robin over the XCDs
+  const int nq = qn[xcd];
+  const TrmmItem *qlist = qitems + (int64_t)xcd * qmax;
+  unsigned int *const my_cnt = qcnt + ((int64_t)qset * 8 + xcd) * 32;
+  if (blockIdx.x == 0 && tid < 8) qcnt[((int64_t)(qset ^ 1) * 8 + tid) * 32] = (unsigned)workers_per_xcd;   // the next launch's set
+  // ring entry j carries its index in the upper bits of `half` (half | j << 1): an entry that has not arrived yet is
+  // told from what the slot held eight items ago
+  if (tid == 0) s_items[0] = (wx < nq) ? qlist[wx] : TrmmItem{-1, 0, 0, 0};
+  if (tid >= 1 && tid < 8) s_items[tid] = TrmmItem{-1, 0, 0, -2};
+  __syncthreads();
+  if (s_items[0].p < 0) return;
+  // item j of this worker: s_items[j & 7] (valid once the fetch pipeline below has written it and a barrier has passed)
+  struct Ring { const TrmmItem *r; __device__ const TrmmItem &operator[](int j) const { return r[j & 7]; } } my{s_items};
+  // fetch pipeline (wave 0): at most one atomic and one item load in flight, one stage per k-tile
+  int f_wr = 1, fst = 0, q_tiles = 0;
+  unsigned int at_val = 0;
+  i4q ld_val = i4q{0, 0, 0, 0};
+
+  // per-lane source offsets (doubles) of the wave's six 1 KiB chunks of a k-tile
+  int offA[2], offB[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int kk = 2 * (wave * 2 + j) + (lane >> 5);          // chunk = two k-rows of the W tile
+    offA[j] = kk * (int)Npad + ((2 * (lane & 31)) ^ ((kk & 1) << 4));
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int kk = wave * 4 + r;                              // chunk = one k-row of the K_*^T tile
+    offB[r] = kk * (int)Bcap + ((2 * lane) ^ ((kk & 1) << 4));
+  }
+  const int64_t astep = (int64_t)KT * Npad, bstep = (int64_t)KT * Bcap;
+
+  // ---- load cursor (one k-tile ahead of the compute cursor) ----
+  int l_item = 0, l_t = 0, l_nt = 1;
+  bool l_end = false;
+  const double *l_pa = Wt, *l_pb = KS;
+  auto fetch_tick = [&]() __attribute__((always_inline)) {
+    {
+      // Fetch pipeline, one stage per k-tile.  Its two memory operations are issued HERE, i.e. before this k-tile's six
+      // LDS-direct loads in wave 0's instruction stream: vmcnt counts in order, so the s_waitcnt vmcnt(6) of the NEXT
+      // k-tile barrier -- "everything but my six newest loads" -- covers them without a cycle of extra waiting.  The
+      // empty asm pins the uses of last k-tile's results behind the barrier.
+      asm volatile("" : "+v"(at_val), "+v"(ld_val));
+      // fst: bit 0 = an atomic is in flight, bit 1 = an item load is in flight, bit 2 = the list is exhausted (one
+      // integer: as separate variables the compiler keeps them in scratch memory, whose reloads wait for vmcnt(0))
+      int st = fst;
+      if (st & 2) {
+        if (lane == 0) s_items[f_wr & 7] = TrmmItem{ld_val[0], ld_val[1], ld_val[2], ld_val[3] | (f_wr << 1)};
+        ++f_wr;
+        q_tiles += 2 * (__builtin_amdgcn_readfirstlane(ld_val[1]) + 1);      // k-tiles of the item: 2 (rb + 1)
+        st &= ~2;
+      }
+      if (st & 1) {
+        st &= ~1;
+        const int idx = __builtin_amdgcn_readfirstlane((int)at_val);
+        if (idx < nq) {
+          const TrmmItem *src = qlist + idx;
+          if (lane == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld_val) : "v"(src) : "memory");
+          st |= 2;
+        } else {
+          if (lane == 0) s_items[f_wr & 7] = TrmmItem{-1, 0, 0, f_wr << 1};
+          ++f_wr;
+          st |= 4;
+        }
+      }
+      // Draw the next item only when it is about to be needed: the load cursor's remaining k-tiles plus those of the
+      // items already waiting for it have shrunk to the fetch latency and a margin.  (Drawing as far ahead as the ring
+      // allows hands out the whole list in the first microseconds, first come first served: 121 us instead of 95.)
+      if (!(st & 7) && (l_nt - l_t) + q_tiles <= 7) {
+        if (lane == 0) {
+          const unsigned one = 1u;
+          asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(at_val) : "v"(my_cnt), "v"(one) : "memory");
+        }
+        st |= 1;
+      }
+      fst = st;
+    }
+  };
+  auto l_open = [&]() __attribute__((always_inline)) {
+    const TrmmItem it = my[l_item];
+    const int64_t i0 = (int64_t)it.rb * TM;
+    l_nt = (int)((i0 + TM + KT - 1) / KT);
+    l_pa = Wt + (int64_t)it.p * Npad * Npad + i0;
+    l_pb = KS + (int64_t)it.p * Npad * Bcap + (it.col0 & ~(TILE - 1));
+    l_t = 0;
+  };
+  // Issued as inline assembly: with the builtin, hipcc's waitcnt insertion treats every later LDS read as a
+  // possible reader of the in-flight destination and drains vmcnt to 0, which defeats the two-tile lookahead;
+  // the waits for these loads are the hand-written s_waitcnt vmcnt(6) of tile_barrier().
+  auto dma1 = [&](const double *src, double *dst_wave_uniform) {
+    const unsigned lds_off = (unsigned)(uintptr_t)((las_ptr)dst_wave_uniform);
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+                 :
+                 : "s"(lds_off), "v"(src)
+                 : "memory");
+  };
+  // one of the wave's six loads of a k-tile (part compile-time after unrolling); the cursor moves on after the last
+  auto dma_part = [&](double *dA, int part) __attribute__((always_inline)) {
+    double *dB = dA + KT * TM;
+    if (part < 2) dma1(l_pa + offA[part], dA + (wave * 2 + part) * 128);
+    else dma1(l_pb + offB[part - 2], dB + (wave * 4 + part - 2) * 128);
+    if (part == 5 && !l_end) {
+      if (++l_t == l_nt) {
+        // Never expected (the fetch runs >= 4 k-tiles ahead of this point), but a late entry must not be mistaken for
+        // the slot's old content: drain the fetch pipeline synchronously until the entry is there.
+        while ((my[l_item + 1].half >> 1) != l_item + 1) {
+          __syncthreads();
+          if (wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fetch_tick();
+          }
+          __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): wave 0's ring write
+          __syncthreads();
+        }
+        if (my[l_item + 1].p >= 0) { ++l_item; l_open(); q_tiles -= l_nt; }
+        else l_end = true;                 // stay on the last k-tile (harmless re-read)
+      } else {
+        l_pa += astep;
+        l_pb += bstep;
+      }
+    }
+  };
+  auto dma = [&](double *dA) {
+#pragma unroll
+    for (int part = 0; part < 6; ++part) dma_part(dA, part);
+  };
+
+  // vmcnt(6) lgkmcnt(0): everything but this wave's six newest loads has landed, every LDS read has returned
+  int c_item = 0;
+  auto tile_barrier = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_s_waitcnt(0x0076);
+    __builtin_amdgcn_s_barrier();
+    if (wave == 0) fetch_tick();
+  };
+  l_open();
+  dma(L0);
+  dma(L1);
+  tile_barrier();
+  if (stamps && tid == 0) stamps[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime();
+
+  d4 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+
+  int c_t = 0;
+  TrmmItem cur = my[0];
+  cur.half &= 1;
+  int c_nt = (int)(((int64_t)cur.rb * TM + TM + KT - 1) / KT);
+  const int sw = (lk & 1) << 4;                                 // this lane's k-rows are odd <=> lk odd
+  const int ia0 = lk * TM + ((wm * 32 + lr) ^ sw), ia1 = lk * TM + ((wm * 32 + 16 + lr) ^ sw);
+
+  auto step = [&](const double *cA, double *nA) __attribute__((always_inline)) -> bool {
+    const double *cB = cA + KT * TM;
+    if (!INTERLEAVE) dma(nA);                                   // k-tile +2 -> the buffer k-tile -1 was read from
+    if (cur.half) {
+      const int ib = lk * TILE + (((cur.col0 & 64) + wn * 16 + lr) ^ sw);
+      double a[2][2], b[2];
+      a[0][0] = cA[ia0];
+      a[0][1] = cA[ia1];
+      b[0] = cB[ib];
+#pragma unroll
+      for (int ks = 0; ks < KT / 4; ++ks) {
+        const int cu = ks & 1, nx = cu ^ 1;
+        if (ks + 1 < KT / 4) {
+          a[nx][0] = cA[(ks + 1) * 4 * TM + ia0];
+          a[nx][1] = cA[(ks + 1) * 4 * TM + ia1];
+          b[nx] = cB[(ks + 1) * 4 * TILE + ib];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[mi][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cu][mi], b[cu], acc[mi][0], 0, 0, 0);
+        if (INTERLEAVE && ks < 6) dma_part(nA, ks);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      const int ib0 = lk * TILE + ((wn * 32 + lr) ^ sw), ib1 = lk * TILE + ((wn * 32 + 16 + lr) ^ sw);
+      double a[2][2], b[2][2];
+      a[0][0] = cA[ia0];
+      a[0][1] = cA[ia1];
+      b[0][0] = cB[ib0];
+      b[0][1] = cB[ib1];
+#pragma unroll
+      for (int ks = 0; ks < KT / 4; ++ks) {
+        const int cu = ks & 1, nx = cu ^ 1;
+        if (ks + 1 < KT / 4) {
+          a[nx][0] = cA[(ks + 1) * 4 * TM + ia0];
+          a[nx][1] = cA[(ks + 1) * 4 * TM + ia1];
+          b[nx][0] = cB[(ks + 1) * 4 * TILE + ib0];
+          b[nx][1] = cB[(ks + 1) * 4 * TILE + ib1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cu][mi], b[cu][ni], acc[mi][ni], 0, 0, 0);
+        if (INTERLEAVE && ks < 6) dma_part(nA, ks);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    tile_barrier();
+    if (++c_t == c_nt) {
+      const int ncols = cur.half ? 64 : TILE;
+      const int wcol = cur.half ? wn * 16 : wn * 32;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        if (ni == 0 || !cur.half) {
+          double sq = 0.0;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sq = fma(acc[mi][ni][r], acc[mi][ni][r], sq);
+          sq += __shfl_xor(sq, 16);
+          sq += __shfl_xor(sq, 32);
+          if (lk == 0) red[wm][wcol + ni * 16 + lr] = sq;
+        }
+      }
+      __syncthreads();
+      if (tid < ncols)
+        out[(((int64_t)cur.col0 + tid) * k + cur.p) * nrb + cur.rb] = red[0][tid] + red[1][tid];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+      if (stamps && tid == 0 && c_item < 13) stamps[blockIdx.x * 16 + 2 + c_item] = __builtin_amdgcn_s_memrealtime();
+      ++c_item;
+      if (my[c_item].p < 0) {
+        if (stamps && tid == 0) stamps[blockIdx.x * 16 + 14] = (unsigned long long)c_item;   // items this worker drew
+        return true;
+      }
+      cur = my[c_item];
+      cur.half &= 1;
+      c_nt = (int)(((int64_t)cur.rb * TM + TM + KT - 1) / KT);
+      c_t = 0;
+    }
+    return false;
+  };
+  for (;;) {
+    if (step(L0, L2)) break;
+    if (step(L1, L0)) break;
+    if (step(L2, L1)) break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Small-batch form (B <= 128 per launch: a rank's slice of the proposing half on a multi-GPU run).
 // With few columns the 64 x 128 items are too few and too long (the longest, full-K item alone takes
 // ~80 us), so here an item is 32 rows x 64 columns and its K range is split four ways INSIDE the
@@ -847,7 +1126,7 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_smallb_kernel(const double *_
 
 // host side: LPT schedule of the items of one launch shape (cached per model and column-tile count)
 static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &flat, std::vector<int> &cnt,
-                                int &max_items, int &nworkers) {
+                                int &max_items, int &nworkers, std::vector<std::vector<TrmmItem>> *queues = nullptr) {
   const int nrb = (int)m->vsq_nrb, k = (int)m->k;
   struct It { double cost; TrmmItem it; };
   std::vector<It> items;
@@ -855,7 +1134,10 @@ static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &
   // are too few items for 256 workers unless every row block is
   static const int split_all_ncb = getenv("GPEMU_TRMM_SPLIT_ALL_NCB") ? atoi(getenv("GPEMU_TRMM_SPLIT_ALL_NCB")) : 2;
   const int split_below = (ncb <= split_all_ncb) ? nrb : nrb / 4;
-  const double ov = 0.15;            // per-item cost of the epilogue, in k-tiles
+  // per-item cost of the epilogue, in k-tiles.  Measured (in-kernel stamps, profiles/r03_trmm_balance.txt): workers with
+  // 2 / 3 / 5 items finish at 85.3 / 87.6 / 88.5 us, but raising it to 0.4-0.9 (3 / 4 items everywhere) leaves the slowest
+  // worker at 91 us: the spread is the XCDs' (means 86.6-88.2 us), not the cost model's
+  static const double ov = getenv("GPEMU_TRMM_OV") ? atof(getenv("GPEMU_TRMM_OV")) : 0.15;
   for (int rb = 0; rb < nrb; ++rb) {
     const double nt = (double)(((int64_t)rb * TM + TM + KT - 1) / KT);
     for (int p = 0; p < k; ++p)
@@ -883,6 +1165,20 @@ static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &
   static const bool xcd_aware = getenv("GPEMU_TRMM_NO_XCD") == nullptr;
   if (xcd_aware && nworkers == ncu && nworkers % nxcd == 0 && ngroups % nxcd == 0) {
     const int gper = ngroups / nxcd;
+    if (queues) {
+      // the work-queue form: every XCD's items as one list in LPT order.  Usable when a worker's first item -- its
+      // index in the list -- is long enough for the fetch pipeline to deliver the second one (a few k-tiles).
+      queues->assign(nxcd, {});
+      for (const It &x : items) (*queues)[(x.it.p * ncb + x.it.col0 / TILE) / gper].push_back(x.it);
+      const int wpx = nworkers / nxcd;
+      bool ok = true;
+      for (const auto &q : *queues) {
+        if ((int)q.size() < wpx) { ok = false; break; }
+        for (int w = 0; w < wpx; ++w)
+          if (((int64_t)q[w].rb * TM + TM + KT - 1) / KT < 8) ok = false;
+      }
+      if (!ok) queues->clear();
+    }
     for (const It &x : items) {
       const int g = x.it.p * ncb + x.it.col0 / TILE;
       const int xcd = g / gper;
@@ -976,8 +1272,9 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
     if (!hit) {
       std::vector<TrmmItem> flat;
       std::vector<int> cnt;
+      std::vector<std::vector<TrmmItem>> queues;
       int max_items = 0, nworkers = 0;
-      build_trmm_schedule(m, ncb, flat, cnt, max_items, nworkers);
+      build_trmm_schedule(m, ncb, flat, cnt, max_items, nworkers, &queues);
       if (max_items > TRMM_MAX_ITEMS) {
         set_error("triangular GEMM schedule needs %d items per worker (limit %d): batch too large for one launch",
                   max_items, TRMM_MAX_ITEMS);
@@ -989,9 +1286,29 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
       GP_HIP(hipMalloc((void **)&e.cnt, sizeof(int) * cnt.size()));
       GP_HIP(hipMemcpy(e.items, flat.data(), sizeof(TrmmItem) * flat.size(), hipMemcpyHostToDevice));
       GP_HIP(hipMemcpy(e.cnt, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice));
+      if (!queues.empty()) {
+        size_t qmax = 0;
+        for (const auto &q : queues) qmax = std::max(qmax, q.size());
+        std::vector<TrmmItem> qflat(8 * qmax, TrmmItem{-1, 0, 0, 0});
+        std::vector<int> qn(8);
+        for (int x = 0; x < 8; ++x) {
+          qn[x] = (int)queues[x].size();
+          std::copy(queues[x].begin(), queues[x].end(), qflat.begin() + x * qmax);
+        }
+        std::vector<unsigned int> qc(2 * 8 * 32, 0u);       // one counter per 128-byte line; both sets start at "workers per XCD"
+        for (int t = 0; t < 16; ++t) qc[(size_t)t * 32] = (unsigned)(nworkers / 8);
+        GP_HIP(hipMalloc(&e.qitems, sizeof(TrmmItem) * qflat.size()));
+        GP_HIP(hipMalloc((void **)&e.qn, sizeof(int) * 8));
+        GP_HIP(hipMalloc((void **)&e.qcnt, sizeof(unsigned int) * qc.size()));
+        GP_HIP(hipMemcpy(e.qitems, qflat.data(), sizeof(TrmmItem) * qflat.size(), hipMemcpyHostToDevice));
+        GP_HIP(hipMemcpy(e.qn, qn.data(), sizeof(int) * 8, hipMemcpyHostToDevice));
+        GP_HIP(hipMemcpy(e.qcnt, qc.data(), sizeof(unsigned int) * qc.size(), hipMemcpyHostToDevice));
+        e.qmax = (int)qmax;
+      }
       m->sched_cache.push_back(e);
       hit = &m->sched_cache.back();
     }
+    m->sched_cur = (int)(hit - m->sched_cache.data());
     m->sched_items = hit->items; m->sched_cnt = hit->cnt;
     m->sched_ncb = ncb; m->sched_cap = cap; m->sched_max_items = hit->max_items; m->sched_workers = hit->workers;
   }
@@ -1005,7 +1322,31 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
     GP_HIP(hipMalloc((void **)&dstamps, sizeof(unsigned long long) * 16 * 1024));
     GP_HIP(hipMemset(dstamps, 0, sizeof(unsigned long long) * 16 * 1024));
   }
-  if (use_dma && interleave)
+  // the work-queue form (GPEMU_TRMM_DYN=1; a measured negative, see trmm_vsq_dyn_kernel): default = the static LPT lists
+  static const bool use_dyn = getenv("GPEMU_TRMM_DYN") && atoi(getenv("GPEMU_TRMM_DYN")) != 0;
+  gpemu_model::SchedEntry *se = (m->sched_cur >= 0) ? &m->sched_cache[(size_t)m->sched_cur] : nullptr;
+  if (use_dma && interleave && use_dyn && se && se->qitems) {
+    // launches on one stream run in order: launch n draws from counter set n & 1 and re-arms the other one
+    const int qset = (int)(se->launches++ & 1u);
+    hipLaunchKernelGGL(trmm_vsq_dyn_kernel, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt, w.KS, w.vsq_part,
+                       (const TrmmItem *)se->qitems, se->qn, se->qcnt, qset, se->qmax, m->sched_workers / 8, m->Npad, w.Bcap,
+                       (int)m->k, nrb, dstamps);
+    static const bool dyn_debug = getenv("GPEMU_TRMM_DYN_DEBUG") != nullptr;
+    if (dyn_debug && se->launches == 50) {
+      GP_HIP(hipStreamSynchronize(st));
+      unsigned int hc[2 * 8 * 32];
+      int hn[8];
+      GP_HIP(hipMemcpy(hc, se->qcnt, sizeof(hc), hipMemcpyDeviceToHost));
+      GP_HIP(hipMemcpy(hn, se->qn, sizeof(hn), hipMemcpyDeviceToHost));
+      fprintf(stderr, "dyn queue after launch 50 (set %d used): items per XCD", qset);
+      for (int x = 0; x < 8; ++x) fprintf(stderr, " %d", hn[x]);
+      fprintf(stderr, "; counters used set:");
+      for (int x = 0; x < 8; ++x) fprintf(stderr, " %u", hc[(qset * 8 + x) * 32]);
+      fprintf(stderr, "; other set:");
+      for (int x = 0; x < 8; ++x) fprintf(stderr, " %u", hc[((qset ^ 1) * 8 + x) * 32]);
+      fprintf(stderr, "\n");
+    }
+  } else if (use_dma && interleave)
     hipLaunchKernelGGL(trmm_vsq_dma_kernel<true>, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
                        w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
                        m->Npad, w.Bcap, (int)m->k, nrb, dstamps);
@@ -1029,8 +1370,9 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
       unsigned long long t0 = ~0ull;
       for (int wk = 0; wk < m->sched_workers; ++wk) t0 = std::min(t0, h[wk * 16]);
       for (int wk = 0; wk < m->sched_workers; ++wk) {
+        if (h[wk * 16 + 14]) cnt[wk] = (int)h[wk * 16 + 14];          // the work-queue kernel: items the worker drew
         fprintf(f, "%d %d", wk, cnt[wk]);
-        for (int i = 0; i < 2 + std::min(cnt[wk], 13); ++i) fprintf(f, " %.2f", (double)(h[wk * 16 + i] - t0) / 100.0);
+        for (int i = 0; i < 2 + std::min(cnt[wk], 12); ++i) fprintf(f, " %.2f", (double)(h[wk * 16 + i] - t0) / 100.0);
         fprintf(f, "\n");
       }
       fclose(f);
