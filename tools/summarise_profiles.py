@@ -24,7 +24,9 @@ def first(pattern):
 
 for name, out in (("stats_bench/**/*kernel_stats.csv", f"{prefix}_bench_kernel_stats.csv"),
                   ("stats_emu8/**/*kernel_stats.csv", f"{prefix}_emulated_world8_kernel_stats.csv"),
-                  ("stats_pca/**/*kernel_stats.csv", f"{prefix}_pca_c3_kernel_stats.csv")):
+                  ("stats_pca/**/*kernel_stats.csv", f"{prefix}_pca_c3_kernel_stats.csv"),
+                  ("stats_predict/**/*kernel_stats.csv", f"{prefix}_predict_kernel_stats.csv"),
+                  ("stats_fit5000/**/*kernel_stats.csv", f"{prefix}_fit_n5000_kernel_stats.csv")):
     f = first(name)
     if f:
         shutil.copy(f, os.path.join(dst, out))
@@ -69,5 +71,16 @@ for B in (512, 64):
         kernels[k] = {"launches": n, "FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb,
                       "bytes_per_launch_corrected": 1024.0 * (2.0 * f_kb + w_kb)}
     traffic["batches"][str(B)] = kernels
+# emulation.predict (metric 2) at B = 1024: the covariance writer's WRITE_SIZE against the bytes it has to write
+fe, wr = pmc("pmc_fetch_predict", "FETCH_SIZE"), pmc("pmc_write_predict", "WRITE_SIZE")
+pk = {}
+for k in sorted(set(fe) | set(wr)):
+    if not any(s in k for s in ("predict_cov", "predict_full", "central_value", "trmm", "kstar")):
+        continue
+    n, f_kb = fe.get(k, (0, 0.0))
+    _, w_kb = wr.get(k, (0, 0.0))
+    pk[k] = {"launches": n, "FETCH_SIZE_KB_per_launch": f_kb, "WRITE_SIZE_KB_per_launch": w_kb,
+             "bytes_read_per_launch_corrected": 2048.0 * f_kb, "bytes_written_per_launch": 1024.0 * w_kb}
+traffic["predict_B1024"] = {"algorithmic_bytes_written": 8 * (1024 * 500 * 500 + 1024 * 500), "kernels": pk}
 json.dump(traffic, open(os.path.join(dst, f"{prefix}_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic["batches"], indent=1)[:3000])
