@@ -22,6 +22,8 @@ struct GemmArgs {
   int k_from_m = 0;    // op(A)[m][k] = 0 for k < m  (A upper triangular in (m, k)): start at the tile's first row
   int k_from_n = 0;    // op(B)[k][n] = 0 for k < n  (B lower triangular in (k, n)): start at the tile's first column
   int k_to_m = 0;      // op(A)[m][k] = 0 for k > m  (A lower triangular in (m, k)): stop after the tile's last row
+  int xcd_batch = 0;   // set by launch_gemm: whole problems of a batch per XCD (see the kernel)
+  int pair = 0;        // set by launch_gemm: a workgroup takes a tile and its mirror image along N (1) or M (2)
 };
 
 // C = alpha op(A) op(B) + beta C; a_kmajor: A stored [k][m] else [m][k]; b_kmajor: B stored [k][n]

@@ -187,7 +187,14 @@ int logpost_padded(gpemu_model *m, int64_t B, double *dXq, double *dout, int acc
                    hipStream_t st, const AcceptArgs *aa = nullptr, const ProposeArgs *pa = nullptr);
 // fit-side building blocks (k_fit.hip): in-place blocked Cholesky of an Np x Np matrix (Np multiple of 64) with the
 // inverted diagonal blocks in Dinv [Np/64][64][64], and W = L^-1 from it (T: Np x Np scratch)
-int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hipStream_t st, int nb = 1);
+// Optional look-ahead of the blocked Cholesky: a second (lower-priority) stream that applies a panel's update to the
+// columns beyond the next panel while the next panel is factored on the caller's stream (k_fit.hip).
+struct CholOverlap {
+  hipStream_t side = nullptr;
+  hipEvent_t panel_done = nullptr, rest_done = nullptr;
+};
+int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hipStream_t st, int nb = 1,
+                            const CholOverlap *ov = nullptr);
 int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double *W, double *T, hipStream_t st, int nb = 1);
 int device_invert_factor_to_Wt(const double *dL, int64_t N, double *Wt, int64_t Npad, double *A, double *Dinv,
                                double *W, double *T, hipStream_t st);

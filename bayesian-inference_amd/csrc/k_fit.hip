@@ -211,8 +211,15 @@ __device__ __forceinline__ void merge_level(double (*D)[NB + 1], double (*X)[NB 
 }
 
 // blockIdx.x: diagonal block (64 apart), blockIdx.y: problem of a batch (strides batchA, batchD; info per problem)
+#ifdef GPEMU_POTRF_STAMPS      // tools/potrf_probe.hip: cycle stamps of the phases of one launch
+__device__ long long g_potrf_stamps[16];
+#define POTRF_STAMP(i) do { if (threadIdx.x == 0) g_potrf_stamps[i] = clock64(); } while (0)
+#else
+#define POTRF_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda, double *Dinv, int do_factor,
                                                          int block_index, int *info, int64_t batchA, int64_t batchD) {
+  POTRF_STAMP(0);
   A += (int64_t)blockIdx.y * batchA;
   Dinv += (int64_t)blockIdx.y * batchD;
   info += blockIdx.y;
@@ -240,17 +247,21 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda,
     }
   }
   __syncthreads();
+  POTRF_STAMP(1);
   if (do_factor) {
     const int blk = block_index + (int)blockIdx.x;
     panel_step<0>(D, tid, blk, info);
-      panel_step<16>(D, tid, blk, info);
+    POTRF_STAMP(2);
+    panel_step<16>(D, tid, blk, info);
     panel_step<32>(D, tid, blk, info);
     panel_step<48>(D, tid, blk, info);
-      for (int idx = tid; idx < NB * NB; idx += 256) {
+    POTRF_STAMP(3);
+    for (int idx = tid; idx < NB * NB; idx += 256) {
       const int r = idx >> 6, c = idx & 63;
       Ab[(int64_t)r * lda + c] = D[r][c];    // zeros above the diagonal
     }
   }
+  POTRF_STAMP(4);
   // inverse of the four 16 x 16 diagonal blocks: wave w, lane = column
   if (lane < PB) {
     const int b0 = wave * PB, c = lane;
@@ -266,15 +277,18 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda,
     for (int ii = 0; ii < PB; ++ii) X[b0 + ii][b0 + c] = x[ii];
   }
   __syncthreads();
+  POTRF_STAMP(5);
   // merge pairs of inverted diagonal blocks of size b into blocks of size 2b (b = 16, then 32); the loops run
   // over the full b (X holds zeros above the diagonal, so the triangular structure needs no bounds) and are
   // unrolled, which lets the LDS reads of one output pipeline instead of waiting on a data-dependent trip count
   merge_level<16>(D, X, T, tid);
   merge_level<32>(D, X, T, tid);
+  POTRF_STAMP(6);
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
     Db[idx] = X[r][c];
   }
+  POTRF_STAMP(7);
 }
 
 // W[ib*64 + r][ib*64 + c] = Dinv[ib][r][c] for every 64 x 64 diagonal block ib = blockIdx.x
@@ -294,11 +308,11 @@ __global__ __launch_bounds__(256) void scatter_diag_blocks_kernel(const double *
 // Two levels: the 64-wide steps (diagonal factor, panel solve) only update the rest of their own PANEL of CHOL_Q blocks;
 // the trailing matrix beyond the panel gets ONE rank-(64 CHOL_Q) update per panel -- a quarter of the passes over it of a
 // rank-64 update per step (the update is HBM bound at K = 64: 8 FLOP per byte moved).
-int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hipStream_t st, int nb) {
+int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hipStream_t st, int nb, const CholOverlap *ov) {
   const int nblk = (int)(Np / NB);
   static const int chol_q = getenv("GPEMU_CHOL_PANEL_BLOCKS") ? std::max(1, atoi(getenv("GPEMU_CHOL_PANEL_BLOCKS"))) : 4;
   // A[rows r0 ..][cols c0 .. c1) -= A[rows r0 ..][k0 .. k1) . A[rows c0 .. c1)[k0 .. k1)^T, lower tiles only
-  auto update = [&](int64_t r0, int64_t c0, int64_t c1, int64_t k0, int64_t k1) -> int {
+  auto update = [&](int64_t r0, int64_t c0, int64_t c1, int64_t k0, int64_t k1, hipStream_t st) -> int {
     const int M = (int)(Np - r0), N = (int)(c1 - c0);
     if (M <= 0 || N <= 0) return GPEMU_OK;
     GemmArgs u;
@@ -309,6 +323,7 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
     u.strideA = Np * Np; u.strideB = Np * Np; u.strideC = Np * Np;
     return launch_gemm(u, false, false, nb, st);
   };
+  bool side_pending = false;
   for (int jb0 = 0; jb0 < nblk; jb0 += chol_q) {
     const int jb1 = std::min(nblk, jb0 + chol_q);             // the panel: blocks [jb0, jb1)
     for (int jb = jb0; jb < jb1; ++jb) {
@@ -328,14 +343,38 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
       int rc = launch_gemm(g, false, false, nb, st);
       if (rc != GPEMU_OK) return rc;
       // the rest of this panel's columns: blocks (jb, jb1), rows from block jb + 1 down
-      rc = update(j0 + NB, j0 + NB, (int64_t)jb1 * NB, j0, j0 + NB);
+      rc = update(j0 + NB, j0 + NB, (int64_t)jb1 * NB, j0, j0 + NB, st);
       if (rc != GPEMU_OK) return rc;
     }
     // everything beyond the panel, with the whole panel at once
-    const int64_t t0 = (int64_t)jb1 * NB;
-    const int rc = update(t0, t0, Np, (int64_t)jb0 * NB, t0);
+    const int64_t t0 = (int64_t)jb1 * NB, k0 = (int64_t)jb0 * NB;
+    if (t0 >= Np) break;
+    const int64_t t1 = std::min<int64_t>(Np, t0 + (int64_t)chol_q * NB);       // the next panel's columns: [t0, t1)
+    if (!ov) {
+      const int rc = update(t0, t0, Np, k0, t0, st);
+      if (rc != GPEMU_OK) return rc;
+      continue;
+    }
+    // Look-ahead.  Only the NEXT panel's columns are on the serial path: its 64-wide steps are single-workgroup and
+    // narrow launches that leave most of the chip idle.  The columns beyond it, [t1, Np), take this panel's update on
+    // the side stream while the next panel is factored on `st`:
+    //   side stream   reads this panel's columns (final), adds into columns >= t1 -- in its own stream order
+    //   st            next panel = columns [t0, t1) only; its update of them adds to what EARLIER side updates left
+    //                 there, so it waits for the previous panel's side update (`rest_done`), not for this one's
+    GP_HIP(hipEventRecord(ov->panel_done, st));
+    if (side_pending) GP_HIP(hipStreamWaitEvent(st, ov->rest_done, 0));        // the side update of the panel before
+    side_pending = false;
+    int rc = update(t0, t0, t1, k0, t0, st);
     if (rc != GPEMU_OK) return rc;
+    if (t1 < Np) {
+      GP_HIP(hipStreamWaitEvent(ov->side, ov->panel_done, 0));
+      rc = update(t1, t1, Np, k0, t0, ov->side);
+      if (rc != GPEMU_OK) return rc;
+      GP_HIP(hipEventRecord(ov->rest_done, ov->side));
+      side_pending = true;
+    }
   }
+  if (side_pending) GP_HIP(hipStreamWaitEvent(st, ov->rest_done, 0));
   return GPEMU_OK;
 }
 
@@ -629,6 +668,7 @@ struct gpemu_fit {
   int kind = 0, has_const = 0, has_noise = 0;
   double jitter = 0.0;
   hipStream_t stream = nullptr;
+  gpemu::CholOverlap overlap;      // side stream + events of the Cholesky look-ahead
   double *X = nullptr, *hp = nullptr, *K = nullptr, *Dinv = nullptr, *W = nullptr,
          *T = nullptr, *Kinv = nullptr, *y = nullptr, *v = nullptr, *alpha = nullptr, *gpart = nullptr,
          *scal = nullptr, *grad = nullptr, *gstage = nullptr;
@@ -698,7 +738,10 @@ static int fit_eval_batch(gpemu_fit *f, int nb, const double *ys, const double *
   hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)((Np + KMAT_ROWS - 1) / KMAT_ROWS), (unsigned)nb), dim3(256), 0, st, f->X,
                      f->hp, f->K, (int)N, (int)Np, f->kind, f->jitter);
   GP_HIP(hipGetLastError());
-  GP_TRY(device_cholesky_blocked(f->K, Np, f->Dinv, f->info, st, nb));
+  // look-ahead: GPEMU_CHOL_LOOKAHEAD=0 switches it off (read per call: a measurement knob)
+  const char *la = getenv("GPEMU_CHOL_LOOKAHEAD");
+  const bool lookahead = f->overlap.side && !(la && atoi(la) == 0);
+  GP_TRY(device_cholesky_blocked(f->K, Np, f->Dinv, f->info, st, nb, lookahead ? &f->overlap : nullptr));
   GP_TRY(device_trtri_blocked(f->K, Np, f->Dinv, f->W, f->T, st, nb));
   // alpha = W^T (W y)
   hipLaunchKernelGGL(gemv_kernel, dim3((unsigned)((Np + 3) / 4), (unsigned)nb), dim3(256), 0, st, f->W, Np, f->y, f->v,
@@ -776,7 +819,30 @@ int gpemu_fit_create(gpemu_fit **out, int device, int64_t N, int64_t d, const do
   f->jitter = jitter;
   const int64_t Np = f->Np;
   f->n_gparts = (int)(((N + 255) / 256) * N);
-  hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
+  // the serial chain of the factorisation runs on `stream`; the look-ahead updates fill the rest of the chip from a
+  // stream of lower priority, so that a waiting step of the chain is dispatched first
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  hipError_t e = hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, prio_greatest);
+  if (e == hipSuccess) {
+    // The side stream may not use the first GPEMU_CHOL_RESERVE (default 4) CUs of every XCD: its GEMM workgroups take a
+    // quarter of a CU's LDS each and are replaced one by one as they finish, so without a reserve the 75 KiB diagonal-block
+    // kernel of the serial chain finds no CU with room until the whole side grid has drained (measured: 18 -> 100 us).
+    // hipExtStreamCreateWithCUMask: bit i = CU i / 8 of XCD i % 8 (profiles/r03_cu_mask_probe.txt).
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    const int ncu = prop.multiProcessorCount;
+    const int reserve = getenv("GPEMU_CHOL_RESERVE") ? atoi(getenv("GPEMU_CHOL_RESERVE")) : 4;
+    if (e == hipSuccess && reserve > 0 && ncu % 8 == 0 && 8 * reserve < ncu) {
+      std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+      for (int i = 8 * reserve; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);
+      e = hipExtStreamCreateWithCUMask(&f->overlap.side, (uint32_t)mask.size(), mask.data());
+    } else if (e == hipSuccess) {
+      e = hipStreamCreateWithPriority(&f->overlap.side, hipStreamNonBlocking, prio_least);
+    }
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&f->overlap.panel_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&f->overlap.rest_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void **)&f->X, sizeof(double) * (size_t)(Np * DPAD));
   if (e == hipSuccess && fit_reserve(f, 1) != GPEMU_OK) e = hipErrorOutOfMemory;
   std::vector<double> hX((size_t)(Np * DPAD), 0.0);
@@ -796,6 +862,9 @@ int gpemu_fit_destroy(gpemu_fit *f) {
   if (!f) return GPEMU_OK;
   (void)hipSetDevice(f->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
+  if (f->overlap.side) { (void)hipStreamSynchronize(f->overlap.side); (void)hipStreamDestroy(f->overlap.side); }
+  if (f->overlap.panel_done) (void)hipEventDestroy(f->overlap.panel_done);
+  if (f->overlap.rest_done) (void)hipEventDestroy(f->overlap.rest_done);
   double *ptrs[] = {f->X, f->hp, f->K, f->Dinv, f->W, f->T, f->Kinv, f->y, f->v, f->alpha, f->gpart, f->scal, f->grad,
                     f->gstage};
   for (double *p : ptrs) (void)hipFree(p);

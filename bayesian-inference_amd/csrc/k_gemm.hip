@@ -37,16 +37,43 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   constexpr int TSZ = (GK * SK > T * GSM) ? GK * SK : T * GSM;
   __shared__ __attribute__((aligned(16))) double sA[2][TSZ];
   __shared__ __attribute__((aligned(16))) double sB[2][TSZ];
-  const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
-  if (g.lower_only && n0 > m0) return;
-  const int z1 = g.batch1 > 0 ? (int)(blockIdx.z % g.batch1) : (int)blockIdx.z;
-  const int z2 = g.batch1 > 0 ? (int)(blockIdx.z / g.batch1) : 0;
+  // Batch entry and tile of this workgroup.  Workgroups go to the 8 XCDs round-robin in launch order (x fastest, z
+  // slowest) and every XCD has its own 4 MiB L2: in launch order each XCD works on every 8th tile of the ~4 problems of a
+  // batch that are in flight and so streams all of their operands (64 problems of N = 1000: K^-1 = W^T W ran at 0.22 of
+  // peak, HBM-bound).  With `xcd_batch` the launch positions are re-dealt so that XCD x takes whole problems
+  // x, x + 8, ...: a problem's operands are read into one L2 only.  (A bijection of the grid when the number of
+  // problems is a multiple of 8; launch_gemm sets the flag only then.)
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.xcd_batch) {
+    const int gx = gridDim.x, gy = gridDim.y, b1 = g.batch1 > 0 ? g.batch1 : 1;
+    const int per_problem = gx * gy * b1;
+    const int lin = (bz * gy + by) * gx + bx;
+    const int xcd = lin & 7, j = lin >> 3;
+    const int problem = (j / per_problem) * 8 + xcd;
+    int rest = j % per_problem;
+    bx = rest % gx; rest /= gx;
+    by = rest % gy; rest /= gy;
+    bz = rest + b1 * problem;
+  }
+  const int z1 = g.batch1 > 0 ? (int)(bz % g.batch1) : bz;
+  const int z2 = g.batch1 > 0 ? (int)(bz / g.batch1) : 0;
   const double *A = g.A + (int64_t)z1 * g.strideA + (int64_t)z2 * g.stride2A;
   const double *B = g.B + (int64_t)z1 * g.strideB + (int64_t)z2 * g.stride2B;
   double *C = g.C + (int64_t)z1 * g.strideC + (int64_t)z2 * g.stride2C;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+  // Triangular operands make the K range of a tile depend on its column (k_from_n) or row (k_to_m): with about as many
+  // tiles as the chip holds workgroups, the launch lasts as long as the longest tile while the average one has half its
+  // k-steps (measured: 0.40 of peak against 0.77 for the dense product).  `pair` folds the tile grid: a workgroup takes
+  // tile t and then its mirror image T - 1 - t along that dimension, which together always have the same K range.
+  const int ntx = g.N / T, nty = g.M / T;
+  for (int rep = 0; rep < (g.pair ? 2 : 1); ++rep) {
+  int ty = by, tx = bx;
+  if (g.pair == 1 && rep == 1) { tx = ntx - 1 - tx; if (tx == bx) break; }
+  if (g.pair == 2 && rep == 1) { ty = nty - 1 - ty; if (ty == by) break; }
+  const int m0 = ty * T, n0 = tx * T;
+  if (g.lower_only && n0 > m0) continue;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 15, lk = lane >> 4;
@@ -141,7 +168,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     ktile(kt, 0, ra0, rb0, ra1, rb1);
     if (kt + 1 < nk) ktile(kt + 1, 1, ra1, rb1, ra0, rb0);
   }
-  if (dead) return;
+  if (dead) continue;
   // D[reg] is row (lane >> 4) + 4 * reg, column lane & 15 of each 16 x 16 tile
   auto cptr = [&](int mi, int ni, int r) {
     return C + (int64_t)(m0 + wm * (T / 2) + mi * 16 + lk + 4 * r) * g.ldc + n0 + wn * (T / 2) + ni * 16 + lr;
@@ -168,6 +195,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
         for (int r = 0; r < 4; ++r) *cptr(mi, ni, r) = fma(g.beta, cold[ni][r], g.alpha * acc[mi][ni][r]);
     }
   }
+  }   // rep
 }
 
 int launch_gemm(const GemmArgs &g, bool a_kmajor, bool b_kmajor, int batch, hipStream_t st) {
@@ -181,12 +209,30 @@ int launch_gemm(const GemmArgs &g, bool a_kmajor, bool b_kmajor, int batch, hipS
   // N = 1000: 5.2 vs 4.25 ms per 64 problems, N = 5000: 7.8 vs 6.4 ms (GPEMU_GEMM_BIG_MIN=256 to measure)
   static const int big_min = getenv("GPEMU_GEMM_BIG_MIN") ? atoi(getenv("GPEMU_GEMM_BIG_MIN")) : 0;
   const bool big = big_min > 0 && g.M >= big_min && g.N >= big_min;
+  GemmArgs gs = g;
+  // fold the tile grid where a triangular operand makes the K range run along one dimension only (see the kernel)
+  static const int pair_on = getenv("GPEMU_GEMM_PAIR") ? atoi(getenv("GPEMU_GEMM_PAIR")) : 1;
+  gs.pair = 0;
+  // ... when there are enough tiles to fill the chip at least half (fewer: a launch lasts as long as its longest tile
+  // either way, and folding only halves the workgroups -- b = 256 pairs batched: 17 -> 22 us)
+  const int64_t tiles = (int64_t)(g.M / GT) * (g.N / GT) * batch;
+  if (pair_on && !big && !g.lower_only && tiles >= 400) {
+    if (g.k_from_n && !g.k_from_m && !g.k_to_m && g.N >= 128) gs.pair = 1;
+    else if (g.k_to_m && !g.k_from_n && !g.k_from_m && g.M >= 128) gs.pair = 2;
+  }
   const int T = big ? 128 : 64;
+  {
+    static const int xcd_on = getenv("GPEMU_GEMM_XCD") ? atoi(getenv("GPEMU_GEMM_XCD")) : 1;
+    const int problems = g.batch1 > 0 ? batch / g.batch1 : batch;
+    gs.xcd_batch = (xcd_on && problems >= 8 && problems % 8 == 0 && (g.batch1 <= 0 || batch % g.batch1 == 0)) ? 1 : 0;
+  }
   dim3 grid((unsigned)((g.N + T - 1) / T), (unsigned)((g.M + T - 1) / T), (unsigned)batch), block(256);
+  if (gs.pair == 1) grid.x = (grid.x + 1) / 2;
+  if (gs.pair == 2) grid.y = (grid.y + 1) / 2;
 #define GP_LAUNCH_GEMM(AK, BK)                                                                  \
   do {                                                                                          \
-    if (big) hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, 4>), grid, block, 0, st, g);           \
-    else hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, 2>), grid, block, 0, st, g);               \
+    if (big) hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, 4>), grid, block, 0, st, gs);          \
+    else hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, 2>), grid, block, 0, st, gs);              \
   } while (0)
   if (a_kmajor && b_kmajor) GP_LAUNCH_GEMM(true, true);
   else if (a_kmajor && !b_kmajor) GP_LAUNCH_GEMM(true, false);
