@@ -192,10 +192,12 @@ int logpost_padded(gpemu_model *m, int64_t B, double *dXq, double *dout, int acc
 struct CholOverlap {
   hipStream_t side = nullptr;
   hipEvent_t panel_done = nullptr, rest_done = nullptr;
+  int *flags = nullptr;      // device, 20 ints per problem: enables the one-launch-per-panel kernel (k_fit.hip)
 };
 int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hipStream_t st, int nb = 1,
                             const CholOverlap *ov = nullptr);
-int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double *W, double *T, hipStream_t st, int nb = 1);
+int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double *W, double *T, hipStream_t st, int nb = 1,
+                         bool zero_upper = true);
 int device_invert_factor_to_Wt(const double *dL, int64_t N, double *Wt, int64_t Npad, double *A, double *Dinv,
                                double *W, double *T, hipStream_t st);
 // profiling helpers: record an event on `st` and return its pool index (-1 when profiling is off)

@@ -214,54 +214,26 @@ __device__ __forceinline__ void merge_level(double (*D)[NB + 1], double (*X)[NB 
 #ifdef GPEMU_POTRF_STAMPS      // tools/potrf_probe.hip: cycle stamps of the phases of one launch
 __device__ long long g_potrf_stamps[16];
 #define POTRF_STAMP(i) do { if (threadIdx.x == 0) g_potrf_stamps[i] = clock64(); } while (0)
+__device__ long long g_panel_stamps[128][16];     // [row of the panel][event]: wall_clock64 (100 MHz, one clock for all XCDs)
+#define PANEL_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 128) g_panel_stamps[blockIdx.x][k] = wall_clock64(); } while (0)
 #else
 #define POTRF_STAMP(i) do { } while (0)
+#define PANEL_STAMP(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda, double *Dinv, int do_factor,
-                                                         int block_index, int *info, int64_t batchA, int64_t batchD) {
-  POTRF_STAMP(0);
-  A += (int64_t)blockIdx.y * batchA;
-  Dinv += (int64_t)blockIdx.y * batchD;
-  info += blockIdx.y;
+
+// Cholesky factor of the 64 x 64 block in D (lower triangle, zeros above), in place; 256 threads
+__device__ __forceinline__ void tile_factor(double (*D)[NB + 1], int tid, int blk, int *info) {
+  panel_step<0>(D, tid, blk, info);
+  POTRF_STAMP(2);
+  panel_step<16>(D, tid, blk, info);
+  panel_step<32>(D, tid, blk, info);
+  panel_step<48>(D, tid, blk, info);
+}
+
+// X = D^-1 for the lower-triangular 64 x 64 factor D; X must hold zeros on entry; T is the scratch of the merges
+__device__ __forceinline__ void tile_inverse(double (*D)[NB + 1], double (*X)[NB + 1], double (*T)[32 + 1], int tid) {
   constexpr int PB = 16;
-  __shared__ double D[NB][NB + 1];     // the factor
-  __shared__ double X[NB][NB + 1];     // its inverse
-  __shared__ double T[32][32 + 1];     // L21 X11 of the merge in flight
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double *Ab = A + ((int64_t)blockIdx.x * NB) * lda + (int64_t)blockIdx.x * NB;
-  double *Db = Dinv + (int64_t)blockIdx.x * NB * NB;
-  {
-    // all 16 loads of a thread in flight together (the block was written by the previous launch on other CUs: every
-    // load is a trip to memory; issued one by one between the LDS stores they cost 4.7 us)
-    double v[NB * NB / 256];
-#pragma unroll
-    for (int u = 0; u < NB * NB / 256; ++u) {
-      const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
-      v[u] = (c <= r) ? Ab[(int64_t)r * lda + c] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < NB * NB / 256; ++u) {
-      const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
-      D[r][c] = v[u];
-      X[r][c] = 0.0;
-    }
-  }
-  __syncthreads();
-  POTRF_STAMP(1);
-  if (do_factor) {
-    const int blk = block_index + (int)blockIdx.x;
-    panel_step<0>(D, tid, blk, info);
-    POTRF_STAMP(2);
-    panel_step<16>(D, tid, blk, info);
-    panel_step<32>(D, tid, blk, info);
-    panel_step<48>(D, tid, blk, info);
-    POTRF_STAMP(3);
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-      const int r = idx >> 6, c = idx & 63;
-      Ab[(int64_t)r * lda + c] = D[r][c];    // zeros above the diagonal
-    }
-  }
-  POTRF_STAMP(4);
+  const int lane = tid & 63, wave = tid >> 6;
   // inverse of the four 16 x 16 diagonal blocks: wave w, lane = column
   if (lane < PB) {
     const int b0 = wave * PB, c = lane;
@@ -283,12 +255,240 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda,
   // unrolled, which lets the LDS reads of one output pipeline instead of waiting on a data-dependent trip count
   merge_level<16>(D, X, T, tid);
   merge_level<32>(D, X, T, tid);
+}
+
+// blockIdx.x: diagonal block (64 apart), blockIdx.y: problem of a batch (strides batchA, batchD; info per problem)
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda, double *Dinv, int do_factor,
+                                                         int block_index, int *info, int64_t batchA, int64_t batchD) {
+  POTRF_STAMP(0);
+  A += (int64_t)blockIdx.y * batchA;
+  Dinv += (int64_t)blockIdx.y * batchD;
+  info += blockIdx.y;
+  __shared__ double D[NB][NB + 1];     // the factor
+  __shared__ double X[NB][NB + 1];     // its inverse
+  __shared__ double T[32][32 + 1];     // L21 X11 of the merge in flight
+  const int tid = threadIdx.x;
+  double *Ab = A + ((int64_t)blockIdx.x * NB) * lda + (int64_t)blockIdx.x * NB;
+  double *Db = Dinv + (int64_t)blockIdx.x * NB * NB;
+  {
+    // all 16 loads of a thread in flight together (the block was written by the previous launch on other CUs: every
+    // load is a trip to memory; issued one by one between the LDS stores they cost 4.7 us)
+    double v[NB * NB / 256];
+#pragma unroll
+    for (int u = 0; u < NB * NB / 256; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
+      v[u] = (c <= r) ? Ab[(int64_t)r * lda + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < NB * NB / 256; ++u) {
+      const int idx = tid + 256 * u, r = idx >> 6, c = idx & 63;
+      D[r][c] = v[u];
+      X[r][c] = 0.0;
+    }
+  }
+  __syncthreads();
+  POTRF_STAMP(1);
+  if (do_factor) {
+    tile_factor(D, tid, block_index + (int)blockIdx.x, info);
+    POTRF_STAMP(3);
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      Ab[(int64_t)r * lda + c] = D[r][c];    // zeros above the diagonal
+    }
+  }
+  POTRF_STAMP(4);
+  tile_inverse(D, X, T, tid);
   POTRF_STAMP(6);
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int r = idx >> 6, c = idx & 63;
     Db[idx] = X[r][c];
   }
   POTRF_STAMP(7);
+}
+
+// ---- one launch per 256-wide panel ------------------------------------------------------------------
+// The four 64-wide steps of a panel (diagonal factor, solve of the rows below, update of the rest of the panel) used
+// to be three dependent launches each -- 12 launch boundaries and as many round trips through memory on the serial
+// path of the factorisation.  Here one workgroup owns one 64-row strip of the panel [rows rb*64 .., columns of the
+// panel] for the whole panel, keeps it in registers (MFMA accumulator layout) and walks the steps s = 0 .. 3:
+//     wait for Dinv_s              (published by the workgroup of diagonal row s: "head" s)
+//     L_rs = A_rs Dinv_s^T         -> memory (in place)
+//     A_rc -= L_rs L_cs^T          for the later columns c of the panel, L_cs published by head c
+// and a head, when it arrives at its own diagonal block, factors and inverts it in LDS and publishes the inverse.
+// Publication is a release store of the panel's tag to a flag, consumption an acquire load (agent scope: the strips
+// live on different XCDs).  No deadlock: a workgroup only ever waits for heads, heads only for heads of smaller row
+// index, and workgroups start in launch order (blockIdx.x = row within the panel, heads first) -- whoever is waited
+// for has been started.  Every wait is bounded all the same (info = -1 on expiry) so that a fault cannot hang the GPU.
+// The arithmetic (operand order of every MFMA chain, C - acc for the updates) is that of the three-launch path: the
+// factor has the same bits.
+constexpr int CHOL_Q = 4;                       // blocks per panel
+constexpr int CHOL_FLAGS = 4 + 4 * 4;           // per problem: D ready [4], L_cs ready [c][s]
+constexpr int CHOL_WAIT_POLLS = 1 << 20;       // ~1 s
+
+// Publication protocol.  The published blocks (Dinv_s, L_cs: 32 KiB each) are written and read with agent-scope
+// relaxed atomics -- stores that go through to the coherence point, loads that do not trust this XCD's L2 -- instead
+// of ordinary accesses bracketed by agent-scope release / acquire fences: those fences write back, respectively
+// invalidate, the WHOLE L2 of the XCD, which the ~10 strips per XCD keep full of their own freshly written blocks
+// (measured: a head's step 18 -> 23 us with 79 strips in flight).  The flag follows when every thread's stores have
+// been acknowledged (workgroup-scope release + barrier).
+__device__ __forceinline__ void publish_store(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double published_load(const double *p) {
+  return __hip_atomic_load(const_cast<double *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool HEAD>
+__device__ __forceinline__ void chol_wait(int *flag, int tag, int *info) {
+  if (threadIdx.x == 0) {
+    int polls = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+      __builtin_amdgcn_s_sleep(HEAD ? 4 : 12);
+      // give up: once anywhere in this problem, then everybody at once (the results are void, the launch must end)
+      if (++polls > CHOL_WAIT_POLLS || ((polls & 1023) == 0 && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0)) {
+        __hip_atomic_store(info, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void chol_post(int *flag, int tag) {
+  // this thread's publish_stores are acknowledged (gfx9 counts stores in vmcnt; a workgroup-scope release fence does not
+  // wait for them: the waves of a workgroup share their L1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// out = rows [16 wave, 16 wave + 16) of U V^T (64 x 64 x 64), four 16 x 16 tiles per wave, k ascending
+__device__ __forceinline__ void strip_product(const double (*U)[NB + 1], const double (*V)[NB + 1], int wave, int lane,
+                                              d4t (&out)[4]) {
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) out[nt] = d4t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < NB / 4; ++ks) {
+    const double a = U[16 * wave + lr][4 * ks + lk];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) out[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, V[16 * nt + lr][4 * ks + lk], out[nt], 0, 0, 0);
+  }
+}
+
+// grid (rows of the panel = nblk - jb0, problems); npb = blocks of this panel (<= 4)
+__global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, double *Dinv, int jb0, int npb, int *info,
+                                                         int *flags, int tag, int64_t batchA, int64_t batchD) {
+  A += (int64_t)blockIdx.y * batchA;
+  Dinv += (int64_t)blockIdx.y * batchD;
+  info += blockIdx.y;
+  flags += (int64_t)blockIdx.y * CHOL_FLAGS;
+  PANEL_STAMP(0);
+  __shared__ double U[NB][NB + 1];     // this strip's current column block (rows wave-private) / the factor of a head
+  __shared__ double V[NB][NB + 1];     // Dinv_s or L_cs / the inverse of a head
+  __shared__ double T[32][32 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  const int q = blockIdx.x, rb = jb0 + q;
+  const bool head = q < npb;
+  const int ncol = head ? q + 1 : npb;           // column blocks of the panel on or under the diagonal in this row
+  double *Arow = A + ((int64_t)rb * NB) * Np + (int64_t)jb0 * NB;
+  // acc[c][nt][reg]: row 16 wave + lk + 4 reg, column 64 c + 16 nt + lr of the strip
+  d4t acc[CHOL_Q][4];
+#pragma unroll
+  for (int c = 0; c < CHOL_Q; ++c)
+    if (c < ncol) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[c][nt][r] = Arow[(int64_t)(16 * wave + lk + 4 * r) * Np + 64 * c + 16 * nt + lr];
+    }
+  auto load_V = [&](const double *src, int64_t ld) {     // a 64 x 64 block from memory, all loads of a thread in flight
+    double v[NB * NB / 256];
+#pragma unroll
+    for (int u = 0; u < NB * NB / 256; ++u) {
+      const int idx = tid + 256 * u;
+      v[u] = published_load(src + (int64_t)(idx >> 6) * ld + (idx & 63));
+    }
+#pragma unroll
+    for (int u = 0; u < NB * NB / 256; ++u) {
+      const int idx = tid + 256 * u;
+      V[idx >> 6][idx & 63] = v[u];
+    }
+  };
+  PANEL_STAMP(1);                                // strip loaded (issued)
+  const int nsolve = head ? q : npb;             // column blocks left of the diagonal: solved against the heads' inverses
+#pragma unroll
+  for (int s = 0; s < CHOL_Q; ++s) {
+    if (s >= nsolve) continue;                   // (no break: the loop must unroll, acc lives in registers)
+    // L_rs = A_rs Dinv_s^T
+    if (head) chol_wait<true>(flags + s, tag, info); else chol_wait<false>(flags + s, tag, info);
+    PANEL_STAMP(2 + 2 * s);                      // Dinv_s seen
+    load_V(Dinv + (int64_t)(jb0 + s) * NB * NB, NB);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) U[16 * wave + lk + 4 * r][16 * nt + lr] = acc[s][nt][r];
+    __syncthreads();
+    d4t l[4];
+    strip_product(U, V, wave, lane, l);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double *dst = Arow + (int64_t)(16 * wave + lk + 4 * r) * Np + 64 * s + 16 * nt + lr;
+        if (head) publish_store(dst, l[nt][r]); else *dst = l[nt][r];
+        U[16 * wave + lk + 4 * r][16 * nt + lr] = l[nt][r];      // own rows of U: read by this wave only
+      }
+    if (head) chol_post(flags + 4 + 4 * q + s, tag);             // L_qs for the rows below (barrier inside)
+    else __syncthreads();                                        // everyone is done with V = Dinv_s
+    // A_rc -= L_rs L_cs^T for the later columns
+#pragma unroll
+    for (int c = s + 1; c < CHOL_Q; ++c) {
+      if (c >= ncol) continue;
+      if (head && c == q) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) V[16 * wave + lk + 4 * r][16 * nt + lr] = l[nt][r];    // L_cs is this row's own
+      } else {
+        if (head) chol_wait<true>(flags + 4 + 4 * c + s, tag, info); else chol_wait<false>(flags + 4 + 4 * c + s, tag, info);
+        load_V(A + ((int64_t)(jb0 + c) * NB) * Np + (int64_t)(jb0 + s) * NB, Np);
+      }
+      __syncthreads();
+      d4t t[4];
+      strip_product(U, V, wave, lane, t);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[c][nt][r] -= t[nt][r];
+      __syncthreads();                                           // before V is refilled
+    }
+    PANEL_STAMP(3 + 2 * s);                      // step s done
+  }
+  if (head) {
+    // the diagonal block of this head, now with the updates of the steps before it: factor, invert, publish
+#pragma unroll
+    for (int c = 0; c < CHOL_Q; ++c)
+      if (c == q) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wave + lk + 4 * r, col = 16 * nt + lr;
+            U[row][col] = (col <= row) ? acc[c][nt][r] : 0.0;
+            V[row][col] = 0.0;
+          }
+      }
+    __syncthreads();
+    tile_factor(U, tid, rb, info);
+    for (int idx = tid; idx < NB * NB; idx += 256) Arow[(int64_t)(idx >> 6) * Np + 64 * q + (idx & 63)] = U[idx >> 6][idx & 63];
+    tile_inverse(U, V, T, tid);
+    double *Db = Dinv + (int64_t)rb * NB * NB;
+    for (int idx = tid; idx < NB * NB; idx += 256) publish_store(Db + idx, V[idx >> 6][idx & 63]);
+    chol_post(flags + q, tag);
+  }
+  PANEL_STAMP(10);
 }
 
 // W[ib*64 + r][ib*64 + c] = Dinv[ib][r][c] for every 64 x 64 diagonal block ib = blockIdx.x
@@ -324,9 +524,20 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
     return launch_gemm(u, false, false, nb, st);
   };
   bool side_pending = false;
+  // one launch per panel (chol_panel_kernel) where the caller provides its flags and the strips of all problems fit on
+  // the chip a few times over; GPEMU_CHOL_PANEL=0: the three-launch steps (same bits)
+  static const int panel_on = getenv("GPEMU_CHOL_PANEL") ? atoi(getenv("GPEMU_CHOL_PANEL")) : 1;
+  static const int panel_max_wg = getenv("GPEMU_CHOL_PANEL_MAX_WG") ? atoi(getenv("GPEMU_CHOL_PANEL_MAX_WG")) : 320;
+  const bool fused = panel_on && chol_q == CHOL_Q && ov && ov->flags && (int64_t)nblk * nb <= panel_max_wg;
+  if (fused) GP_HIP(hipMemsetAsync(ov->flags, 0, sizeof(int) * (size_t)CHOL_FLAGS * nb, st));
   for (int jb0 = 0; jb0 < nblk; jb0 += chol_q) {
     const int jb1 = std::min(nblk, jb0 + chol_q);             // the panel: blocks [jb0, jb1)
-    for (int jb = jb0; jb < jb1; ++jb) {
+    if (fused) {
+      hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(nblk - jb0), (unsigned)nb), dim3(256), 0, st, A, Np, Dinv, jb0,
+                         jb1 - jb0, dinfo, ov->flags, jb0 / chol_q + 1, Np * Np, Np * NB);
+      GP_HIP(hipGetLastError());
+    }
+    for (int jb = jb0; jb < jb1 && !fused; ++jb) {
       const int64_t j0 = (int64_t)jb * NB;
       hipLaunchKernelGGL(potrf_diag_kernel, dim3(1, (unsigned)nb), dim3(256), 0, st, A + j0 * Np + j0, Np,
                          Dinv + (int64_t)jb * NB * NB, 1, jb, dinfo, Np * Np, Np * NB);
@@ -350,7 +561,7 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
     const int64_t t0 = (int64_t)jb1 * NB, k0 = (int64_t)jb0 * NB;
     if (t0 >= Np) break;
     const int64_t t1 = std::min<int64_t>(Np, t0 + (int64_t)chol_q * NB);       // the next panel's columns: [t0, t1)
-    if (!ov) {
+    if (!ov || !ov->side) {
       const int rc = update(t0, t0, Np, k0, t0, st);
       if (rc != GPEMU_OK) return rc;
       continue;
@@ -383,9 +594,11 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
 // diagonal of W; a pair (W11, W22) becomes inv([[L11,0],[L21,L22]]) by  W21 = -W22 (L21 W11),
 // two GEMMs per level, batched over all pairs (blockIdx.z), so the whole inverse takes
 // 2 log2(Np/64) (+ ragged-tail) launches of large MFMA GEMMs.  T is an Np x Np scratch.
-int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double *W, double *T, hipStream_t st, int nb) {
+int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double *W, double *T, hipStream_t st, int nb,
+                         bool zero_upper) {
   const int nblk = (int)(Np / NB);
-  GP_HIP(hipMemsetAsync(W, 0, sizeof(double) * (size_t)(Np * Np) * nb, st));
+  // what lies above the block diagonal is never written below: zero it for readers of the full square
+  if (zero_upper) GP_HIP(hipMemsetAsync(W, 0, sizeof(double) * (size_t)(Np * Np) * nb, st));
   // diagonal blocks: Dinv [nblk][64][64] -> W, one launch
   hipLaunchKernelGGL(scatter_diag_blocks_kernel, dim3((unsigned)nblk, (unsigned)nb), dim3(256), 0, st, Dinv, W, Np);
   GP_HIP(hipGetLastError());
@@ -428,8 +641,10 @@ int device_trtri_blocked(const double *L, int64_t Np, const double *Dinv, double
 
 // ---- small vector kernels ------------------------------------------------------------------------
 // out[i] = sum_j M[i][j] v[j] (trans = 0, one wave per row) or sum_j M[j][i] v[j] (trans = 1)
+// lower = 1: M is lower triangular in 64 x 64 blocks; what lies above the block diagonal is not read (it need not even be
+// initialised) -- the skipped terms are exact zeros, so the sums keep their bits.
 __global__ void gemv_kernel(const double *__restrict__ Mx, int64_t ld, const double *__restrict__ v,
-                            double *__restrict__ out, int n, int trans) {
+                            double *__restrict__ out, int n, int trans, int lower) {
   Mx += (int64_t)blockIdx.y * ld * ld;        // blockIdx.y: problem of a batch (square matrices ld x ld, vectors of ld)
   v += (int64_t)blockIdx.y * ld;
   out += (int64_t)blockIdx.y * ld;
@@ -438,7 +653,8 @@ __global__ void gemv_kernel(const double *__restrict__ Mx, int64_t ld, const dou
     const int lane = threadIdx.x & 63;
     if (row >= n) return;
     double s = 0.0;
-    for (int j = lane; j < n; j += 64) s = fma(Mx[(int64_t)row * ld + j], v[j], s);
+    const int jend = lower ? min(n, (row / NB + 1) * NB) : n;
+    for (int j = lane; j < jend; j += 64) s = fma(Mx[(int64_t)row * ld + j], v[j], s);
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) out[row] = s;
   } else {
@@ -454,10 +670,14 @@ __global__ void gemv_kernel(const double *__restrict__ Mx, int64_t ld, const dou
 // then a column sum over the chunks
 __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double *__restrict__ Mx, int64_t ld,
                                                              const double *__restrict__ v, double *__restrict__ part,
-                                                             int n) {
+                                                             int n, int lower) {
   const int col = blockIdx.x * 256 + threadIdx.x;
   const int j0 = blockIdx.y * 64;
   if (col >= n) return;
+  if (lower && (int)blockIdx.y < col / NB) {      // rows above this column's diagonal block: zeros, not read
+    part[(int64_t)blockIdx.z * ld * ld + (int64_t)blockIdx.y * n + col] = 0.0;
+    return;
+  }
   Mx += (int64_t)blockIdx.z * ld * ld;        // blockIdx.z: problem of a batch
   v += (int64_t)blockIdx.z * ld;
   part += (int64_t)blockIdx.z * ld * ld;
@@ -707,6 +927,9 @@ static int fit_reserve(gpemu_fit *f, int nb) {
   A(&f->gpart, (int64_t)f->n_gparts * NTH_MAX); A(&f->scal, 4); A(&f->grad, NTH_MAX);
   A(&f->gstage, (int64_t)GR_BLOCKS * NTH_MAX);
   if (e == hipSuccess) e = hipMalloc((void **)&f->info, sizeof(int) * nb);
+  (void)hipFree(f->overlap.flags);
+  f->overlap.flags = nullptr;
+  if (e == hipSuccess) e = hipMalloc((void **)&f->overlap.flags, sizeof(int) * (size_t)CHOL_FLAGS * nb);
   if (e != hipSuccess) { set_error("fit workspace for %d problems: %s", nb, hipGetErrorString(e)); return GPEMU_ERR_HIP; }
   f->cap = nb;
   return GPEMU_OK;
@@ -738,18 +961,22 @@ static int fit_eval_batch(gpemu_fit *f, int nb, const double *ys, const double *
   hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)((Np + KMAT_ROWS - 1) / KMAT_ROWS), (unsigned)nb), dim3(256), 0, st, f->X,
                      f->hp, f->K, (int)N, (int)Np, f->kind, f->jitter);
   GP_HIP(hipGetLastError());
-  // look-ahead: GPEMU_CHOL_LOOKAHEAD=0 switches it off (read per call: a measurement knob)
+  // look-ahead: measured at +-1 % for N = 5000, batches of 8 and of 64 x N = 1000 (the serial steps slow down by what the
+  // overlap gains: profiles/r03_chol_lookahead.txt), so it stays off; GPEMU_CHOL_LOOKAHEAD=1 switches it on (read per call)
   const char *la = getenv("GPEMU_CHOL_LOOKAHEAD");
-  const bool lookahead = f->overlap.side && !(la && atoi(la) == 0);
-  GP_TRY(device_cholesky_blocked(f->K, Np, f->Dinv, f->info, st, nb, lookahead ? &f->overlap : nullptr));
-  GP_TRY(device_trtri_blocked(f->K, Np, f->Dinv, f->W, f->T, st, nb));
+  const bool lookahead = f->overlap.side && la && atoi(la) == 1;
+  CholOverlap ov = f->overlap;
+  if (!lookahead) ov.side = nullptr;
+  GP_TRY(device_cholesky_blocked(f->K, Np, f->Dinv, f->info, st, nb, &ov));
+  // every reader of W below keeps to the 64 x 64 blocks on and under the diagonal: no zero fill of the rest
+  GP_TRY(device_trtri_blocked(f->K, Np, f->Dinv, f->W, f->T, st, nb, false));
   // alpha = W^T (W y)
   hipLaunchKernelGGL(gemv_kernel, dim3((unsigned)((Np + 3) / 4), (unsigned)nb), dim3(256), 0, st, f->W, Np, f->y, f->v,
-                     (int)Np, 0);
+                     (int)Np, 0, 1);
   {
     const int nchunk = (int)((Np + 63) / 64);                 // T (Np x Np) is free again after the inverse
     hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)nchunk, (unsigned)nb), dim3(256),
-                       0, st, f->W, Np, f->v, f->T, (int)Np);
+                       0, st, f->W, Np, f->v, f->T, (int)Np, 1);
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)nb), dim3(256), 0, st, f->T, nchunk,
                        (int)Np, f->alpha);
   }
@@ -779,6 +1006,10 @@ static int fit_eval_batch(gpemu_fit *f, int nb, const double *ys, const double *
   int first_bad = 0;
   for (int z = 0; z < nb; ++z) {
     if (info_out) info_out[z] = info[z];
+    if (info[z] < 0) {
+      set_error("fit: a workgroup of the panel factorisation waited for its neighbour beyond the poll bound");
+      return GPEMU_ERR_STATE;
+    }
     if (info[z] != 0 && first_bad == 0) first_bad = info[z];
     if (lml) lml[z] = -0.5 * hs[(size_t)z * 4] - hs[(size_t)z * 4 + 1] - 0.5 * (double)N * std::log(2.0 * M_PI);
     if (want_grad && grad)
@@ -869,6 +1100,7 @@ int gpemu_fit_destroy(gpemu_fit *f) {
                     f->gstage};
   for (double *p : ptrs) (void)hipFree(p);
   (void)hipFree(f->info);
+  (void)hipFree(f->overlap.flags);
   if (f->stream) (void)hipStreamDestroy(f->stream);
   delete f;
   return GPEMU_OK;

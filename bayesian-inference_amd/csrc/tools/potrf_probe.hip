@@ -47,6 +47,35 @@ int main() {
     printf("%d dependent launches: %.2f us each\n", nblk, 1e3 * ms / nblk);
     hipMemcpy(A, h.data(), sizeof(double) * Np * Np, hipMemcpyHostToDevice);
   }
+  {
+    // one launch of the panel kernel on the first panel of a fresh matrix: who does what when (us after the first start)
+    hipMemcpy(A, h.data(), sizeof(double) * Np * Np, hipMemcpyHostToDevice);
+    int *flags;
+    hipMalloc(&flags, sizeof(int) * gpemu::CHOL_FLAGS);
+    for (int rows : {79, 39, 11}) {
+      hipMemcpy(A, h.data(), sizeof(double) * Np * Np, hipMemcpyHostToDevice);
+      hipMemset(flags, 0, sizeof(int) * gpemu::CHOL_FLAGS);
+      hipEventRecord(e0, nullptr);
+      hipLaunchKernelGGL(gpemu::chol_panel_kernel, dim3(rows, 1), dim3(256), 0, nullptr, A, Np, Dinv, 0, 4, info, flags, 1, Np * Np, Np * 64);
+      hipEventRecord(e1, nullptr);
+      hipEventSynchronize(e1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, e0, e1);
+      static long long ps[128][16];
+      hipMemcpyFromSymbol(ps, HIP_SYMBOL(gpemu::g_panel_stamps), sizeof(ps));
+      long long t0 = ps[0][0];
+      for (int r = 0; r < rows; ++r) t0 = ps[r][0] < t0 ? ps[r][0] : t0;
+      printf("panel kernel, %d rows: %.1f us by events\n row  start loaded |  D0 seen, step 0 done | D1 ... | D2 ... | D3 ... | end\n", rows, 1e3 * ms);
+      for (int r = 0; r < rows; ++r) {
+        if (r >= 6 && r < rows - 3 && r % 16) continue;
+        printf("%4d", r);
+        for (int k = 0; k <= 10; ++k) printf(" %7.2f", ps[r][k] ? (ps[r][k] - t0) / 100.0 : 0.0);
+        printf("\n");
+      }
+      static long long zero[128][16];
+      hipMemcpyToSymbol(HIP_SYMBOL(gpemu::g_panel_stamps), zero, sizeof(zero));
+    }
+  }
   long long st[16];
   hipMemcpyFromSymbol(st, HIP_SYMBOL(gpemu::g_potrf_stamps), sizeof(st));
   const char *names[] = {"global load -> LDS", "panel step 0", "panel steps 1-3", "store factor", "16 x 16 inverses", "two merge levels",
