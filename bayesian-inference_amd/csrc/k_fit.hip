@@ -235,15 +235,21 @@ __device__ __forceinline__ void tile_inverse(double (*D)[NB + 1], double (*X)[NB
   constexpr int PB = 16;
   const int lane = tid & 63, wave = tid >> 6;
   // inverse of the four 16 x 16 diagonal blocks: wave w, lane = column
+  // Forward substitution, column by column of L (right-looking): once x[mm] is known every later row takes its term
+  // -- independent FMAs; the serial path is one multiply and one FMA per row instead of a dot product and a division.
+  // The reciprocals of the diagonal: one division per lane, handed round through the scratch T (same wave: in order).
   if (lane < PB) {
     const int b0 = wave * PB, c = lane;
-    double x[PB];
+    double *rdiag = &T[0][0] + b0;
+    rdiag[c] = 1.0 / D[b0 + c][b0 + c];
+    double acc[PB], x[PB];
 #pragma unroll
-    for (int ii = 0; ii < PB; ++ii) {
-      double sacc = (ii == c) ? 1.0 : 0.0;
+    for (int ii = 0; ii < PB; ++ii) acc[ii] = (ii == c) ? 1.0 : 0.0;
 #pragma unroll
-      for (int mm = 0; mm < ii; ++mm) sacc = fma(-D[b0 + ii][b0 + mm], x[mm], sacc);   // uniform address: broadcast
-      x[ii] = (ii >= c) ? sacc / D[b0 + ii][b0 + ii] : 0.0;
+    for (int mm = 0; mm < PB; ++mm) {
+      x[mm] = (mm >= c) ? acc[mm] * rdiag[mm] : 0.0;
+#pragma unroll
+      for (int ii = mm + 1; ii < PB; ++ii) acc[ii] = fma(-D[b0 + ii][b0 + mm], x[mm], acc[ii]);   // uniform address: broadcast
     }
 #pragma unroll
     for (int ii = 0; ii < PB; ++ii) X[b0 + ii][b0 + c] = x[ii];
@@ -440,7 +446,11 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, 
         if (head) publish_store(dst, l[nt][r]); else *dst = l[nt][r];
         U[16 * wave + lk + 4 * r][16 * nt + lr] = l[nt][r];      // own rows of U: read by this wave only
       }
-    if (head) chol_post(flags + 4 + 4 * q + s, tag);             // L_qs for the rows below (barrier inside)
+    // L_qs for the rows below (barrier inside).  In a head's last step (s = q - 1) the only update is the one of its
+    // own diagonal block, which is what the next publication of Dinv waits for: it goes first, the stores of L_qs
+    // complete underneath it and the post follows the update (its readers have until Dinv_q arrives)
+    const bool post_late = head && s == q - 1;
+    if (head && !post_late) chol_post(flags + 4 + 4 * q + s, tag);
     else __syncthreads();                                        // everyone is done with V = Dinv_s
     // A_rc -= L_rs L_cs^T for the later columns
 #pragma unroll
@@ -464,6 +474,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, 
         for (int r = 0; r < 4; ++r) acc[c][nt][r] -= t[nt][r];
       __syncthreads();                                           // before V is refilled
     }
+    if (post_late) chol_post(flags + 4 + 4 * q + s, tag);
     PANEL_STAMP(3 + 2 * s);                      // step s done
   }
   if (head) {
@@ -482,11 +493,12 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, 
       }
     __syncthreads();
     tile_factor(U, tid, rb, info);
-    for (int idx = tid; idx < NB * NB; idx += 256) Arow[(int64_t)(idx >> 6) * Np + 64 * q + (idx & 63)] = U[idx >> 6][idx & 63];
     tile_inverse(U, V, T, tid);
     double *Db = Dinv + (int64_t)rb * NB * NB;
     for (int idx = tid; idx < NB * NB; idx += 256) publish_store(Db + idx, V[idx >> 6][idx & 63]);
     chol_post(flags + q, tag);
+    // the factor itself is not read before the next launch: after the publication
+    for (int idx = tid; idx < NB * NB; idx += 256) Arow[(int64_t)(idx >> 6) * Np + 64 * q + (idx & 63)] = U[idx >> 6][idx & 63];
   }
   PANEL_STAMP(10);
 }
@@ -561,13 +573,18 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
     const int64_t t0 = (int64_t)jb1 * NB, k0 = (int64_t)jb0 * NB;
     if (t0 >= Np) break;
     const int64_t t1 = std::min<int64_t>(Np, t0 + (int64_t)chol_q * NB);       // the next panel's columns: [t0, t1)
-    if (!ov || !ov->side) {
+    // (worth its two cross-stream events -- ~12 us per panel -- only while the side update is long: measured per panel
+    // -43 us with 60 tile rows left, break-even at ~38: profiles/r03_chol_lookahead.txt)
+    static const int la_min = getenv("GPEMU_CHOL_LOOKAHEAD_MIN") ? atoi(getenv("GPEMU_CHOL_LOOKAHEAD_MIN")) : 40;
+    if (!ov || !ov->side || !fused || Np - t1 < (int64_t)la_min * NB) {
+      if (side_pending) GP_HIP(hipStreamWaitEvent(st, ov->rest_done, 0));
+      side_pending = false;
       const int rc = update(t0, t0, Np, k0, t0, st);
       if (rc != GPEMU_OK) return rc;
       continue;
     }
-    // Look-ahead.  Only the NEXT panel's columns are on the serial path: its 64-wide steps are single-workgroup and
-    // narrow launches that leave most of the chip idle.  The columns beyond it, [t1, Np), take this panel's update on
+    // Look-ahead.  Only the NEXT panel's columns are on the serial path: its panel kernel is a chain of four diagonal
+    // blocks on at most one CU per strip, which leaves most of the chip idle.  The columns beyond it, [t1, Np), take this panel's update on
     // the side stream while the next panel is factored on `st`:
     //   side stream   reads this panel's columns (final), adds into columns >= t1 -- in its own stream order
     //   st            next panel = columns [t0, t1) only; its update of them adds to what EARLIER side updates left
@@ -961,10 +978,10 @@ static int fit_eval_batch(gpemu_fit *f, int nb, const double *ys, const double *
   hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)((Np + 255) / 256), (unsigned)((Np + KMAT_ROWS - 1) / KMAT_ROWS), (unsigned)nb), dim3(256), 0, st, f->X,
                      f->hp, f->K, (int)N, (int)Np, f->kind, f->jitter);
   GP_HIP(hipGetLastError());
-  // look-ahead: measured at +-1 % for N = 5000, batches of 8 and of 64 x N = 1000 (the serial steps slow down by what the
-  // overlap gains: profiles/r03_chol_lookahead.txt), so it stays off; GPEMU_CHOL_LOOKAHEAD=1 switches it on (read per call)
+  // look-ahead (with the one-launch panels only; it gained nothing over the three-launch steps, whose narrow kernels
+  // slowed down by what the overlap won: profiles/r03_chol_lookahead.txt); GPEMU_CHOL_LOOKAHEAD=0 switches it off
   const char *la = getenv("GPEMU_CHOL_LOOKAHEAD");
-  const bool lookahead = f->overlap.side && la && atoi(la) == 1;
+  const bool lookahead = f->overlap.side && !(la && atoi(la) == 0);
   CholOverlap ov = f->overlap;
   if (!lookahead) ov.side = nullptr;
   GP_TRY(device_cholesky_blocked(f->K, Np, f->Dinv, f->info, st, nb, &ov));
