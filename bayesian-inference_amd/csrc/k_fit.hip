@@ -368,7 +368,10 @@ __device__ __forceinline__ void chol_post(int *flag, int tag) {
   if (threadIdx.x == 0) __hip_atomic_store(flag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// out = rows [16 wave, 16 wave + 16) of U V^T (64 x 64 x 64), four 16 x 16 tiles per wave, k ascending
+// out = rows [16 wave, 16 wave + 16) of U V^T (64 x 64 x 64), four 16 x 16 tiles per wave, k ascending.
+// V_LOWER: V is lower triangular (an inverted diagonal block): column tile nt only has terms k < 16 (nt + 1) -- the
+// k-steps beyond would add exact zeros and are skipped (40 of 64 MFMAs remain; same bits).
+template <bool V_LOWER>
 __device__ __forceinline__ void strip_product(const double (*U)[NB + 1], const double (*V)[NB + 1], int wave, int lane,
                                               d4t (&out)[4]) {
   const int lr = lane & 15, lk = lane >> 4;
@@ -378,7 +381,9 @@ __device__ __forceinline__ void strip_product(const double (*U)[NB + 1], const d
   for (int ks = 0; ks < NB / 4; ++ks) {
     const double a = U[16 * wave + lr][4 * ks + lk];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) out[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, V[16 * nt + lr][4 * ks + lk], out[nt], 0, 0, 0);
+    for (int nt = 0; nt < 4; ++nt)
+      if (!V_LOWER || ks < 4 * (nt + 1))
+        out[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, V[16 * nt + lr][4 * ks + lk], out[nt], 0, 0, 0);
   }
 }
 
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, 
       for (int r = 0; r < 4; ++r) U[16 * wave + lk + 4 * r][16 * nt + lr] = acc[s][nt][r];
     __syncthreads();
     d4t l[4];
-    strip_product(U, V, wave, lane, l);
+    strip_product<true>(U, V, wave, lane, l);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, 
       }
       __syncthreads();
       d4t t[4];
-      strip_product(U, V, wave, lane, t);
+      strip_product<false>(U, V, wave, lane, t);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
