@@ -543,7 +543,7 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
   bool side_pending = false;
   // one launch per panel (chol_panel_kernel) where the caller provides its flags and the strips of all problems fit on
   // the chip a few times over; GPEMU_CHOL_PANEL=0: the three-launch steps (same bits)
-  static const int panel_on = getenv("GPEMU_CHOL_PANEL") ? atoi(getenv("GPEMU_CHOL_PANEL")) : 1;
+  const int panel_on = getenv("GPEMU_CHOL_PANEL") ? atoi(getenv("GPEMU_CHOL_PANEL")) : 1;      // read per call (tests)
   static const int panel_max_wg = getenv("GPEMU_CHOL_PANEL_MAX_WG") ? atoi(getenv("GPEMU_CHOL_PANEL_MAX_WG")) : 320;
   const bool fused = panel_on && chol_q == CHOL_Q && ov && ov->flags && (int64_t)nblk * nb <= panel_max_wg;
   if (fused) GP_HIP(hipMemsetAsync(ov->flags, 0, sizeof(int) * (size_t)CHOL_FLAGS * nb, st));

@@ -88,6 +88,10 @@ int main(int argc, char **argv) {
   {  // K^-1 = W^T W
     GemmArgs g; g.A = A; g.B = A; g.C = C; g.lda = g.ldb = g.ldc = Np; g.M = g.N = g.K = n; g.lower_only = 1; g.k_from_m = 1;
     report("WtW    K^-1 = W^T W, lower tiles, k >= m", g, true, true, 1, (double)n * n * n / 3.0);
+    g.k_from_m = 0;
+    report("WtW    lower tiles, full K range", g, true, true, 1, (double)n * n * n);
+    g.lower_only = 0;
+    report("WtW    all tiles, full K range", g, true, true, 1, 2.0 * n * n * n);
   }
   hipFree(A); hipFree(B); hipFree(C);
   return 0;

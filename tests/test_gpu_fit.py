@@ -219,3 +219,45 @@ def test_pca_rank_deficient_and_wide_matrices():
             assert abs(row[j]) >= np.max(np.abs(row)) * (1 - 1e-12) and row[j] > 0, name
         assert relerr(np.abs(out["components"][:k]), np.abs(ref["components"][:k])) < 1e-8, name
         assert 1 <= out["n_sweeps"] <= 40, name
+
+
+@pytest.mark.parametrize("N", [700, 3300])
+def test_panel_factorisation_has_the_bits_of_the_three_launch_steps(N, monkeypatch):
+    """The one-launch-per-panel Cholesky (strips in registers, heads publishing through flags) and its look-ahead stream
+    keep every MFMA chain's operand order and the ``C - acc`` form of the updates of the three-launch steps: factor,
+    alpha, LML and gradient are bit-identical in all three variants (N = 700: three panels, ragged last one;
+    N = 3300: 52 tile rows, so the look-ahead stream is in use for the first panels).  The small case also against the
+    oracle (skl _gpr.py:537-652 restated)."""
+    from gpemu import synthetic
+    from gpemu.fit import DeviceFit
+    prob = synthetic.make_problem(N, 6, seed=3)
+    X = prob["design"]
+    y = prob["Y"][:, 0] - prob["Y"][:, 0].mean()
+    theta = np.log(np.r_[(prob["hi"] - prob["lo"]) * 0.4, 0.02])
+    results = {}
+    for label, env in (("panel+lookahead", {}), ("panel", {"GPEMU_CHOL_LOOKAHEAD": "0"}),
+                       ("three launches", {"GPEMU_CHOL_PANEL": "0"})):
+        for key in ("GPEMU_CHOL_LOOKAHEAD", "GPEMU_CHOL_PANEL"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        fit = DeviceFit(X, kernel_kind=0, has_noise=True, jitter=1e-10)
+        lml, grad = fit.lml(y, theta, eval_gradient=True)
+        L, alpha, lml2 = fit.factor(y, theta)
+        fit.close()
+        assert lml == lml2
+        results[label] = (lml, grad, L, alpha)
+    ref = results["three launches"]
+    for label in ("panel", "panel+lookahead"):
+        got = results[label]
+        assert got[0] == ref[0], label
+        np.testing.assert_array_equal(got[1], ref[1], err_msg=label)
+        np.testing.assert_array_equal(got[2], ref[2], err_msg=label)
+        np.testing.assert_array_equal(got[3], ref[3], err_msg=label)
+    if N <= 1000:
+        spec = O.KernelSpec(kind=O.RBF, has_noise=True)
+        lml_ref, grad_ref = O.lml_and_grad(X, y, theta, spec, jitter=1e-10)
+        gp = O.gp_fit_at_theta(X, y, theta, spec, jitter=1e-10)
+        assert abs(ref[0] - lml_ref) <= 1e-8 * abs(lml_ref)
+        assert relerr(ref[1], grad_ref) < 1e-6
+        assert relerr(ref[2], gp.L) < 1e-8

@@ -30,4 +30,7 @@ python3 $R/tools/time_predict.py 512 1024 4096 > $OUT/predict_gbps.txt 2>&1
 python3 $R/tools/bench_closure.py > $OUT/closure_batch.txt 2>&1
 python3 $R/tools/time_lml_batch.py 1000 64 > $OUT/fit_batch.txt 2>&1
 python3 $R/tools/time_fit_c3.py 50 64 >> $OUT/fit_batch.txt 2>&1
+python3 $R/tools/time_lml_batch.py 5000 8 >> $OUT/fit_batch.txt 2>&1
+( cd $R/bayesian-inference_amd/csrc && ./tools/gemm_probe && ./tools/potrf_probe ) > $OUT/fit_probes.txt 2>&1
+python3 $R/tools/run_dropin_c3.py 50 1000 10000 > $OUT/dropin_c3_end_to_end.txt 2>&1
 echo collected

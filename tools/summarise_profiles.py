@@ -33,12 +33,16 @@ for name, out in (("stats_bench/**/*kernel_stats.csv", f"{prefix}_bench_kernel_s
 for name, out in (("bench_default.json", f"{prefix}_bench_default.json"), ("emulated_sharding.jsonl", f"{prefix}_emulated_sharding.jsonl"),
                   ("fit_lml.txt", f"{prefix}_fit_lml.txt"), ("predict_gbps.txt", f"{prefix}_predict_gbps.txt"),
                   ("closure_batch.txt", f"{prefix}_closure_batch.txt"), ("pca.txt", f"{prefix}_pca.txt"),
-                  ("fit_batch.txt", f"{prefix}_fit_batch.txt")):
+                  ("fit_batch.txt", f"{prefix}_fit_batch.txt"), ("fit_probes.txt", f"{prefix}_fit_probes.txt"),
+                  ("dropin_c3_end_to_end.txt", f"{prefix}_dropin_c3_end_to_end.txt")):
     f = os.path.join(src, name)
     if os.path.exists(f):
         lines = [ln for ln in open(f) if "amdgpu.ids" not in ln]
         if name == "bench_default.json":
             lines = [ln for ln in lines if ln.startswith("{")]
+        if name == "dropin_c3_end_to_end.txt":
+            lines = ["The whole C3 analysis THROUGH THE DROP-IN MODULES (tools/run_dropin_c3.py 50 1000 10000), one MI355X:\n"] + \
+                    [ln for ln in lines if "Warning" not in ln and "warn" not in ln]
         open(os.path.join(dst, out), "w").writelines(lines)
 
 
