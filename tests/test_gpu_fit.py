@@ -261,3 +261,45 @@ def test_panel_factorisation_has_the_bits_of_the_three_launch_steps(N, monkeypat
         assert abs(ref[0] - lml_ref) <= 1e-8 * abs(lml_ref)
         assert relerr(ref[1], grad_ref) < 1e-6
         assert relerr(ref[2], gp.L) < 1e-8
+
+
+def test_panel_factorisation_in_a_batch(monkeypatch):
+    """Eight problems of N = 700 through one launch chain: 88 strips, so the batch takes the one-launch-per-panel
+    kernel too (blockIdx.y = problem, flags per problem).  Same bits as the three-launch steps and as eight single
+    evaluations; a problem that is not positive definite is reported for that problem alone."""
+    from gpemu import synthetic
+    from gpemu.fit import DeviceFit
+    N, nb = 700, 8
+    prob = synthetic.make_problem(N, 8, seed=5)
+    X = prob["design"]
+    rng = np.random.default_rng(11)
+    ys = np.stack([prob["Y"][:, j] - prob["Y"][:, j].mean() for j in range(nb)])
+    base = np.log(np.r_[(prob["hi"] - prob["lo"]) * 0.4, 0.02])
+    thetas = base + 0.3 * rng.standard_normal((nb, base.size))
+    out = {}
+    for label, env in (("panel", {}), ("three launches", {"GPEMU_CHOL_PANEL": "0"})):
+        monkeypatch.delenv("GPEMU_CHOL_PANEL", raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        fit = DeviceFit(X, kernel_kind=0, has_noise=True, jitter=1e-10)
+        lml, grad, info = fit.lml_batch(ys, thetas, eval_gradient=True)
+        singles = [fit.lml(ys[z], thetas[z], eval_gradient=True) for z in range(nb)]
+        fit.close()
+        assert not info.any()
+        for z in range(nb):
+            assert lml[z] == singles[z][0]
+            np.testing.assert_array_equal(grad[z], singles[z][1])
+        out[label] = (lml, grad)
+    np.testing.assert_array_equal(out["panel"][0], out["three launches"][0])
+    np.testing.assert_array_equal(out["panel"][1], out["three launches"][1])
+    # one numerically indefinite problem in the batch (length scales of 1e6 box widths, no noise, no jitter: K is the
+    # all-ones matrix to 1e-12, rounding turns a pivot non-positive within a few rows): flagged alone
+    monkeypatch.delenv("GPEMU_CHOL_PANEL", raising=False)
+    fit = DeviceFit(X, kernel_kind=0, has_noise=True, jitter=0.0)
+    th = thetas.copy()
+    th[3, :-1] = np.log(1e6)
+    th[3, -1] = -80.0
+    lml, grad, info = fit.lml_batch(ys, th, eval_gradient=True)
+    fit.close()
+    assert info[3] != 0 and not np.delete(info, 3).any()
+    assert np.all(np.isfinite(np.delete(lml, 3)))
