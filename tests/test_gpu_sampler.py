@@ -145,8 +145,11 @@ def _sharded_worker(rank, world, port, out_dir, transport):
     W = 26     # halves of 13: ragged shards
     ds = DeviceSampler([dm], W, seed=99)
     ds.set_state(synthetic.make_walkers(W, seed=3, lo=g["lo"], hi=g["hi"]))
-    ds.run_sharded(4, transport=transport)     # two calls: the exchange slots carry over
-    ds.run_sharded(5, transport=transport)
+    # many short back-to-back runs (9 steps in all): the exchange slots and their hand-back carry over from run to
+    # run, and a rank may re-enter while its peer is still finishing the run before (the ranks pass a
+    # barrier before every fused run)
+    for n_steps in (1, 1, 2, 1, 3, 1):
+        ds.run_sharded(n_steps, transport=transport)
     if transport == "peer":
         assert ds._peer_ok and all(ds._peer_ok.values()), "the peer transport was not taken"
     chain, lps = ds.get_chain()
