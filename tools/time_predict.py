@@ -15,7 +15,7 @@ dm = DeviceModel(X_train=prob["design"], ls=wl["ls"], alpha=wl["alpha"], L=wl["L
                  scaler_mean=wl["mean"], scaler_scale=wl["scale"], kernel_kind=0, noise=wl["noise"],
                  cov_unexplained=wl["cun"], device=0)
 for B in [int(a) for a in (sys.argv[1:] or ["512", "1024", "2048", "4096"])]:
-    r = bench.measure_predict(dm, n_samples=B, reps=5)
+    r = bench.measure_predict(dm, n_samples=B, reps=20)
     print(f"B={B}: {r['ms_per_batch']:.3f} ms  {r['value']:.0f} GB/s  ({r['roofline']['frac']:.3f} of 8 TB/s)  "
           f"{r['samples_per_s'] / 1e6:.3f} M samples/s", flush=True)
 dm.close()
