@@ -221,12 +221,13 @@ def test_pca_rank_deficient_and_wide_matrices():
         assert 1 <= out["n_sweeps"] <= 40, name
 
 
-@pytest.mark.parametrize("N", [700, 3300])
+@pytest.mark.parametrize("N", [130, 300, 700, 3300])
 def test_panel_factorisation_has_the_bits_of_the_three_launch_steps(N, monkeypatch):
     """The one-launch-per-panel Cholesky (strips in registers, heads publishing through flags) and its look-ahead stream
     keep every MFMA chain's operand order and the ``C - acc`` form of the updates of the three-launch steps: factor,
-    alpha, LML and gradient are bit-identical in all three variants (N = 700: three panels, ragged last one;
-    N = 3300: 52 tile rows, so the look-ahead stream is in use for the first panels).  The small case also against the
+    alpha, LML and gradient are bit-identical in all three variants (N = 130: one ragged panel of three blocks; 300: a
+    full panel and a one-block one; 700: three panels, ragged last one; 3300: 52 tile rows, so the look-ahead stream is in
+    use for the first panels).  The small case also against the
     oracle (skl _gpr.py:537-652 restated)."""
     from gpemu import synthetic
     from gpemu.fit import DeviceFit
