@@ -388,8 +388,10 @@ __device__ __forceinline__ void strip_product(const double (*U)[NB + 1], const d
 }
 
 // grid (rows of the panel = nblk - jb0, problems); npb = blocks of this panel (<= 4)
+// fault != 0 (tests only, GPEMU_CHOL_FAULT): the second head of the first panel never publishes its inverse -- the waits
+// for it must expire and the evaluation end with GPEMU_ERR_STATE.
 __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, double *Dinv, int jb0, int npb, int *info,
-                                                         int *flags, int tag, int64_t batchA, int64_t batchD) {
+                                                         int *flags, int tag, int64_t batchA, int64_t batchD, int fault) {
   A += (int64_t)blockIdx.y * batchA;
   Dinv += (int64_t)blockIdx.y * batchD;
   info += blockIdx.y;
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, 
     tile_inverse(U, V, T, tid);
     double *Db = Dinv + (int64_t)rb * NB * NB;
     for (int idx = tid; idx < NB * NB; idx += 256) publish_store(Db + idx, V[idx >> 6][idx & 63]);
-    chol_post(flags + q, tag);
+    if (!(fault && jb0 == 0 && q == 1)) chol_post(flags + q, tag);
     // the factor itself is not read before the next launch: after the publication
     for (int idx = tid; idx < NB * NB; idx += 256) Arow[(int64_t)(idx >> 6) * Np + 64 * q + (idx & 63)] = U[idx >> 6][idx & 63];
   }
@@ -546,12 +548,13 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
   const int panel_on = getenv("GPEMU_CHOL_PANEL") ? atoi(getenv("GPEMU_CHOL_PANEL")) : 1;      // read per call (tests)
   static const int panel_max_wg = getenv("GPEMU_CHOL_PANEL_MAX_WG") ? atoi(getenv("GPEMU_CHOL_PANEL_MAX_WG")) : 320;
   const bool fused = panel_on && chol_q == CHOL_Q && ov && ov->flags && (int64_t)nblk * nb <= panel_max_wg;
+  const int fault = getenv("GPEMU_CHOL_FAULT") ? atoi(getenv("GPEMU_CHOL_FAULT")) : 0;     // tests: a head that never publishes
   if (fused) GP_HIP(hipMemsetAsync(ov->flags, 0, sizeof(int) * (size_t)CHOL_FLAGS * nb, st));
   for (int jb0 = 0; jb0 < nblk; jb0 += chol_q) {
     const int jb1 = std::min(nblk, jb0 + chol_q);             // the panel: blocks [jb0, jb1)
     if (fused) {
       hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(nblk - jb0), (unsigned)nb), dim3(256), 0, st, A, Np, Dinv, jb0,
-                         jb1 - jb0, dinfo, ov->flags, jb0 / chol_q + 1, Np * Np, Np * NB);
+                         jb1 - jb0, dinfo, ov->flags, jb0 / chol_q + 1, Np * Np, Np * NB, fault);
       GP_HIP(hipGetLastError());
     }
     for (int jb = jb0; jb < jb1 && !fused; ++jb) {

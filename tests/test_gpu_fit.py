@@ -304,3 +304,28 @@ def test_panel_factorisation_in_a_batch(monkeypatch):
     fit.close()
     assert info[3] != 0 and not np.delete(info, 3).any()
     assert np.all(np.isfinite(np.delete(lml, 3)))
+
+
+def test_panel_wait_is_bounded(monkeypatch):
+    """Every wait inside the one-launch-per-panel kernel is bounded: with a head that never publishes its inverse
+    (fault injection, GPEMU_CHOL_FAULT) the strips' waits expire, every later wait gives up at once, and the evaluation
+    ends with GPEMU_ERR_STATE in seconds instead of hanging the GPU; the handle stays usable afterwards."""
+    import time
+    from gpemu import _lib, synthetic
+    from gpemu.fit import DeviceFit
+    N = 700
+    prob = synthetic.make_problem(N, 6, seed=3)
+    X = prob["design"]
+    y = prob["Y"][:, 0] - prob["Y"][:, 0].mean()
+    theta = np.log(np.r_[(prob["hi"] - prob["lo"]) * 0.4, 0.02])
+    fit = DeviceFit(X, kernel_kind=0, has_noise=True, jitter=1e-10)
+    good = fit.lml(y, theta, eval_gradient=False)
+    monkeypatch.setenv("GPEMU_CHOL_FAULT", "1")
+    t0 = time.perf_counter()
+    with pytest.raises(_lib.GpemuError) as err:
+        fit.lml(y, theta, eval_gradient=False)
+    assert time.perf_counter() - t0 < 30.0
+    assert err.value.code == -4 and "poll bound" in str(err.value)          # GPEMU_ERR_STATE
+    monkeypatch.delenv("GPEMU_CHOL_FAULT")
+    assert fit.lml(y, theta, eval_gradient=False) == good
+    fit.close()
