@@ -23,6 +23,7 @@ struct GemmArgs {
   int k_from_n = 0;    // op(B)[k][n] = 0 for k < n  (B lower triangular in (k, n)): start at the tile's first column
   int k_to_m = 0;      // op(A)[m][k] = 0 for k > m  (A lower triangular in (m, k)): stop after the tile's last row
   int xcd_batch = 0;   // set by launch_gemm: whole problems of a batch per XCD (see the kernel)
+  int packed = 0;      // set by launch_gemm: 1-D grid over the lower-triangle tiles (lower_only, square)
   int pair = 0;        // set by launch_gemm: a workgroup takes a tile and its mirror image along N (1) or M (2)
 };
 

@@ -55,6 +55,15 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
     by = rest % gy; rest /= gy;
     bz = rest + b1 * problem;
   }
+  if (g.packed) {
+    // lower_only on a square tile grid launched as a 1-D grid over the tiles on and under the diagonal only: position t
+    // is tile (m, n), t = m (m + 1) / 2 + n -- no workgroups that start only to find themselves above the diagonal
+    int m = (int)((sqrt(8.0 * (double)bx + 1.0) - 1.0) * 0.5);
+    while (m * (m + 1) / 2 > bx) --m;
+    while ((m + 1) * (m + 2) / 2 <= bx) ++m;
+    by = m;
+    bx -= m * (m + 1) / 2;
+  }
   const int z1 = g.batch1 > 0 ? (int)(bz % g.batch1) : bz;
   const int z2 = g.batch1 > 0 ? (int)(bz / g.batch1) : 0;
   const double *A = g.A + (int64_t)z1 * g.strideA + (int64_t)z2 * g.stride2A;
@@ -229,6 +238,9 @@ int launch_gemm(const GemmArgs &g, bool a_kmajor, bool b_kmajor, int batch, hipS
   dim3 grid((unsigned)((g.N + T - 1) / T), (unsigned)((g.M + T - 1) / T), (unsigned)batch), block(256);
   if (gs.pair == 1) grid.x = (grid.x + 1) / 2;
   if (gs.pair == 2) grid.y = (grid.y + 1) / 2;
+  static const int packed_on = getenv("GPEMU_GEMM_PACKED") ? atoi(getenv("GPEMU_GEMM_PACKED")) : 1;
+  gs.packed = (packed_on && g.lower_only && !big && g.M == g.N) ? 1 : 0;
+  if (gs.packed) { grid.x = grid.x * (grid.x + 1) / 2; grid.y = 1; }
 #define GP_LAUNCH_GEMM(AK, BK)                                                                  \
   do {                                                                                          \
     if (big) hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, 4>), grid, block, 0, st, gs);          \
