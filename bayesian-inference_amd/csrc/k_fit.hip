@@ -763,16 +763,20 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(const double *__restrict_
                                                        double *__restrict__ gpart, int N, int d, int kind,
                                                        int has_const, int has_noise) {
   __shared__ double red[NTH_MAX][4];
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j0 = blockIdx.y * GRAD_ROWS;               // this workgroup's rows j0 .. j0 + GRAD_ROWS - 1 (one reduction for all)
+  // 1-D grid over the (row group, 256-column block) pairs that reach under the diagonal only (half of the full grid's
+  // workgroups would start to find nothing to do): row groups 16 b .. 16 b + 15 have b + 1 blocks, so position
+  // t = (b + 1)(8 b + r) + x  <->  row group 16 b + r, block x
+  int b = (int)((sqrt(1.0 + 0.5 * (double)blockIdx.x) - 1.0) * 0.5);
+  while (8 * b * (b + 1) > (int)blockIdx.x) --b;
+  while (8 * (b + 1) * (b + 2) <= (int)blockIdx.x) ++b;
+  const int rem = (int)blockIdx.x - 8 * b * (b + 1);
+  const int by = 16 * b + rem / (b + 1), bx = rem % (b + 1);
+  const int l = bx * blockDim.x + threadIdx.x;
+  const int j0 = by * GRAD_ROWS;                       // this workgroup's rows j0 .. j0 + GRAD_ROWS - 1 (one reduction for all)
   hp += (int64_t)blockIdx.z * (DPAD + 2);              // blockIdx.z: problem of a batch
   alpha += (int64_t)blockIdx.z * ld;
   Kinv += (int64_t)blockIdx.z * ld * ld;
-  gpart += (int64_t)blockIdx.z * gridDim.x * gridDim.y * NTH_MAX;
-  if ((int)(blockIdx.x * blockDim.x) > j0 + GRAD_ROWS - 1) {   // wholly above the diagonal: nothing to add
-    if (threadIdx.x < NTH_MAX) gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NTH_MAX + threadIdx.x] = 0.0;
-    return;
-  }
+  gpart += (int64_t)blockIdx.z * gridDim.x * NTH_MAX;
   double acc[NTH_MAX];
 #pragma unroll
   for (int t = 0; t < NTH_MAX; ++t) acc[t] = 0.0;
@@ -821,7 +825,7 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(const double *__restrict_
   __syncthreads();
   if (threadIdx.x < NTH_MAX) {
     const int t = threadIdx.x;
-    gpart[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NTH_MAX + t] = (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+    gpart[(int64_t)blockIdx.x * NTH_MAX + t] = (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
   }
 }
 
@@ -1014,11 +1018,15 @@ static int fit_eval_batch(gpemu_fit *f, int nb, const double *ys, const double *
     g.lower_only = 1; g.k_from_m = 1;
     g.strideA = Np * Np; g.strideB = Np * Np; g.strideC = Np * Np;
     GP_TRY(launch_gemm(g, true, true, nb, st));
-    dim3 grid((unsigned)((N + 255) / 256), (unsigned)((N + GRAD_ROWS - 1) / GRAD_ROWS), (unsigned)nb);
+    // (row group, column block) pairs under the diagonal: row group y has y / 16 + 1 blocks of 256 columns
+    const int ngroups = (int)((N + GRAD_ROWS - 1) / GRAD_ROWS);
+    int npairs = 0;
+    for (int y = 0; y < ngroups; ++y) npairs += y / 16 + 1;
+    dim3 grid((unsigned)npairs, 1, (unsigned)nb);
     hipLaunchKernelGGL(lml_grad_kernel, grid, dim3(256), 0, st, f->X, f->hp, f->alpha, f->Kinv, Np, f->gpart, (int)N,
                        (int)d, f->kind, f->has_const, f->has_noise);
     hipLaunchKernelGGL(grad_reduce_stage1_kernel, dim3(GR_BLOCKS, (unsigned)nb), dim3(256), 0, st, f->gpart,
-                       (int)(grid.x * grid.y), f->gstage, nth);
+                       npairs, f->gstage, nth);
     hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)nb), dim3(64), 0, st, f->gstage, f->grad, nth);
     GP_HIP(hipGetLastError());
   }
