@@ -423,6 +423,19 @@ class _LbfgsbRun:
         return 1 if (self.nfev > self.maxfun or self.nit >= self.maxiter) else 2
 
 
+def fit_batch_size(n_design, requested=None):
+    """Problems (target, theta) evaluated through one launch chain: ``GPEMU_FIT_BATCH`` (default 64), within a memory
+    budget -- every problem of a batch owns ~6 N x N f64 work matrices on the device, and a batch may take a quarter of
+    the MI355X's 288 GB (``GPEMU_FIT_BATCH_GB``, default 72): 64 problems up to N ~ 4800, 58 at N = 5000.  The serial
+    steps of the factorisation cost the same for 8 problems as for 64, so large batches are what the chain wants
+    (N = 5000: 3.13 / 2.93 / 2.85 ms per problem at 8 / 16 / 32)."""
+    if requested is None:
+        requested = int(os.environ.get("GPEMU_FIT_BATCH", "64"))
+    budget = float(os.environ.get("GPEMU_FIT_BATCH_GB", "72")) * 1e9
+    n_pad = -(-int(n_design) // 64) * 64
+    return max(1, min(int(requested), int(budget // (6 * 8 * n_pad * n_pad))))
+
+
 def _lockstep_minimise(dfit, problems, bounds, max_batch):
     """``problems``: list of (target y, start theta).  All minimisations advance together on one host thread: every
     round takes the next requested point of each run in flight (at most ``max_batch``), evaluates them in ONE launch
@@ -500,10 +513,7 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
             for _ in range(n_restarts_optimizer):
                 starts[i].append(rng.uniform(bounds[:, 0], bounds[:, 1]))
     if n_streams is None:
-        n_streams = int(os.environ.get("GPEMU_FIT_BATCH", "64"))
-        # every problem of a batch owns ~6 N x N f64 work matrices on the device: keep a batch within ~24 GB
-        n_pad = -(-X.shape[0] // 64) * 64
-        n_streams = max(1, min(n_streams, int(24e9 // (6 * 8 * n_pad * n_pad))))
+        n_streams = fit_batch_size(X.shape[0])
     tasks = [(i, j) for i in range(k_gp) for j in range(len(starts[i]))]
     n_threads = max(1, min(int(n_streams), max(len(tasks), 1)))
     shared = _fit.DeviceFit(X, kk.kind, kk.nu, kk.has_const, kk.has_noise, alpha, device)

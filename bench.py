@@ -129,7 +129,8 @@ def measure_fit_c5(device=0):
                                   "unit": "TFLOP/s", "frac": flop / dt / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
                                   "algorithmic_gflop": flop / 1e9}
     # the form the fit itself uses: several (target, theta) problems through one launch chain (gpemu_fit_lml_batch)
-    nbatch = 8
+    from gpemu import estimators
+    nbatch = estimators.fit_batch_size(N)              # what fit_gps would put through one chain at this N (58 at N = 5000)
     rng = np.random.default_rng(1)
     ys = np.stack([Y_pca[:, i % Y_pca.shape[1]] for i in range(nbatch)])
     thetas = np.stack([theta + 0.1 * rng.normal(size=theta.size) for _ in range(nbatch)])
