@@ -4,6 +4,7 @@
 #include <cstdarg>
 
 #include "internal.h"
+#include "kstar_host.h"
 #include "gemm.h"
 #include "linalg_dev.h"
 
@@ -163,6 +164,13 @@ int gpemu_device_name(int device, char *buf, int64_t buflen) {
   return GPEMU_OK;
 }
 
+int gpemu_device_bus_id(int device, char *buf, int64_t buflen) {
+  GP_TRY(check_device(device));
+  GP_ARG(buf && buflen >= 16, "buf");
+  GP_HIP(hipDeviceGetPCIBusId(buf, (int)buflen, device));
+  return GPEMU_OK;
+}
+
 int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int64_t F, int64_t k,
                        int kernel_kind, double nu, int has_const, int has_noise,
                        const double *X_train, const double *ls, const double *constv,
@@ -210,7 +218,8 @@ int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int6
   hipStream_t st = m->stream;
 
   // host staging of the small padded arrays
-  std::vector<double> hXs((size_t)(k * Np * DPAD), 0.0), hls((size_t)(k * DPAD), 1.0),
+  const bool matern05 = kernel_kind == GPEMU_KERNEL_MATERN && nu == 0.5;
+  std::vector<double> hXs(matern05 ? (size_t)(k * Np * DPAD) : 0, 0.0), hls((size_t)(k * DPAD), 1.0),
       hc((size_t)k, 0.0), hkd((size_t)k, 1.0), hal((size_t)(k * Np), 0.0);
   for (int64_t p = 0; p < k; ++p) {
     for (int64_t dd = 0; dd < d; ++dd) {
@@ -218,17 +227,16 @@ int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int6
       if (!(l > 0.0)) { set_error("length scale must be positive"); return fail(GPEMU_ERR_ARG); }
       hls[p * DPAD + dd] = l;
     }
-    for (int64_t j = 0; j < N; ++j)
-      for (int64_t dd = 0; dd < d; ++dd)
-        hXs[(p * Np + j) * DPAD + dd] = X_train[j * d + dd] / ls[p * d + dd];  // skl: X / length_scale
+    if (matern05)
+      for (int64_t j = 0; j < N; ++j)
+        for (int64_t dd = 0; dd < d; ++dd)
+          hXs[(p * Np + j) * DPAD + dd] = X_train[j * d + dd] / ls[p * d + dd];  // skl: X / length_scale
     if (has_const) { hc[p] = constv[p]; hkd[p] += constv[p]; }
     if (has_noise) hkd[p] += noise[p];
     for (int64_t j = 0; j < N; ++j) hal[p * Np + j] = alpha[p * N + j];
   }
 #define GP_STEP(expr) if ((rc = (expr)) != GPEMU_OK) return fail(rc)
-  GP_STEP(dev_alloc(&m->Xs, k * Np * DPAD));
   GP_STEP(dev_alloc(&m->ls, k * DPAD));
-  GP_STEP(dev_alloc(&m->inv_ls, k * DPAD));
   GP_STEP(dev_alloc(&m->constv, k));
   GP_STEP(dev_alloc(&m->kdiag, k));
   GP_STEP(dev_alloc(&m->alpha, k * Np));
@@ -238,13 +246,34 @@ int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int6
   GP_STEP(dev_alloc(&m->sscale, F));
   GP_STEP(dev_alloc(&m->cunexpl, F * F));
   GP_STEP(dev_alloc(&dL, k * N * N));
-  GP_STEP(upload(m->Xs, hXs.data(), k * Np * DPAD, st));
   GP_STEP(upload(m->ls, hls.data(), k * DPAD, st));
   {
+    // the cross-kernel's operands for the matrix cores (kstar_host.h)
+    KstarHost kh;
+    build_kstar_operands(N, Np, d, k, kstar_kind(m), X_train, ls, alpha, kh);
+    m->ksteps = kh.ksteps;
+    GP_STEP(dev_alloc(&m->Xa, (int64_t)kh.Xa.size()));
+    GP_STEP(dev_alloc(&m->alf, (int64_t)kh.alf.size()));
+    GP_STEP(dev_alloc(&m->qsc, (int64_t)kh.qsc.size()));
+    GP_STEP(dev_alloc(&m->qof, (int64_t)kh.qof.size()));
+    GP_STEP(dev_alloc(&m->etab, (int64_t)kh.tab.size()));
+    GP_STEP(upload(m->Xa, kh.Xa.data(), (int64_t)kh.Xa.size(), st));
+    GP_STEP(upload(m->alf, kh.alf.data(), (int64_t)kh.alf.size(), st));
+    GP_STEP(upload(m->qsc, kh.qsc.data(), (int64_t)kh.qsc.size(), st));
+    GP_STEP(upload(m->qof, kh.qof.data(), (int64_t)kh.qof.size(), st));
+    GP_STEP(upload(m->etab, kh.tab.data(), (int64_t)kh.tab.size(), st));
     std::vector<double> hinv(hls.size());
-    for (size_t i = 0; i < hls.size(); ++i) hinv[i] = 1.0 / hls[i];
-    GP_STEP(upload(m->inv_ls, hinv.data(), k * DPAD, st));
-    GP_HIP(hipStreamSynchronize(st));   // hinv goes out of scope
+    if (matern05) {
+      for (size_t i = 0; i < hls.size(); ++i) hinv[i] = 1.0 / hls[i];
+      GP_STEP(dev_alloc(&m->Xs, k * Np * DPAD));
+      GP_STEP(dev_alloc(&m->inv_ls, k * DPAD));
+      GP_STEP(upload(m->Xs, hXs.data(), k * Np * DPAD, st));
+      GP_STEP(upload(m->inv_ls, hinv.data(), k * DPAD, st));
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) {   // the staging vectors go out of scope
+      set_error("model_create: upload failed");
+      return fail(GPEMU_ERR_HIP);
+    }
   }
   GP_STEP(upload(m->constv, hc.data(), k, st));
   GP_STEP(upload(m->kdiag, hkd.data(), k, st));
@@ -294,22 +323,17 @@ int gpemu_model_destroy(gpemu_model *m) {
   if (!m) return GPEMU_OK;
   hipSetDevice(m->device);
   if (m->stream) hipStreamSynchronize(m->stream);
-  hipFree(m->Xs); hipFree(m->inv_ls); hipFree(m->ls); hipFree(m->constv); hipFree(m->kdiag);
+  hipFree(m->Xs); hipFree(m->inv_ls); hipFree(m->ls); hipFree(m->Xa); hipFree(m->alf); hipFree(m->qsc); hipFree(m->qof);
+  hipFree(m->etab); hipFree(m->constv); hipFree(m->kdiag);
   hipFree(m->alpha); hipFree(m->Wt); hipFree(m->comp); hipFree(m->smean); hipFree(m->sscale);
   hipFree(m->cunexpl); hipFree(m->yexp); hipFree(m->yerr); hipFree(m->lo); hipFree(m->hi);
   for (const gpemu_model::LikEntry &en : m->lik_cache) { hipFree(en.G); hipFree(en.g0); hipFree(en.scal); }
   hipFree(m->exact_scratch);
   hipFree(m->blk_start); hipFree(m->blk_of);
-  for (const gpemu_model::SchedEntry &en : m->sched_cache) {
-    hipFree(en.items); hipFree(en.cnt); hipFree(en.qitems); hipFree(en.qn); hipFree(en.qcnt);
-  }
+  for (const gpemu_model::SchedEntry &en : m->sched_cache) { hipFree(en.items); hipFree(en.cnt); }
   hipFree(m->sm_items); hipFree(m->sm_cnt);
   free_workspace(m->ws);
-  hipFree(m->pf_mean); hipFree(m->pf_var);
   for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
-  for (hipEvent_t e : m->split_ev) (void)hipEventDestroy(e);
-  if (m->split_gp) hipStreamDestroy(m->split_gp);
-  if (m->split_wr) hipStreamDestroy(m->split_wr);
   if (m->stream) hipStreamDestroy(m->stream);
   delete m;
   return GPEMU_OK;
@@ -617,125 +641,6 @@ int gpemu_truncation_cov(int device, int64_t n_comp, int64_t F, int64_t n_pc, co
 // ---- full predict ----------------------------------------------------------------------------------
 }  // extern "C"
 namespace gpemu {
-// CU-partitioned streams for the predict pipeline.  hipExtStreamCreateWithCUMask: bit i of the mask is CU i / 8 of XCD
-// i % 8 (measured: profiles/r03_cu_mask_probe.txt), so the first 8 n bits give n CUs on every XCD and the last 8 w
-// bits w others; shares take effect in steps of 4 CUs per XCD.
-static int ensure_split_streams(gpemu_model *m, int gp_per_xcd, int wr_per_xcd = 0) {
-  if (wr_per_xcd <= 0) wr_per_xcd = m->num_cu / 8 - gp_per_xcd;
-  if (m->split_gp && m->split_gp_per_xcd == gp_per_xcd && m->split_wr_per_xcd == wr_per_xcd) return GPEMU_OK;
-  if (m->split_gp) { (void)hipStreamSynchronize(m->split_gp); (void)hipStreamDestroy(m->split_gp); m->split_gp = nullptr; }
-  if (m->split_wr) { (void)hipStreamSynchronize(m->split_wr); (void)hipStreamDestroy(m->split_wr); m->split_wr = nullptr; }
-  const int ncu = m->num_cu, per_xcd = ncu / 8;
-  if (ncu % 8 != 0 || gp_per_xcd < 1 || gp_per_xcd > per_xcd || wr_per_xcd < 1 || wr_per_xcd > per_xcd) {
-    set_error("CU split %d / %d of %d per XCD", gp_per_xcd, wr_per_xcd, per_xcd);
-    return GPEMU_ERR_ARG;
-  }
-  std::vector<uint32_t> gp((size_t)(ncu + 31) / 32, 0u), wr((size_t)(ncu + 31) / 32, 0u);
-  for (int i = 0; i < ncu; ++i) {
-    if (i < 8 * gp_per_xcd) gp[i / 32] |= 1u << (i % 32);
-    if (i >= ncu - 8 * wr_per_xcd) wr[i / 32] |= 1u << (i % 32);
-  }
-  GP_HIP(hipExtStreamCreateWithCUMask(&m->split_gp, (uint32_t)gp.size(), gp.data()));
-  GP_HIP(hipExtStreamCreateWithCUMask(&m->split_wr, (uint32_t)wr.size(), wr.data()));
-  m->split_gp_per_xcd = gp_per_xcd;
-  m->split_wr_per_xcd = wr_per_xcd;
-  return GPEMU_OK;
-}
-
-static hipEvent_t split_event(gpemu_model *m, size_t i) {
-  while (m->split_ev.size() <= i) {
-    hipEvent_t e = nullptr;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-    m->split_ev.push_back(e);
-  }
-  return m->split_ev[i];
-}
-
-// GPEMU_PREDICT_SPLIT = CUs per XCD for the GP stage (multiples of 4: the mask takes effect per shader engine; default
-// 0 = the serial form, which is the faster one -- see predict_full_pipelined), GPEMU_PREDICT_CHUNK = samples per
-// pipeline stage (default 256)
-static int predict_split_cus() {
-  const char *e = getenv("GPEMU_PREDICT_SPLIT");
-  return e ? atoi(e) : 0;
-}
-static int64_t predict_chunk() {
-  const char *e = getenv("GPEMU_PREDICT_CHUNK");
-  const int64_t c = e ? atoll(e) : 256;
-  return round_up(c < TILE ? TILE : c, TILE);
-}
-
-// MEASURED NEGATIVE, kept behind GPEMU_PREDICT_SPLIT (profiles/r03_predict_overlap.txt).  A store-only kernel keeps
-// its HBM rate down to 64 CUs (5.2 TB/s; 5.5 on 96 and on all 256), which suggested confining the covariance writer to a
-// quarter of the chip while the GP stage of the next chunk has the rest.  But the writer is not store-only: its rank-k
-// product needs 2.5 fp64 FLOP per byte, i.e. a fifth of the chip's fp64 rate at 5.3 TB/s, and the matrix-core writer
-// sustains 85 % of that rate alone but 45-55 % with its LDS staging and stores: 354 us per 512 samples on 64 CUs, 274 on
-// 96, 211 on 128, 184 on 256, while the GP stage takes 170 us on 256 CUs, 206 on 192, 217 on 160, 246 on 128.  No
-// partition beats the sum of the two full-chip stages by more than the pipeline's fill and drain cost at B = 1024, and
-// with both running the stages slow each other down further (HBM and fabric are shared): every split x chunk setting
-// measured slower than the serial form.
-//
-// emulation.predict over a large batch as a two-stage pipeline on disjoint CUs:
-//   chunk 0's GP stage on the whole chip (nothing to overlap it with), then for i >= 1 the GP stage of chunk i on the GP
-//   share of the CUs WHILE the covariance writer of chunk i - 1 streams to HBM from the others; the last chunk's writer
-//   gets the whole chip again.  Means / variances of the whole batch are kept ([B][k], tiny), so the stages only meet
-//   through events.
-static int predict_full_pipelined(gpemu_model *m, int64_t B, const double *dX, double n_div, double *dcv, double *dcov,
-                                  hipStream_t st, int gp_per_xcd, int64_t chunk) {
-  const int64_t F = m->F, k = m->k;
-  GP_TRY(ensure_split_streams(m, gp_per_xcd));
-  GP_TRY(ensure_workspace(m, chunk));
-  if (m->pf_cap < B) {
-    GP_HIP(hipStreamSynchronize(st));
-    (void)hipFree(m->pf_mean); (void)hipFree(m->pf_var);
-    m->pf_mean = m->pf_var = nullptr; m->pf_cap = 0;
-    GP_TRY(dev_alloc(&m->pf_mean, B * k));
-    GP_TRY(dev_alloc(&m->pf_var, B * k));
-    m->pf_cap = B;
-  }
-  const int64_t n = (B + chunk - 1) / chunk;
-  for (int64_t i = 0; i <= n + 1; ++i)
-    if (!split_event(m, (size_t)i)) { set_error("hipEventCreate failed"); return GPEMU_ERR_HIP; }
-  hipStream_t A = m->split_gp, Wr = m->split_wr;
-  int rc = GPEMU_OK;
-  auto gp_stage = [&](int64_t i, hipStream_t s, int limit) {
-    const int64_t off = i * chunk, nb = std::min(chunk, B - off);
-    m->worker_limit = limit;
-    int r = gp_predict_core(m, nb, dX + off * m->d, s);
-    if (r == GPEMU_OK) r = launch_reduce_mean_var(m, nb, m->pf_mean + off * k, m->pf_var + off * k, s);
-    m->worker_limit = 0;
-    return r;
-  };
-  auto writer = [&](int64_t i, hipStream_t s) {
-    const int64_t off = i * chunk, nb = std::min(chunk, B - off);
-    return launch_predict_full(m, nb, n_div, dcv + off * F, dcov + off * F * F, s, m->pf_mean + off * k,
-                               m->pf_var + off * k);
-  };
-  // chunk 0: GP stage on the caller's stream, whole chip
-  rc = gp_stage(0, st, 0);
-  if (rc != GPEMU_OK) return rc;
-  GP_HIP(hipEventRecord(m->split_ev[0], st));
-  hipEvent_t last_wr = nullptr;
-  if (n > 1) {
-    GP_HIP(hipStreamWaitEvent(A, m->split_ev[0], 0));     // the workspace is the GP stage's, one chunk at a time
-    for (int64_t i = 1; i < n; ++i) {
-      rc = gp_stage(i, A, 8 * gp_per_xcd);
-      if (rc != GPEMU_OK) break;
-      GP_HIP(hipEventRecord(m->split_ev[(size_t)i], A));
-      GP_HIP(hipStreamWaitEvent(Wr, m->split_ev[(size_t)i - 1], 0));
-      rc = writer(i - 1, Wr);
-      if (rc != GPEMU_OK) break;
-    }
-    if (rc == GPEMU_OK) {
-      last_wr = m->split_ev[(size_t)n];
-      GP_HIP(hipEventRecord(last_wr, Wr));
-      GP_HIP(hipStreamWaitEvent(st, m->split_ev[(size_t)n - 1], 0));
-    }
-  }
-  if (rc == GPEMU_OK) rc = writer(n - 1, st);                 // last chunk: whole chip
-  if (last_wr) GP_HIP(hipStreamWaitEvent(st, last_wr, 0));   // join
-  if (rc != GPEMU_OK) { (void)hipStreamSynchronize(A); (void)hipStreamSynchronize(Wr); }
-  return rc;
-}
 }  // namespace gpemu
 extern "C" {
 
@@ -746,48 +651,6 @@ int gpemu_predict_full_dev(gpemu_model *m, int64_t B, const double *dX, double n
   GP_HIP(hipSetDevice(m->device));
   hipStream_t st = stream ? (hipStream_t)stream : m->stream;
   const int64_t F = m->F;
-  const int split = predict_split_cus();
-  const int64_t chunk = predict_chunk();
-  if (split > 0 && m->num_cu % 8 == 0 && split < m->num_cu / 8 && B >= 2 * chunk)
-    return predict_full_pipelined(m, B, dX, n_div, dcv, dcov, st, split, chunk);
-  // diagnostic (profiles/r03_predict_overlap.txt): GPEMU_SERIAL_MASK="g,w" runs the two stages one after the other,
-  // the GP stage confined to g CUs per XCD and the writer to w -- each stage's time on a share of the chip, alone
-  int mg = 0, mw = 0;
-  if (const char *e = getenv("GPEMU_SERIAL_MASK")) sscanf(e, "%d,%d", &mg, &mw);
-  if (mg > 0 && mw > 0) {
-    GP_TRY(ensure_split_streams(m, mg, mw));
-    GP_TRY(ensure_workspace(m, std::min<int64_t>(B, MAX_CHUNK)));
-    for (size_t i = 0; i < 3; ++i)
-      if (!split_event(m, i)) { set_error("hipEventCreate failed"); return GPEMU_ERR_HIP; }
-    GP_HIP(hipEventRecord(m->split_ev[0], st));
-    GP_HIP(hipStreamWaitEvent(m->split_gp, m->split_ev[0], 0));
-    for (int64_t off = 0; off < B; off += MAX_CHUNK) {
-      const int64_t nb = (B - off < MAX_CHUNK) ? (B - off) : MAX_CHUNK;
-      m->worker_limit = 8 * mg;
-      int rc = gp_predict_core(m, nb, dX + off * m->d, m->split_gp);
-      m->worker_limit = 0;
-      GP_TRY(rc);
-      GP_TRY(launch_reduce_mean_var(m, nb, m->ws.mean, m->ws.var, m->split_gp));
-      GP_HIP(hipEventRecord(m->split_ev[1], m->split_gp));
-      GP_HIP(hipStreamWaitEvent(m->split_wr, m->split_ev[1], 0));
-      static hipEvent_t t0 = nullptr, t1 = nullptr;      // diagnostic: the writer's own time on its share
-      if (!t0) { GP_HIP(hipEventCreate(&t0)); GP_HIP(hipEventCreate(&t1)); }
-      GP_HIP(hipEventRecord(t0, m->split_wr));
-      GP_TRY(launch_predict_full(m, nb, n_div, dcv + off * F, dcov + off * F * F, m->split_wr, m->ws.mean, m->ws.var));
-      GP_HIP(hipEventRecord(t1, m->split_wr));
-      GP_HIP(hipEventRecord(m->split_ev[2], m->split_wr));
-      GP_HIP(hipStreamWaitEvent(m->split_gp, m->split_ev[2], 0));
-      if (getenv("GPEMU_SERIAL_MASK_PRINT")) {
-        GP_HIP(hipEventSynchronize(t1));
-        float ms = 0.f;
-        GP_HIP(hipEventElapsedTime(&ms, t0, t1));
-        fprintf(stderr, "writer on %d CUs per XCD: %lld samples in %.1f us = %.2f TB/s\n", mw, (long long)nb, ms * 1e3,
-                8.0 * nb * F * F / (ms * 1e-3) / 1e12);
-      }
-    }
-    GP_HIP(hipStreamWaitEvent(st, m->split_ev[2], 0));
-    return GPEMU_OK;
-  }
   for (int64_t off = 0; off < B; off += MAX_CHUNK) {
     const int64_t nb = (B - off < MAX_CHUNK) ? (B - off) : MAX_CHUNK;
     GP_TRY(gp_predict_core(m, nb, dX + off * m->d, st));

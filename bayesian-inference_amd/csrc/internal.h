@@ -36,14 +36,15 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 
 constexpr int DPAD = 8;        // parameter dimensions padded to 8 (reference uses d = 6 or 7)
 constexpr int TILE = 128;      // row / column tile of the triangular GEMM
-constexpr int JCHUNK = 128;    // training rows per workgroup in the cross-kernel kernel
+constexpr int KSTAR_ROWS_BIG = 64;    // training rows per workgroup of the cross-kernel: batches of more than 256 columns
+constexpr int KSTAR_ROWS_SMALL = 32;  // ... and of at most 256
 
 // ---- device model -----------------------------------------------------------------------------
 struct Workspace {
   int64_t Bcap = 0;            // padded batch capacity (multiple of TILE)
   double *Xq = nullptr;        // [Bcap][DPAD]   query points (padded with 0)
   double *KS = nullptr;        // [k][Npad][Bcap] cross-kernel K_*^T per PC
-  double *mean_part = nullptr; // [Bcap][k][nchunk] partial K_* . alpha per 128- (or 32-) row chunk
+  double *mean_part = nullptr; // [Bcap][k][nchunk] partial K_* . alpha per 64- (or 32-) row chunk
   double *mean_part2 = nullptr; // second copy: the fused sampler run reads one half-step's while the next is written
   double *vsq_part = nullptr;  // [Bcap][k][nrb]    partial ||W k_*||^2 per 64- (or 32-) row block
   double *mean = nullptr;      // [Bcap][k]
@@ -65,21 +66,8 @@ struct gpemu_model {
   int *sched_cnt = nullptr;    // [sched_workers]
   int sched_ncb = -1, sched_max_items = 0, sched_workers = 0;
   int sched_cap = 0;           // worker cap the current schedule was built for
-  int sched_cur = -1;          // index of the current schedule in sched_cache
-  struct SchedEntry {
-    int ncb, cap; void *items; int *cnt; int max_items, workers;
-    // work-queue form (trmm_vsq_dyn_kernel): per-XCD item lists, list lengths, two sets of per-XCD counters
-    void *qitems = nullptr; int *qn = nullptr; unsigned int *qcnt = nullptr; int qmax = 0; unsigned launches = 0;
-  };
+  struct SchedEntry { int ncb, cap; void *items; int *cnt; int max_items, workers; };
   std::vector<SchedEntry> sched_cache;   // every schedule built so far (sched_items / sched_cnt point into one of them)
-  int worker_limit = 0;        // > 0: persistent kernels are scheduled for this many workers (a CU-masked stream)
-  // CU-partitioned predict pipeline (gpemu_predict_full_dev): the GP stage of chunk i + 1 on one set of CUs while the
-  // covariance writer of chunk i streams to HBM from the others
-  hipStream_t split_gp = nullptr, split_wr = nullptr;
-  int split_gp_per_xcd = 0, split_wr_per_xcd = 0;   // CUs per XCD of split_gp (first bits) / split_wr (last bits)
-  std::vector<hipEvent_t> split_ev;
-  double *pf_mean = nullptr, *pf_var = nullptr;   // [pf_cap][k] GP mean / variance of a whole predict batch
-  int64_t pf_cap = 0;
   int64_t vsq_nrb = 0;         // row blocks of partial ||W k_*||^2 the triangular GEMM writes
   // schedule of the small-batch triangular GEMM (k_trmm_small.hip) for the current number of 32-column blocks
   void *sm_items = nullptr;
@@ -91,6 +79,14 @@ struct gpemu_model {
   hipStream_t stream = nullptr;
 
   // per-PC GP state on the device
+  // cross-kernel operands for the matrix cores (kstar_host.h; predict_dev.h: kstar_mfma_block)
+  int ksteps = 2;              // MFMA k-steps of the augmented product: 4 ksteps >= d + 1
+  double *Xa = nullptr;        // [k][Npad/16][ksteps][64]  augmented, centred training rows in A-fragment order
+  double *alf = nullptr;       // [k][Npad/16][16]          alpha in accumulator-row order
+  double *qsc = nullptr;       // [k][4 ksteps]             query side: q' = q qsc + qof
+  double *qof = nullptr;
+  double *etab = nullptr;      // [2^KSTAR_TB]              2^(j / 2^KSTAR_TB)
+  // Matern-0.5 only (the direct distance of near-coincident pairs): row-major scaled rows, else null
   double *Xs = nullptr;        // [k][Npad][DPAD]  X_train / ls_p  (padded rows/dims = 0)
   double *inv_ls = nullptr;    // [k][DPAD]        1 / ls (the query side multiplies; the training side X / ls is exact)
   double *ls = nullptr;        // [k][DPAD]        length scales (padded dims = 1)
@@ -174,6 +170,11 @@ struct ProposeArgs {
 };
 
 int ensure_workspace(gpemu_model *m, int64_t B);
+// base kernel of the cross-kernel templates: 0 RBF, 1 / 2 / 3 Matern 0.5 / 1.5 / 2.5
+static inline int kstar_kind(const gpemu_model *m) {
+  if (m->kernel_kind != GPEMU_KERNEL_MATERN) return 0;
+  return (m->nu == 0.5) ? 1 : (m->nu == 1.5 ? 2 : 3);
+}
 
 // kernels (launchers; all asynchronous on `st`)
 // dXq_padded is read, or -- with pa->enabled -- written (rows [0, round_up(B, 128))) by the kernel

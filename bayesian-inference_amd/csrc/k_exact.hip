@@ -434,7 +434,7 @@ int launch_predict_full(gpemu_model *m, int64_t B, double n_div, double *dcv, do
   const GpParts parts{dmean, dvar, m->ws.mean_part, m->ws.vsq_part, m->kdiag, m->ws.cur_nchunk, m->ws.cur_nrb};
   if (pair && k <= 16 && F <= 512 && !no_mfma) {
     const int nrow = (F + 15) / 16, ngroups = (int)((B + PM_NB - 1) / PM_NB), total = nrow * ngroups;
-    const int ncu = (m->worker_limit > 0 && m->worker_limit < m->num_cu) ? m->worker_limit : m->num_cu;
+    const int ncu = m->num_cu;
     const int workers = std::min(ncu, total);
     const size_t shm_pm = sizeof(double) * (2 * 16 * (size_t)F + PM_NB * 16);
     // 16 waves x 32 columns (GPEMU_PM_CBW=2: 8 waves x 64 columns, within 1 % on the whole chip, slower on a share)

@@ -20,6 +20,7 @@
 #include <algorithm>
 
 #include "internal.h"
+#include "kstar_host.h"
 #include "loglik_dev.h"
 #include "predict_dev.h"
 #include "sampler_internal.h"
@@ -31,8 +32,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 constexpr int FRONT_MAX_GROUPS = 8;
 
 struct FrontGroup {
-  // cross-kernel of the half being opened
-  const double *Xs, *inv_ls, *constv, *alpha;
+  // cross-kernel of the half being opened (matrix-core operands, kstar_host.h; Xs / inv_ls: Matern-0.5 only)
+  const double *Xa, *alf, *qsc, *qof, *etab, *constv, *Xs, *inv_ls;
   double *KS, *mean_part_next;
   // likelihood of the half before
   const double *mean_part_prev, *vsq_part, *kdiag, *G, *g0, *scal;
@@ -195,35 +196,32 @@ __device__ __forceinline__ double front_loglik_lds(const FrontGroup &gr, bool in
   return walker_loglik_lowrank_lds(inside, mu, sd, gr.G, gr.g0, gr.scal, gr.k, gr.nblk, lane, M, gr.k + 1);
 }
 
-// rows of K_*^T for this wave's RPW training rows and the workgroup's 64 query columns (kstar_kernel's loop)
-template <int KIND, int RPW>
-__device__ __forceinline__ double front_kstar_rows(const double (&xq)[DPAD], const double *xs, const double *al,
-                                                   const double *s_tab, double c, int64_t jbase, int64_t N,
-                                                   double *ks, int64_t Bcap) {
-  double macc = 0.0;
-#pragma unroll 4
-  for (int jj = 0; jj < RPW; ++jj) {
-    double r2 = 0.0;
-#pragma unroll
-    for (int dd = 0; dd < DPAD; ++dd) {
-      double df = xq[dd] - xs[jj * DPAD + dd];
-      r2 = fma(df, df, r2);
-    }
-    double v = base_kernel_fast<KIND>(r2, s_tab) + c;
-    if (jbase + jj >= N) v = 0.0;
-    ks[(int64_t)jj * Bcap] = v;
-    macc = fma(al[jj], v, macc);
+// the cross-kernel rows of one workgroup (kstar_kernel's arithmetic: predict_dev.h), base kernel chosen at run time
+template <int JTW>
+__device__ __forceinline__ double front_kstar_block(const FrontGroup &gk, const double *s_q, const double *s_tab, double *s_red,
+                                                    int p, int chunk, int64_t b0, int d, int lane, int wave) {
+  constexpr int JT = 2 * JTW;                         // NBW = 2: two wave rows x JTW j-tiles
+  const int64_t njt = gk.Npad / 16;
+  const double c = gk.has_const ? gk.constv[p] : 0.0;
+  const double *Xa = gk.Xa + (int64_t)p * njt * 2 * 64, *alf = gk.alf + (int64_t)p * njt * 16;
+  const double *qsc = gk.qsc + p * 8, *qof = gk.qof + p * 8;
+  double *ks = gk.KS + (int64_t)p * gk.Npad * gk.Bcap + b0;
+  const KstarDirect none{nullptr, nullptr};
+  switch (gk.kind) {
+    case 0: return kstar_mfma_block<0, 2, JTW, 2, KSTAR_TB>(s_q, s_tab, s_red, Xa, alf, qsc, qof, c, d, (int64_t)chunk * JT, gk.N, ks, gk.Bcap, none, lane, wave);
+    case 1: return kstar_mfma_block<1, 2, JTW, 2, KSTAR_TB>(s_q, s_tab, s_red, Xa, alf, qsc, qof, c, d, (int64_t)chunk * JT, gk.N, ks, gk.Bcap,
+                                                           KstarDirect{gk.Xs + (int64_t)p * gk.Npad * DPAD, gk.inv_ls + p * DPAD}, lane, wave);
+    case 2: return kstar_mfma_block<2, 2, JTW, 2, KSTAR_TB>(s_q, s_tab, s_red, Xa, alf, qsc, qof, c, d, (int64_t)chunk * JT, gk.N, ks, gk.Bcap, none, lane, wave);
+    default: return kstar_mfma_block<3, 2, JTW, 2, KSTAR_TB>(s_q, s_tab, s_red, Xa, alf, qsc, qof, c, d, (int64_t)chunk * JT, gk.N, ks, gk.Bcap, none, lane, wave);
   }
-  return macc;
 }
 
-template <int RPW>
-__global__ __launch_bounds__(256) void front_kernel(FrontArgs fa) {
-  __shared__ double s_tab[32];
-  __shared__ __attribute__((aligned(16))) double s_xs[4 * RPW * DPAD];
-  __shared__ double s_al[4 * RPW];
+template <int JTW>   // j-tiles per wave of the cross-kernel workgroups: 1 = 32 training rows per workgroup, 2 = 64
+__global__ __launch_bounds__(256, 2) void front_kernel(FrontArgs fa) {
+  __shared__ double s_tab[1 << KSTAR_TB];
+  __shared__ __attribute__((aligned(16))) double s_q[64 * DPAD];
   __shared__ double s_eff[2][64][DPAD];
-  __shared__ double red[4][64];
+  __shared__ double red[4 * 64];
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];   // [4 waves][lds_k (lds_k + 1)]: likelihood, k > 16
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -266,23 +264,8 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs fa) {
   const int chunk = rest % gk.nchunk;
   const int p = rest / gk.nchunk;
   const int64_t b = (int64_t)cb * 64 + lane;
-  const int64_t jb0 = (int64_t)chunk * (4 * RPW);
-
-  // the workgroup's training rows: requested first, their latency overlaps everything below
-  constexpr int NPAIR = 4 * RPW * DPAD / 2;
-  constexpr int PER_T = (NPAIR + 255) / 256;
-  d2 stage[PER_T];
-  double al_stage = 0.0;
   const bool does_kstar = fa.have_next && g < fa.nkstar;
-  if (does_kstar) {
-    const d2 *xsrc = reinterpret_cast<const d2 *>(gk.Xs + ((int64_t)p * gk.Npad + jb0) * DPAD);
-#pragma unroll
-    for (int t = 0; t < PER_T; ++t) {
-      const int idx = threadIdx.x + 256 * t;
-      stage[t] = (idx < NPAIR) ? xsrc[idx] : d2{0.0, 0.0};
-    }
-    if (threadIdx.x < 4 * RPW) al_stage = gk.alpha[(int64_t)p * gk.Npad + jb0 + threadIdx.x];
-  }
+  if (does_kstar && threadIdx.x < (1 << KSTAR_TB)) s_tab[threadIdx.x] = gk.etab[threadIdx.x];
 
   // (A) + (B): likelihood of the previous half's proposals of this rank (first workgroups), stored to every rank
   if (fa.have_prev && g < fa.n_llwg) {
@@ -329,55 +312,32 @@ __global__ __launch_bounds__(256) void front_kernel(FrontArgs fa) {
     for (int dd = 0; dd < DPAD; ++dd) s_eff[wave][lane][dd] = px[dd];
   }
   if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 2] = __builtin_amdgcn_s_memrealtime();
-  if (threadIdx.x < 32) s_tab[threadIdx.x] = c_exp2_32[threadIdx.x];
-#pragma unroll
-  for (int t = 0; t < PER_T; ++t) {
-    const int idx = threadIdx.x + 256 * t;
-    if (idx < NPAIR) reinterpret_cast<d2 *>(s_xs)[idx] = stage[t];
-  }
-  if (threadIdx.x < 4 * RPW) s_al[threadIdx.x] = al_stage;
   __syncthreads();
   if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 3] = __builtin_amdgcn_s_memrealtime();
 
-  // stretch proposal q = c - (c - s) z  (emcee moves/stretch.py), stored once per column
-  double xq[DPAD];
+  // stretch proposal q = c - (c - s) z  (emcee moves/stretch.py), two components per thread, stored once per column
   {
     const double z = live ? fa.zz_next[b] : 1.0;
-#pragma unroll
-    for (int dd = 0; dd < DPAD; ++dd) {
-      double v = 0.0;
-      if (live && dd < fa.d) {
-        const double cj = s_eff[1][lane][dd], sw = s_eff[0][lane][dd];
-        v = cj - (cj - sw) * z;
-      }
-      xq[dd] = v;
+    const int c0 = wave, c1 = wave + 4;
+    double q0 = 0.0, q1 = 0.0;
+    if (live && c0 < fa.d) {
+      const double cj = s_eff[1][lane][c0], sw = s_eff[0][lane][c0];
+      q0 = cj - (cj - sw) * z;
     }
-    if (gi == 0 && chunk == 0 && p == 0 && wave == 0) {
-#pragma unroll
-      for (int dd = 0; dd < DPAD; ++dd) fa.Xq_next[b * DPAD + dd] = xq[dd];
+    if (live && c1 < fa.d) {
+      const double cj = s_eff[1][lane][c1], sw = s_eff[0][lane][c1];
+      q1 = cj - (cj - sw) * z;
     }
-#pragma unroll
-    for (int dd = 0; dd < DPAD; ++dd) xq[dd] = xq[dd] * gk.inv_ls[p * DPAD + dd];
+    if (gi == 0 && chunk == 0 && p == 0) {
+      fa.Xq_next[b * DPAD + c0] = q0;
+      fa.Xq_next[b * DPAD + c1] = q1;
+    }
+    s_q[lane * DPAD + c0] = q0;
+    s_q[lane * DPAD + c1] = q1;
   }
-  const double c = gk.has_const ? gk.constv[p] : 0.0;
-
-  const int64_t jbase = jb0 + wave * RPW;
-  const double *xs = s_xs + wave * RPW * DPAD;
-  const double *al = s_al + wave * RPW;
-  double *ks = gk.KS + ((int64_t)p * gk.Npad + jbase) * gk.Bcap + b;
-  double macc;
-  switch (gk.kind) {
-    case 0: macc = front_kstar_rows<0, RPW>(xq, xs, al, s_tab, c, jbase, gk.N, ks, gk.Bcap); break;
-    case 1: macc = front_kstar_rows<1, RPW>(xq, xs, al, s_tab, c, jbase, gk.N, ks, gk.Bcap); break;
-    case 2: macc = front_kstar_rows<2, RPW>(xq, xs, al, s_tab, c, jbase, gk.N, ks, gk.Bcap); break;
-    default: macc = front_kstar_rows<3, RPW>(xq, xs, al, s_tab, c, jbase, gk.N, ks, gk.Bcap); break;
-  }
-  red[wave][lane] = macc;
   __syncthreads();
-  if (wave == 0) {
-    const double sum = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    gk.mean_part_next[(b * gk.k + p) * gk.nchunk + chunk] = sum;
-  }
+  const double sum = front_kstar_block<JTW>(gk, s_q, s_tab, red, p, chunk, (int64_t)cb * 64, fa.d, lane, wave);
+  if (wave == 0) gk.mean_part_next[(b * gk.k + p) * gk.nchunk + chunk] = sum;
   if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 4] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -436,24 +396,50 @@ static int peer_timeout_polls() {        // read per launch: a getenv, nothing n
   return (int)(ms * 1000.0 / 3.5);
 }
 
-// Workgroups of a front launch wait on each other (the state and cross-kernel workgroups on the likelihood workgroups
-// of every rank), so all of them must be resident at once: LDS per workgroup (static ~20 KB + the k > 16 likelihood's
-// matrices) and 4 waves each bound how many fit on a CU.
+// Who waits for whom in a front launch: the state and the cross-kernel workgroups poll gather entries, which the
+// LIKELIHOOD workgroups of every rank store -- the first n_llwg workgroups of their launch, which wait for nothing of
+// that launch (their inputs are the previous launches' partial sums, ordered by the stream).  A 1-D grid is dispatched in
+// index order (round-robin over the XCDs, each XCD taking its share in order), so on every XCD the likelihood
+// workgroups are placed before any poller of the same launch can hold a slot: the pollers never keep them out, and a
+// launch may be (and at C3 with 2 ranks is: 1 285 workgroups against 768 resident ones) larger than what is resident
+// at once.  One GPU per rank therefore needs NO residency rule.  Only when several ranks SHARE a device (the one-GPU
+// rehearsals of the tests and of bench.py) can one process's resident pollers keep another process's likelihood
+// workgroups off the chip; then every rank's launch must fit beside the others': grid x ranks on the device <= resident
+// workgroups, taken from the runtime's occupancy figure for the kernel actually launched (3 per CU at 168 VGPRs, not the 8
+// an LDS-only count gives).  The ranks learn the share from gpemu_sampler_peer_share; a launch that does not fit makes
+// the import fail with GPEMU_ERR_UNSUPPORTED and the ranks fall back to the collective transports together.
 static int front_lds_k(const gpemu_sampler *s) {
   int lds_k = 0;
   for (const gpemu_model *m : s->groups)
     if (m->k > 16) lds_k = std::max(lds_k, (int)m->k);
   return lds_k;
 }
-static int64_t front_capacity(const gpemu_sampler *s) {
+static size_t front_dyn_lds(const gpemu_sampler *s) {
   const int lds_k = front_lds_k(s);
-  const int64_t lds = 20 * 1024 + (int64_t)4 * 8 * lds_k * (lds_k + 1);
-  const int64_t per_cu = std::min<int64_t>(8, (160 * 1024) / lds);
-  return per_cu * s->groups[0]->num_cu;
+  return sizeof(double) * 4 * (size_t)lds_k * (lds_k + 1);
+}
+static int front_set_lds_limit() {
+  static bool attr_set = false;
+  if (!attr_set) {
+    GP_HIP(hipFuncSetAttribute((const void *)front_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+    GP_HIP(hipFuncSetAttribute((const void *)front_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+    attr_set = true;
+  }
+  return GPEMU_OK;
+}
+// workgroups of front_kernel resident at once on the device (runtime occupancy x CUs); 0 if the runtime cannot say
+static int64_t front_capacity(const gpemu_sampler *s, bool small) {
+  const size_t dyn = front_dyn_lds(s);
+  if (dyn > 40 * 1024 && front_set_lds_limit() != GPEMU_OK) return 0;
+  int per_cu = 0;
+  const hipError_t e = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, front_kernel<1>, 256, dyn)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, front_kernel<2>, 256, dyn);
+  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return (int64_t)per_cu * s->groups[0]->num_cu;
 }
 // workgroups a front launch needs for `cnt` proposals of this rank
 static int64_t front_grid(const gpemu_sampler *s, int64_t cnt) {
-  const int rows_per_wg = cnt <= 256 ? 32 : 128;
+  const int rows_per_wg = cnt <= 256 ? KSTAR_ROWS_SMALL : KSTAR_ROWS_BIG;
   const int64_t ncolblk = ((cnt <= 64) ? 64 : round_up(cnt, TILE)) / 64;
   int64_t nkstar = 0;
   for (const gpemu_model *m : s->groups) nkstar += ncolblk * (m->Npad / rows_per_wg) * m->k;
@@ -465,12 +451,17 @@ bool front_eligible(const gpemu_sampler *s) {
   static const bool off = getenv("GPEMU_NO_FUSED") != nullptr;
   if (off || s->groups.empty() || (int)s->groups.size() > FRONT_MAX_GROUPS || s->nchains != 1) return false;
   for (const gpemu_model *m : s->groups)
-    if (m->k > 64 || m->device != s->groups[0]->device) return false;
+    if (m->k > 64 || m->ksteps != 2 || m->device != s->groups[0]->device) return false;   // ksteps 3: d = 8 parameters
   return true;
 }
 
-// can `cnt` proposals per rank and half run fused (every workgroup resident)?
-static bool front_fits(const gpemu_sampler *s, int64_t cnt) { return front_grid(s, std::max<int64_t>(cnt, 1)) <= front_capacity(s); }
+// can `cnt` proposals per rank and half run fused?  Always with one rank per device; with `device_share` ranks on one
+// device only if all their launches can be resident together (see above)
+static bool front_fits(const gpemu_sampler *s, int64_t cnt) {
+  if (s->device_share <= 1) return true;
+  cnt = std::max<int64_t>(cnt, 1);
+  return front_grid(s, cnt) * s->device_share <= front_capacity(s, cnt <= 256);
+}
 
 bool front_eligible_for(const gpemu_sampler *s, int world) {
   return front_eligible(s) && front_fits(s, (s->ns[0] + world - 1) / std::max(world, 1));
@@ -504,7 +495,7 @@ static int launch_front(gpemu_sampler *s, const Pending &pv, bool have_next, int
   fa.lds_k = front_lds_k(s);
   fa.d = (int)s->d; fa.W = (int)W;
   const bool small = cnt <= 256;
-  const int rows_per_wg = small ? 32 : 128;
+  const int rows_per_wg = small ? KSTAR_ROWS_SMALL : KSTAR_ROWS_BIG;
   const int64_t ncols = (cnt <= 64) ? 64 : round_up(cnt, TILE);
   fa.ncolblk = (int)(ncols / 64);
   int wg = 0;
@@ -512,13 +503,13 @@ static int launch_front(gpemu_sampler *s, const Pending &pv, bool have_next, int
     gpemu_model *m = s->groups[g];
     Workspace &w = m->ws;
     FrontGroup &fg = fa.grp[g];
-    fg.Xs = m->Xs; fg.inv_ls = m->inv_ls; fg.constv = m->constv; fg.alpha = m->alpha;
+    fg.Xa = m->Xa; fg.alf = m->alf; fg.qsc = m->qsc; fg.qof = m->qof; fg.etab = m->etab; fg.constv = m->constv;
+    fg.Xs = m->Xs; fg.inv_ls = m->inv_ls;
     fg.KS = w.KS;
     fg.mean_part_next = parity ? w.mean_part2 : w.mean_part;
     fg.N = m->N; fg.Npad = m->Npad; fg.Bcap = w.Bcap;
     fg.has_const = m->has_const; fg.k = (int)m->k;
-    fg.kind = 0;
-    if (m->kernel_kind == GPEMU_KERNEL_MATERN) fg.kind = (m->nu == 0.5) ? 1 : (m->nu == 1.5 ? 2 : 3);
+    fg.kind = kstar_kind(m);
     fg.nchunk = (int)(m->Npad / rows_per_wg);
     fg.wg0 = wg;
     if (have_next) wg += fa.ncolblk * fg.nchunk * fg.k;
@@ -595,23 +586,11 @@ static int launch_front(gpemu_sampler *s, const Pending &pv, bool have_next, int
     GP_HIP(hipMemset(dstamps, 0, sizeof(unsigned long long) * 8 * 4096));
   }
   fa.stamps = (stamp_path && grid.x <= 4096) ? dstamps : nullptr;
-  const size_t dyn = sizeof(double) * 4 * (size_t)fa.lds_k * (fa.lds_k + 1);
-  if (dyn > 40 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      GP_HIP(hipFuncSetAttribute((const void *)front_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-      GP_HIP(hipFuncSetAttribute((const void *)front_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-      attr_set = true;
-    }
-  }
-  if ((int64_t)grid.x > front_capacity(s)) {
-    set_error("fused front launch of %u workgroups exceeds what can be resident at once (%lld)", grid.x,
-              (long long)front_capacity(s));
-    return GPEMU_ERR_UNSUPPORTED;
-  }
+  const size_t dyn = front_dyn_lds(s);
+  if (dyn > 40 * 1024 && front_set_lds_limit() != GPEMU_OK) return GPEMU_ERR_HIP;
   const int pe0 = prof_mark(m0, st);
-  if (small) hipLaunchKernelGGL((front_kernel<8>), grid, block, dyn, st, fa);
-  else hipLaunchKernelGGL((front_kernel<32>), grid, block, dyn, st, fa);
+  if (small) hipLaunchKernelGGL((front_kernel<1>), grid, block, dyn, st, fa);
+  else hipLaunchKernelGGL((front_kernel<2>), grid, block, dyn, st, fa);
   GP_HIP(hipGetLastError());
   prof_pair(m0, 1, pe0, prof_mark(m0, st));
   if (fa.stamps && ++stamp_calls == 400) {
@@ -664,8 +643,8 @@ int front_run(gpemu_sampler *s, int64_t steps, int store_chain, int world, int r
   int64_t lo[2], cnt[2];
   for (int h = 0; h < 2; ++h) share_of(s, h, world, emulate ? 0 : rank, lo[h], cnt[h]);
   if (!front_fits(s, std::max(cnt[0], cnt[1]))) {
-    set_error("the fused run cannot keep every workgroup of a launch resident for %lld proposals per rank over %d group(s)",
-              (long long)std::max(cnt[0], cnt[1]), (int)s->groups.size());
+    set_error("the fused run's launches for %lld proposals per rank over %d group(s) do not fit beside those of the %d ranks "
+              "sharing this device", (long long)std::max(cnt[0], cnt[1]), (int)s->groups.size(), s->device_share);
     return GPEMU_ERR_UNSUPPORTED;
   }
   for (gpemu_model *m : s->groups) {
@@ -749,7 +728,7 @@ int gpemu_sampler_peer_export(gpemu_sampler *s, char *handle_out64) {
   GP_ARG(s && handle_out64, "null pointer");
   GP_HIP(hipSetDevice(s->device));
   if (!front_eligible(s)) {     // the caller (every rank alike) then stays on the collective transports
-    set_error("the fused run needs one emulation group with at most 16 PCs and at most 2048 walkers");
+    set_error("the fused run needs at most %d emulation groups of at most 64 PCs and 7 parameters, one chain", FRONT_MAX_GROUPS);
     return GPEMU_ERR_UNSUPPORTED;
   }
   int rc = ensure_gather(s);
@@ -765,8 +744,9 @@ int gpemu_sampler_peer_import(gpemu_sampler *s, int world, int rank, const char 
   GP_ARG(s && handles && world >= 1 && world <= 64 && rank >= 0 && rank < world, "world / rank / handles");
   GP_HIP(hipSetDevice(s->device));
   if (!front_eligible_for(s, world)) {
-    set_error("the fused run cannot take this sampler at %d rank(s): at most %d groups of at most 64 PCs, one chain, and "
-              "every workgroup of a launch resident at once", world, FRONT_MAX_GROUPS);
+    set_error("the fused run cannot take this sampler at %d rank(s): at most %d groups of at most 64 PCs and 7 parameters, "
+              "one chain, and -- with %d ranks on this device -- all their launches resident together", world,
+              FRONT_MAX_GROUPS, s->device_share);
     return GPEMU_ERR_UNSUPPORTED;
   }
   int rc = ensure_gather(s);
@@ -797,6 +777,12 @@ int gpemu_sampler_peer_import(gpemu_sampler *s, int world, int rank, const char 
   GP_HIP(hipMemcpy(s->peers, ptrs.data(), sizeof(double *) * world, hipMemcpyHostToDevice));
   s->peer_world = world;
   s->peer_rank = rank;
+  return GPEMU_OK;
+}
+
+int gpemu_sampler_peer_share(gpemu_sampler *s, int ranks_on_device) {
+  GP_ARG(s && ranks_on_device >= 1 && ranks_on_device <= 64, "sampler / ranks_on_device");
+  s->device_share = ranks_on_device;
   return GPEMU_OK;
 }
 

@@ -205,13 +205,12 @@ static void build_small_schedule(const gpemu_model *m, int ncb, std::vector<Smal
       for (int cb = 0; cb < ncb; ++cb) items.push_back({nt + ov, SmallItem{p, rb, cb * ST_N, 0}, p * ncb + cb});
   }
   std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.cost > b.cost; });
-  const int ncu = (m->worker_limit > 0 && m->worker_limit < m->num_cu) ? m->worker_limit : m->num_cu;
+  const int ncu = m->num_cu;
   nworkers = ncu < (int)items.size() ? ncu : (int)items.size();
   std::vector<std::vector<SmallItem>> per(nworkers);
   std::vector<double> load(nworkers, 0.0);
   const int nxcd = 8, ngroups = k * ncb;
-  static const bool xcd_aware = getenv("GPEMU_TRMM_NO_XCD") == nullptr;
-  const bool use_xcd = xcd_aware && nworkers == ncu && nworkers % nxcd == 0 && ngroups >= nxcd;
+  const bool use_xcd = nworkers == ncu && nworkers % nxcd == 0 && ngroups >= nxcd;
   const int whole = use_xcd ? (ngroups / nxcd) * nxcd : 0;     // groups [0, whole) live on one XCD each
   const int gper = use_xcd ? ngroups / nxcd : 1;
   for (const It &x : items) {
@@ -245,7 +244,7 @@ int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st) {
   Workspace &w = m->ws;
   const int nrb = (int)(m->Npad / ST_M);
   const int ncb = (int)(round_up(B, ST_N) / ST_N);
-  const int cap = (m->worker_limit > 0 && m->worker_limit < m->num_cu) ? m->worker_limit : m->num_cu;
+  const int cap = m->num_cu;
   if (m->sm_ncb != ncb || m->sm_cap != cap) {
     std::vector<SmallItem> flat;
     std::vector<int> cnt;

@@ -48,4 +48,227 @@ __device__ __forceinline__ double base_kernel_fast(double r2, const double *tab)
   return (1.0 + t + t * t / 3.0) * exp_neg(-t, tab);
 }
 
+
+// ---- cross-kernel on the matrix cores ---------------------------------------------------------------------------
+// K_*[j][b] = k(|x_j - q_b|) needs the squared scaled distance of every (training row, query) pair.  Round 3 formed
+// it on the vector ALUs (d subtractions + d FMAs per pair, padded to 8: 16 of the 29 fp64 instructions per element);
+// here it is one rank-8 product on v_mfma_f64_16x16x4_f64:
+//     -1/2 |x - q|^2 = x.q - 1/2 |x|^2 - 1/2 |q|^2
+// with the training side AUGMENTED by its own -1/2 |x|^2 in slot d and the query side by a 1 there, so that two MFMAs
+// (K = 8 >= d + 1) give x.q - 1/2 |x|^2 for a 16 x 16 tile of pairs and one add of the query's -1/2 |q|^2 -- a
+// per-lane constant, every accumulator register of a lane belongs to the same query -- finishes it.  Both sides are
+// CENTRED per PC (the mid-range of the scaled training coordinates) so that the cancellation error is ~d (range / 2 ls)^2
+// eps, and for the RBF kernel scaled by sqrt(2^TB / ln 2) so that the product IS the exponent in units of ln 2 / 2^TB:
+// the exponential then needs no range-reduction multiply (exp2_scaled).  Layouts (built on the host at model creation,
+// gpemu_api.hip: build_kstar_operands): Xa[p][jt][ks][lane] = aug[16 jt + (lane & 15)][4 ks + (lane >> 4)] -- the A
+// fragment of a j-tile is one coalesced 512-byte load -- and alf[p][jt][4 q + r] = alpha[16 jt + q + 4 r], the order in
+// which the accumulator rows of lane group q = lane >> 4 come.
+// ref: emulation.py:497 -> skl kernels.py:1553-1582 (RBF), 1708-1781 (Matern).
+typedef double kd4 __attribute__((ext_vector_type(4)));
+
+constexpr double KSTAR_LN2 = 0.6931471805599453;
+template <int TB> constexpr double kstar_rbf_scale2() { return (double)(1 << TB) / KSTAR_LN2; }   // s^2: x' = s (x/ls - c)
+
+// exp(y ln2 / 2^TB) for y <= ~0: n = rint(y) through the 1.5 2^52 shifter (the integer is the low word of the sum),
+// f = y - n exactly, 2^(n / 2^TB) = 2^(n >> TB) tab[n & (2^TB - 1)], exp(f ln2 / 2^TB) - 1 by a Taylor polynomial whose
+// degree follows the table size (|f| <= 1/2: truncation < 0.35 ulp), the power of two added into the exponent field.
+// Arguments below -700 (natural units) are clamped: the result stays a normal number.  A NaN comes out as a finite
+// value (v_max_f64 drops it): callers inject the NaN of a query on their own (kstar_mfma_block: the column's mean).
+template <int TB>
+__device__ __forceinline__ kd4 exp2_scaled4(kd4 y, const double *tab) {
+  constexpr double H = KSTAR_LN2 / (double)(1 << TB);
+  constexpr double SHIFT = 6755399441055744.0;   // 1.5 * 2^52
+  // four independent arguments stage by stage: the table reads of all four are in flight together
+  kd4 t, f, p, tb, v;
+  int n[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    y[r] = fmax(y[r], -700.0 / H);
+    t[r] = y[r] + SHIFT;
+    n[r] = __double2loint(t[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tb[r] = tab[n[r] & ((1 << TB) - 1)];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) f[r] = y[r] - (t[r] - SHIFT);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double q;
+    if (TB <= 5) {
+      q = fma(f[r], H * H * H * H * H * H / 720.0, H * H * H * H * H / 120.0);
+      q = fma(q, f[r], H * H * H * H / 24.0);
+    } else if (TB <= 7) {
+      q = fma(f[r], H * H * H * H * H / 120.0, H * H * H * H / 24.0);
+    } else {
+      q = H * H * H * H / 24.0;
+    }
+    q = fma(q, f[r], H * H * H / 6.0);
+    q = fma(q, f[r], H * H / 2.0);
+    q = fma(q, f[r], H);
+    p[r] = q * f[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double w = fma(tb[r], p[r], tb[r]);
+    const int hi = __double2hiint(w) + ((n[r] >> TB) << 20);
+    v[r] = __hiloint2double(hi, __double2loint(w));
+  }
+  return v;
+}
+
+// Matern-0.5 only: exp(-r) is not flat at r = 0, so a pair closer than ~1e-3.5 of the data's extent (a query ON a
+// training point) needs r^2 to better than the product form's ~d eps |x|^2: those few pairs are recomputed from the
+// coordinate differences, round 3's arithmetic (row-major scaled rows xs[j][8], query q inv_ls).
+struct KstarDirect {
+  const double *xs;    // [Npad][8] of this PC
+  const double *inv;   // [8]
+};
+__device__ __forceinline__ double kstar_direct_r2(const KstarDirect &dir, const double *s_q, int64_t row, int col) {
+  double r2 = 0.0;
+#pragma unroll
+  for (int dd = 0; dd < 8; ++dd) {
+    const double df = s_q[col * 8 + dd] * dir.inv[dd] - dir.xs[row * 8 + dd];
+    r2 = fma(df, df, r2);
+  }
+  return r2;
+}
+
+// kernel values of the four accumulator registers of a lane (one query column, four training rows)
+//   KIND 0 (RBF): operands scaled, acc + hq = -1/2 r^2 2^TB / ln2;  hq = -1/2 |q'|^2
+//   KIND 1, 2, 3 (Matern 0.5 / 1.5 / 2.5): operands unscaled, r^2 = max(-2 acc + |q'|^2, 0);  hq = |q'|^2
+template <int KIND, int TB>
+__device__ __forceinline__ kd4 kstar_value4(kd4 acc, double hq, const double *tab, const KstarDirect &dir,
+                                            const double *s_q, int64_t row0, int col) {
+  if (KIND == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += hq;
+    return exp2_scaled4<TB>(acc, tab);
+  }
+  constexpr double C = (double)(1 << TB) / KSTAR_LN2;
+  kd4 t, y, v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double r2 = fmax(fma(acc[r], -2.0, hq), 0.0);
+    if (KIND == 1 && r2 < 1e-7 * (hq + 1.0)) r2 = kstar_direct_r2(dir, s_q, row0 + 4 * r, col);
+    const double rr = sqrt(r2);
+    t[r] = (KIND == 1) ? rr : rr * ((KIND == 2) ? 1.7320508075688772 : 2.23606797749979);
+    y[r] = -C * t[r];
+  }
+  y = exp2_scaled4<TB>(y, tab);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (KIND == 1) v[r] = y[r];
+    else if (KIND == 2) v[r] = (1.0 + t[r]) * y[r];
+    else v[r] = (1.0 + t[r] + t[r] * t[r] / 3.0) * y[r];
+  }
+  return v;
+}
+
+// one j-tile (16 training rows) against the wave's NBW b-tiles: all MFMAs first (k-step major, so that no MFMA waits
+// for the one before it), then the kernel values, the stores and the mean's FMAs tile by tile
+template <int KIND, int KS, int NBW, int TB, bool RAGGED, int ABL = 0>   // ABL: probe ablations (1: no stores, 2: no exponential)
+__device__ __forceinline__ void kstar_mfma_jtile(const double (&a)[KS], const double (&bq)[NBW][KS], const double (&hq)[NBW],
+                                                 kd4 al, double c, const double *s_tab, int64_t row0, int64_t N,
+                                                 double *__restrict__ krow, int64_t Bcap, double (&macc)[NBW],
+                                                 const KstarDirect &dir, const double *s_q, int col0) {
+  kd4 acc[NBW];
+#pragma unroll
+  for (int bt = 0; bt < NBW; ++bt) acc[bt] = kd4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int bt = 0; bt < NBW; ++bt) acc[bt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bq[bt][s], acc[bt], 0, 0, 0);
+#pragma unroll
+  for (int bt = 0; bt < NBW; ++bt) {
+    kd4 v = (ABL == 2) ? acc[bt] : kstar_value4<KIND, TB>(acc[bt], hq[bt], s_tab, dir, s_q, row0, col0 + bt * 16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] += c;
+      if (RAGGED && row0 + 4 * r >= N) v[r] = 0.0;         // padded training rows contribute nothing
+      if (ABL != 1) krow[(int64_t)(4 * r) * Bcap + bt * 16] = v[r];
+      macc[bt] = fma(al[r], v[r], macc[bt]);
+    }
+  }
+}
+
+// One workgroup (4 waves) of the cross-kernel: WR JTW j-tiles of 16 training rows x 64 query columns.
+//   wave w: wave row wr = w % WR, wave column wc = w / WR (WC = 4 / NBW, WR = 4 / WC);
+//           j-tiles jt0 + wr JTW .. + JTW - 1, b-tiles wc NBW .. + NBW - 1
+//   NBW = 4, JTW = 2: 128 rows per workgroup (large batches);  NBW = 2, JTW = 1: 32 rows (small batches)
+// s_q: LDS [64][8] raw (unscaled, zero-padded) query rows of the workgroup's columns; s_red: LDS [4][64].
+// Returns, in wave 0, the workgroup's partial mean  sum_j alpha_j K[j][b]  of column b = lane (NaN if the query has one).
+template <int KIND, int KS, int JTW, int NBW, int TB, int ABL = 0>
+__device__ __forceinline__ double kstar_mfma_block(const double *s_q, const double *s_tab, double *s_red,
+                                                   const double *__restrict__ Xa, const double *__restrict__ alf,
+                                                   const double *__restrict__ qsc, const double *__restrict__ qof,
+                                                   double c, int d, int64_t jt0, int64_t N, double *__restrict__ ks,
+                                                   int64_t Bcap, const KstarDirect &dir, int lane, int wave) {
+  constexpr int WC = 4 / NBW, WR = 4 / WC;
+  const int wr = wave % WR, wc = wave / WR;
+  const int ln = lane & 15, lq = lane >> 4;
+  // the A fragments and alpha of the wave's j-tiles first: their latency overlaps the query side below
+  double a[JTW][KS];
+  kd4 al[JTW];
+#pragma unroll
+  for (int jj = 0; jj < JTW; ++jj) {
+    const int64_t jt = jt0 + wr * JTW + jj;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) a[jj][s] = Xa[(jt * KS + s) * 64 + lane];
+    al[jj] = *reinterpret_cast<const kd4 *>(alf + jt * 16 + lq * 4);
+  }
+  // B fragments: this lane's two (three) components of its NBW queries, scaled and centred; |q'|^2 per query
+  double bq[NBW][KS], hq[NBW];
+  double sc[KS], of[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) { sc[s] = qsc[4 * s + lq]; of[s] = qof[4 * s + lq]; }
+#pragma unroll
+  for (int bt = 0; bt < NBW; ++bt) {
+    const int col = (wc * NBW + bt) * 16 + ln;
+    double part = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int comp = 4 * s + lq;
+      const double qv = (comp < 8) ? s_q[col * 8 + comp] : 0.0;
+      const double v = fma(qv, sc[s], of[s]);
+      bq[bt][s] = v;
+      part = (comp < d) ? fma(v, v, part) : part;
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    hq[bt] = (KIND == 0) ? -0.5 * part : part;
+  }
+  double macc[NBW];
+#pragma unroll
+  for (int bt = 0; bt < NBW; ++bt) macc[bt] = 0.0;
+  double *kcol = ks + (int64_t)lq * Bcap + wc * NBW * 16 + ln;
+#pragma unroll
+  for (int jj = 0; jj < JTW; ++jj) {
+    const int64_t jt = jt0 + wr * JTW + jj;
+    double *krow = kcol + jt * 16 * Bcap;
+    if ((jt + 1) * 16 > N)      // wave-uniform: only the tiles that hold padded rows
+      kstar_mfma_jtile<KIND, KS, NBW, TB, true, ABL>(a[jj], bq, hq, al[jj], c, s_tab, jt * 16 + lq, N, krow, Bcap, macc, dir,
+                                                s_q, wc * NBW * 16 + ln);
+    else
+      kstar_mfma_jtile<KIND, KS, NBW, TB, false, ABL>(a[jj], bq, hq, al[jj], c, s_tab, jt * 16 + lq, N, krow, Bcap, macc, dir,
+                                                s_q, wc * NBW * 16 + ln);
+  }
+  // column sums: over the four lane groups, then over the wave rows in a fixed order
+#pragma unroll
+  for (int bt = 0; bt < NBW; ++bt) {
+    double s = macc[bt];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (hq[bt] != hq[bt]) s = hq[bt];                // a NaN in the query: the column's mean says so
+    if (lq == 0) s_red[wr * 64 + (wc * NBW + bt) * 16 + ln] = s;
+  }
+  __syncthreads();
+  double sum = 0.0;
+  if (wave == 0) {
+    if (WR == 4) sum = (s_red[lane] + s_red[64 + lane]) + (s_red[128 + lane] + s_red[192 + lane]);
+    else if (WR == 2) sum = s_red[lane] + s_red[64 + lane];
+    else sum = s_red[lane];
+  }
+  return sum;
+}
+
 }  // namespace gpemu

@@ -60,6 +60,7 @@ struct gpemu_sampler {
   double **peers = nullptr;    // device array [peer_world]: every rank's gather buffer (own one included)
   std::vector<void *> peer_opened;   // IPC mappings to close
   int peer_world = 0, peer_rank = 0;
+  int device_share = 1;        // ranks of the job whose samplers run on this device (gpemu_sampler_peer_share)
   uint64_t front_count = 0;    // fused launches so far (gather slot and buffer parity)
   // autocorrelation estimate (k_acf.hip): scratch kept between the lag blocks of one estimate
   double *acf_part = nullptr, *acf_acf = nullptr, *acf_mean = nullptr, *acf_acf0 = nullptr;
@@ -75,7 +76,7 @@ int sampler_check_nan(gpemu_sampler *s);
 // k_front.hip
 void front_release(gpemu_sampler *s);                         // frees the gather buffer and the peer mappings
 bool front_eligible(const gpemu_sampler *s);
-bool front_eligible_for(const gpemu_sampler *s, int world);   // ... and a rank's share of a `world`-rank run fits on the chip
+bool front_eligible_for(const gpemu_sampler *s, int world);   // ... and, with several ranks on this device, their launches fit on it together
 // `steps` stretch-move steps with two launches per half-step (fused front kernel + triangular GEMM); world / rank:
 // how the proposing half is split (world = 1: everything here); emulate: evaluate rank 0's share of a `world`-rank job
 int front_run(gpemu_sampler *s, int64_t steps, int store_chain, int world, int rank, bool emulate);

@@ -1,0 +1,221 @@
+// Probe: the cross-kernel K_*^T (k_predict.hip: kstar_kernel) with the squared distance on the vector ALUs (round 3)
+// against the matrix-core form (predict_dev.h: kstar_mfma_block), same problem, same outputs: times per launch under
+// back-to-back load and the largest difference of K and of the partial means from a long-double host evaluation.
+//   tools/kstar_probe [N] [B] [k] [d] [kind]
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+constexpr int DPAD = 8;
+#include "../predict_dev.h"
+#include "../kstar_host.h"
+using namespace gpemu;
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+// round 3's kernel, query rows read from the padded buffer (no proposal)
+template <int KIND, int RPW>
+__global__ __launch_bounds__(256) void kstar_valu(const double *Xq, const double *Xs, const double *inv_ls, const double *alpha,
+                                                  double *KS, double *mean_part, int64_t N, int64_t Npad, int64_t Bcap, double c) {
+  __shared__ double s_tab[32];
+  __shared__ __attribute__((aligned(16))) double s_xs[4 * RPW * DPAD];
+  __shared__ double s_al[4 * RPW];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = blockIdx.z, chunk = blockIdx.y, nchunk = gridDim.y;
+  const int64_t b = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t jb0 = (int64_t)chunk * (4 * RPW);
+  constexpr int NPAIR = 4 * RPW * DPAD / 2;
+  constexpr int PER_T = (NPAIR + 255) / 256;
+  d2 stage[PER_T];
+  const d2 *xsrc = reinterpret_cast<const d2 *>(Xs + ((int64_t)p * Npad + jb0) * DPAD);
+#pragma unroll
+  for (int t = 0; t < PER_T; ++t) {
+    const int idx = threadIdx.x + 256 * t;
+    stage[t] = (idx < NPAIR) ? xsrc[idx] : d2{0.0, 0.0};
+  }
+  double al_stage = 0.0;
+  if (threadIdx.x < 4 * RPW) al_stage = alpha[(int64_t)p * Npad + jb0 + threadIdx.x];
+  double xq[DPAD];
+#pragma unroll
+  for (int dd = 0; dd < DPAD; ++dd) xq[dd] = Xq[b * DPAD + dd] * inv_ls[p * DPAD + dd];
+  if (threadIdx.x < 32) s_tab[threadIdx.x] = c_exp2_32[threadIdx.x];
+#pragma unroll
+  for (int t = 0; t < PER_T; ++t) {
+    const int idx = threadIdx.x + 256 * t;
+    if (idx < NPAIR) reinterpret_cast<d2 *>(s_xs)[idx] = stage[t];
+  }
+  if (threadIdx.x < 4 * RPW) s_al[threadIdx.x] = al_stage;
+  __syncthreads();
+  const int64_t jbase = jb0 + wave * RPW;
+  const double *xs = s_xs + wave * RPW * DPAD;
+  const double *al = s_al + wave * RPW;
+  double *ks = KS + ((int64_t)p * Npad + jbase) * Bcap + b;
+  double macc = 0.0;
+#pragma unroll 4
+  for (int jj = 0; jj < RPW; ++jj) {
+    double r2 = 0.0;
+#pragma unroll
+    for (int dd = 0; dd < DPAD; ++dd) {
+      double df = xq[dd] - xs[jj * DPAD + dd];
+      r2 = fma(df, df, r2);
+    }
+    double v = base_kernel_fast<KIND>(r2, s_tab) + c;
+    if (jbase + jj >= N) v = 0.0;
+    ks[(int64_t)jj * Bcap] = v;
+    macc = fma(al[jj], v, macc);
+  }
+  __shared__ double red[4][64];
+  red[wave][lane] = macc;
+  __syncthreads();
+  if (wave == 0) mean_part[(b * gridDim.z + p) * nchunk + chunk] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// the matrix-core form: grid (Bcap/64, Npad / rows per workgroup, k)
+template <int KIND, int KS, int JTW, int NBW, int TB, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void kstar_mfma(const double *Xq, const double *Xa, const double *alf, const double *qsc,
+                                                  const double *qof, const double *tab, double *KSo, double *mean_part,
+                                                  int64_t N, int64_t Npad, int64_t Bcap, double c, int d, const double *Xs, const double *inv) {
+  __shared__ double s_tab[1 << TB];
+  __shared__ __attribute__((aligned(16))) double s_q[64 * 8];
+  __shared__ double s_red[4 * 64];
+  constexpr int WC = 4 / NBW, WR = 4 / WC, JT = WR * JTW;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = blockIdx.z, chunk = blockIdx.y, nchunk = gridDim.y;
+  const int64_t b0 = (int64_t)blockIdx.x * 64;
+  for (int i = threadIdx.x; i < (1 << TB); i += 256) s_tab[i] = tab[i];
+  reinterpret_cast<d2 *>(s_q)[threadIdx.x] = reinterpret_cast<const d2 *>(Xq + b0 * 8)[threadIdx.x];
+  __syncthreads();
+  const int64_t njt = Npad / 16;
+  const double sum = kstar_mfma_block<KIND, KS, JTW, NBW, TB, ABL>(
+      s_q, s_tab, s_red, Xa + (int64_t)p * njt * KS * 64, alf + (int64_t)p * njt * 16, qsc + p * 4 * KS, qof + p * 4 * KS, c, d,
+      (int64_t)chunk * JT, N, KSo + (int64_t)p * Npad * Bcap + b0, Bcap, KstarDirect{Xs + (int64_t)p * Npad * 8, inv + p * 8}, lane, wave);
+  if (wave == 0) mean_part[((b0 + lane) * gridDim.z + p) * nchunk + chunk] = sum;
+}
+
+int main(int argc, char **argv) {
+  const int64_t N = argc > 1 ? atoll(argv[1]) : 1000, B = argc > 2 ? atoll(argv[2]) : 512;
+  const int64_t k = argc > 3 ? atoll(argv[3]) : 10, d = argc > 4 ? atoll(argv[4]) : 6;
+  const int kind = argc > 5 ? atoi(argv[5]) : 0;
+  const int64_t Npad = (N + 127) / 128 * 128, Bcap = (B + 127) / 128 * 128;
+  const double lo[8] = {0.1, 1, 0.0067, 0.0067, 0, 0.05, 0.3, 2}, hi[8] = {0.5, 10, 10, 10, 1.5, 100, 0.9, 7};
+  unsigned long long s = 88172645463325252ull;
+  auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) / 9007199254740992.0; };
+  std::vector<double> X(N * d), ls(k * d), al(k * N), Q(Bcap * 8, 0.0);
+  for (auto &v : X) v = 0;
+  for (int64_t j = 0; j < N; ++j) for (int64_t dd = 0; dd < d; ++dd) X[j * d + dd] = lo[dd] + (hi[dd] - lo[dd]) * rnd();
+  for (int64_t p = 0; p < k; ++p) for (int64_t dd = 0; dd < d; ++dd) ls[p * d + dd] = (hi[dd] - lo[dd]) * (0.3 + 0.4 * rnd());
+  for (auto &v : al) v = 2.0 * rnd() - 1.0;
+  for (int64_t b = 0; b < B; ++b) for (int64_t dd = 0; dd < d; ++dd) Q[b * 8 + dd] = lo[dd] + (hi[dd] - lo[dd]) * rnd();
+  for (int64_t dd = 0; dd < d; ++dd) Q[3 * 8 + dd] = X[5 * d + dd];      // a query ON a training point
+  const double cval = 0.0;
+  // round-3 operands
+  std::vector<double> Xs(k * Npad * 8, 0.0), inv(k * 8, 1.0), alp(k * Npad, 0.0);
+  for (int64_t p = 0; p < k; ++p) {
+    for (int64_t dd = 0; dd < d; ++dd) inv[p * 8 + dd] = 1.0 / ls[p * d + dd];
+    for (int64_t j = 0; j < N; ++j) {
+      for (int64_t dd = 0; dd < d; ++dd) Xs[(p * Npad + j) * 8 + dd] = X[j * d + dd] / ls[p * d + dd];
+      alp[p * Npad + j] = al[p * N + j];
+    }
+  }
+  auto up = [&](const std::vector<double> &h) { double *p; CK(hipMalloc(&p, 8 * h.size())); CK(hipMemcpy(p, h.data(), 8 * h.size(), hipMemcpyHostToDevice)); return p; };
+  double *dXs = up(Xs), *dinv = up(inv), *dalp = up(alp), *dQ = up(Q);
+  double *KS0, *KS1, *mp0, *mp1;
+  const size_t nks = (size_t)k * Npad * Bcap, nmp = (size_t)Bcap * k * (Npad / 32);
+  CK(hipMalloc(&KS0, 8 * nks)); CK(hipMalloc(&KS1, 8 * nks)); CK(hipMalloc(&mp0, 8 * nmp)); CK(hipMalloc(&mp1, 8 * nmp));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int reps = 300;
+  auto timeit = [&](const char *name, auto launch) {
+    for (int i = 0; i < 400; ++i) launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) launch();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipGetLastError());
+    printf("%-44s %8.2f us per launch\n", name, ms * 1e3 / reps);
+  };
+  // host reference (long double) for a sample of elements and the full means of a few columns
+  auto kern = [&](long double r2) -> long double {
+    if (kind == 0) return expl(-0.5L * r2);
+    const long double r = sqrtl(r2);
+    if (kind == 1) return expl(-r);
+    if (kind == 2) { const long double t = r * sqrtl(3.0L); return (1 + t) * expl(-t); }
+    const long double t = r * sqrtl(5.0L); return (1 + t + t * t / 3) * expl(-t);
+  };
+  auto ref = [&](int64_t p, int64_t j, int64_t b) -> long double {
+    long double r2 = 0;
+    for (int64_t dd = 0; dd < d; ++dd) { const long double df = ((long double)X[j * d + dd] - (long double)Q[b * 8 + dd]) / (long double)ls[p * d + dd]; r2 += df * df; }
+    return kern(r2) + cval;
+  };
+  auto check = [&](const char *name, double *dKS, double *dmp, int nchunk) {
+    std::vector<double> hK(nks), hm(nmp);
+    CK(hipMemcpy(hK.data(), dKS, 8 * nks, hipMemcpyDeviceToHost)); CK(hipMemcpy(hm.data(), dmp, 8 * nmp, hipMemcpyDeviceToHost));
+    long double ek = 0, em = 0, e_on = 0;
+    for (int64_t p = 0; p < k; ++p)
+      for (int64_t b = 0; b < B; b += 7) {
+        long double mean = 0, got = 0;
+        for (int64_t j = 0; j < Npad; ++j) {
+          const double v = hK[(p * Npad + j) * Bcap + b];
+          if (j >= N) { if (v != 0.0) ek = INFINITY; continue; }
+          const long double r = ref(p, j, b);
+          ek = fmaxl(ek, fabsl(v - r) / fmaxl(r, 1e-300L));
+          mean += (long double)al[p * N + j] * r;
+        }
+        for (int c = 0; c < nchunk; ++c) got += hm[(b * k + p) * nchunk + c];
+        em = fmaxl(em, fabsl(got - mean));
+      }
+    for (int64_t p = 0; p < k; ++p) e_on = fmaxl(e_on, fabsl(hK[(p * Npad + 5) * Bcap + 3] - (1.0L + cval)));
+    printf("%-44s max rel err K %.3Le   max abs err mean %.3Le   |K - 1| at a training point %.3Le\n", name, ek, em, e_on);
+  };
+  const bool small = B <= 256;
+  dim3 blk(256);
+  {
+    dim3 grid((unsigned)(Bcap / 64), (unsigned)(Npad / (small ? 32 : 128)), (unsigned)k);
+#define LV(KD) if (small) hipLaunchKernelGGL((kstar_valu<KD, 8>), grid, blk, 0, 0, dQ, dXs, dinv, dalp, KS0, mp0, N, Npad, Bcap, cval); \
+               else hipLaunchKernelGGL((kstar_valu<KD, 32>), grid, blk, 0, 0, dQ, dXs, dinv, dalp, KS0, mp0, N, Npad, Bcap, cval)
+    timeit("vector-ALU distance (round 3)", [&]() { switch (kind) { case 0: LV(0); break; case 1: LV(1); break; case 2: LV(2); break; default: LV(3); } });
+    check("vector-ALU distance (round 3)", KS0, mp0, (int)grid.y);
+  }
+#define RUN(TBV, JTWV, NBWV, label)                                                                                         \
+  {                                                                                                                         \
+    KstarHost h;                                                                                                            \
+    build_kstar_operands(N, Npad, d, k, kind, X.data(), ls.data(), al.data(), h, TBV);                                      \
+    double *dXa = up(h.Xa), *dalf = up(h.alf), *dqsc = up(h.qsc), *dqof = up(h.qof), *dtab = up(h.tab);                      \
+    constexpr int JT = (4 / (4 / NBWV)) * JTWV;                                                                             \
+    dim3 grid((unsigned)(Bcap / 64), (unsigned)(Npad / (16 * JT)), (unsigned)k);                                            \
+    auto go = [&]() {                                                                                                       \
+      if (h.ksteps == 2) { switch (kind) {                                                                                  \
+        case 0: hipLaunchKernelGGL((kstar_mfma<0, 2, JTWV, NBWV, TBV>), grid, blk, 0, 0, dQ, dXa, dalf, dqsc, dqof, dtab, KS1, mp1, N, Npad, Bcap, cval, (int)d, dXs, dinv); break; \
+        case 1: hipLaunchKernelGGL((kstar_mfma<1, 2, JTWV, NBWV, TBV>), grid, blk, 0, 0, dQ, dXa, dalf, dqsc, dqof, dtab, KS1, mp1, N, Npad, Bcap, cval, (int)d, dXs, dinv); break; \
+        case 2: hipLaunchKernelGGL((kstar_mfma<2, 2, JTWV, NBWV, TBV>), grid, blk, 0, 0, dQ, dXa, dalf, dqsc, dqof, dtab, KS1, mp1, N, Npad, Bcap, cval, (int)d, dXs, dinv); break; \
+        default: hipLaunchKernelGGL((kstar_mfma<3, 2, JTWV, NBWV, TBV>), grid, blk, 0, 0, dQ, dXa, dalf, dqsc, dqof, dtab, KS1, mp1, N, Npad, Bcap, cval, (int)d, dXs, dinv); } } \
+      else hipLaunchKernelGGL((kstar_mfma<0, 3, JTWV, NBWV, TBV>), grid, blk, 0, 0, dQ, dXa, dalf, dqsc, dqof, dtab, KS1, mp1, N, Npad, Bcap, cval, (int)d, dXs, dinv); \
+    };                                                                                                                      \
+    CK(hipMemset(KS1, 0xff, 8 * nks));                                                                                      \
+    timeit(label, go);                                                                                                      \
+    check(label, KS1, mp1, (int)grid.y);                                                                                    \
+    hipFree(dXa); hipFree(dalf); hipFree(dqsc); hipFree(dqof); hipFree(dtab);                                               \
+  }
+  if (kind == 0 && d <= 7) {
+    KstarHost h;
+    build_kstar_operands(N, Npad, d, k, kind, X.data(), ls.data(), al.data(), h, 6);
+    double *dXa = up(h.Xa), *dalf = up(h.alf), *dqsc = up(h.qsc), *dqof = up(h.qof), *dtab = up(h.tab);
+    dim3 grid((unsigned)(Bcap / 64), (unsigned)(Npad / 64), (unsigned)k);
+    timeit("ablation: 2 x 2 waves, no stores", [&]() { hipLaunchKernelGGL((kstar_mfma<0, 2, 2, 2, 6, 1>), grid, blk, 0, 0, dQ, dXa, dalf, dqsc, dqof, dtab, KS1, mp1, N, Npad, Bcap, cval, (int)d, dXs, dinv); });
+    timeit("ablation: 2 x 2 waves, no exponential", [&]() { hipLaunchKernelGGL((kstar_mfma<0, 2, 2, 2, 6, 2>), grid, blk, 0, 0, dQ, dXa, dalf, dqsc, dqof, dtab, KS1, mp1, N, Npad, Bcap, cval, (int)d, dXs, dinv); });
+    timeit("hipMemsetAsync of the K_* workspace", [&]() { (void)hipMemsetAsync(KS1, 0, 8 * nks, 0); });
+  }
+  RUN(5, 2, 4, "matrix cores, table 32, 128 rows / wg");
+  RUN(6, 2, 4, "matrix cores, table 64, 128 rows / wg");
+  RUN(8, 2, 4, "matrix cores, table 256, 128 rows / wg");
+  RUN(6, 1, 4, "matrix cores, table 64, 64 rows / wg");
+  RUN(6, 4, 4, "matrix cores, table 64, 256 rows / wg");
+  RUN(6, 1, 2, "matrix cores, table 64, 32 rows / wg");
+  RUN(6, 2, 2, "matrix cores, table 64, 64 rows / wg (2 x 2 waves)");
+  return 0;
+}

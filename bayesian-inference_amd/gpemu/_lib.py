@@ -33,6 +33,7 @@ _SIGNATURES = {
     "gpemu_last_error": (C.c_char_p, []),
     "gpemu_device_count": (C.c_int, []),
     "gpemu_device_name": (C.c_int, [C.c_int, C.c_char_p, c_i64]),
+    "gpemu_device_bus_id": (C.c_int, [C.c_int, C.c_char_p, c_i64]),
     "gpemu_model_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, c_i64, c_i64, c_i64, c_i64,
                                      C.c_int, C.c_double, C.c_int, C.c_int] + [C.c_void_p] * 10),
     "gpemu_model_destroy": (C.c_int, [C.c_void_p]),
@@ -93,6 +94,7 @@ _SIGNATURES = {
     "gpemu_sampler_peer_import": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "gpemu_sampler_run_peer": (C.c_int, [C.c_void_p, c_i64, C.c_int]),
     "gpemu_sampler_peer_selftest": (C.c_int, [C.c_void_p]),
+    "gpemu_sampler_peer_share": (C.c_int, [C.c_void_p, C.c_int]),
     "gpemu_philox4x32": (C.c_int, [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]),
 }
 

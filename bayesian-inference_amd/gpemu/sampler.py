@@ -357,6 +357,20 @@ class DeviceSampler:
         L = _lib.lib()
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         where = torch.device("cuda", self.device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        # ranks sharing this GPU (one-GPU rehearsals): the library then checks that all their launches fit on it
+        # together; one rank per GPU -- the production layout -- needs no such rule
+        import hashlib
+        import socket
+        bus = C.create_string_buffer(64)
+        check(L.gpemu_device_bus_id(int(self.device), bus, 64))
+        key16 = hashlib.sha256(socket.gethostname().encode() + b"/" + bus.value).digest()[:16]
+        mykey = torch.tensor(list(key16), dtype=torch.uint8, device=where)
+        keys = torch.zeros(16 * world, dtype=torch.uint8, device=where)
+        dist.all_gather_into_tensor(keys, mykey, group=group)
+        keys = bytes(keys.cpu().tolist())
+        share = sum(1 for r in range(world) if keys[16 * r:16 * r + 16] == key16)
+        check(L.gpemu_sampler_peer_share(self._h, int(share)))
+        self.transport_info["ranks_on_this_device"] = int(share)
         mine = (C.c_char * 64)()
         ok = 1
         stage = "ok"

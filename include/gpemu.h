@@ -54,6 +54,9 @@ const char *gpemu_version(void);
 const char *gpemu_last_error(void);
 int gpemu_device_count(void); /* number of HIP devices, 0 if none (never an error) */
 int gpemu_device_name(int device, char *buf, int64_t buflen);
+/* PCI bus id of the device ("0000:c1:00.0"): with the host name it tells whether two ranks of a job share a GPU
+ * (gpemu_sampler_peer_share) */
+int gpemu_device_bus_id(int device, char *buf, int64_t buflen);
 
 /* ---- model: one emulation group --------------------------------------------------------- */
 /* Replaces the per-worker state of ref: log_posterior.py:26-38 (initialize_pool_variables) and
@@ -264,12 +267,17 @@ int gpemu_sampler_peer_selftest(gpemu_sampler *s);
  * and each imports all of them (handles[world*64], its own entry is ignored).  gpemu_sampler_run_peer then runs
  * `steps` stretch-move steps with one front launch + one triangular GEMM per emulation group per half-step and no RCCL
  * call; same chain as gpemu_sampler_run on every rank.  Takes up to 8 emulation groups of up to 64 PCs each, one chain,
- * as long as every workgroup of a front launch can be resident at once for the rank's share of the proposals (else
- * GPEMU_ERR_UNSUPPORTED from the export / import: use gpemu_sampler_run_sharded).  The ranks must enter every call
+ * d <= 7 parameters (else GPEMU_ERR_UNSUPPORTED from the export / import: use gpemu_sampler_run_sharded).  The ranks must enter every call
  * together (a barrier on the host side): a peer's stores may arrive as soon as it has started.  A peer that does not
  * deliver within GPEMU_PEER_TIMEOUT_MS (5000) ends the run with GPEMU_ERR_STATE on every rank.
  * Replaces ref: mcmc.py:77-85 (the pool.map over walkers). */
 int gpemu_sampler_peer_export(gpemu_sampler *s, char *handle_out64);
+/* How many ranks of the job run their samplers on THIS device (default 1: one process per GPU, the production layout of
+ * ref: mcmc.py:77-85's pool).  Call before gpemu_sampler_peer_import.  With one rank per device a fused launch needs no
+ * residency rule (its waits only target workgroups dispatched before the waiters); with several ranks on one device
+ * (one-GPU rehearsals) all their launches must be resident together, which the import then checks against the runtime's
+ * occupancy figure -- failing with GPEMU_ERR_UNSUPPORTED (fall back to gpemu_sampler_run_sharded) instead of a time-out. */
+int gpemu_sampler_peer_share(gpemu_sampler *s, int ranks_on_device);
 int gpemu_sampler_peer_import(gpemu_sampler *s, int world, int rank, const char *handles);
 int gpemu_sampler_run_peer(gpemu_sampler *s, int64_t steps, int store_chain);
 
