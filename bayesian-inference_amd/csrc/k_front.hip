@@ -198,21 +198,20 @@ __device__ __forceinline__ double front_loglik_lds(const FrontGroup &gr, bool in
 
 // the cross-kernel rows of one workgroup (kstar_kernel's arithmetic: predict_dev.h), base kernel chosen at run time
 template <int JTW>
-__device__ __forceinline__ double front_kstar_block(const FrontGroup &gk, const double *s_q, const double *s_tab, double *s_red,
-                                                    int p, int chunk, int64_t b0, int d, int lane, int wave) {
+__device__ __forceinline__ double front_kstar_block(const FrontGroup &gk, const KstarFrags<2, JTW> &fr, const double *s_q,
+                                                    const double *s_tab, double *s_red, int p, int chunk, int64_t b0, int d,
+                                                    int lane, int wave) {
   constexpr int JT = 2 * JTW;                         // NBW = 2: two wave rows x JTW j-tiles
-  const int64_t njt = gk.Npad / 16;
   const double c = gk.has_const ? gk.constv[p] : 0.0;
-  const double *Xa = gk.Xa + (int64_t)p * njt * 2 * 64, *alf = gk.alf + (int64_t)p * njt * 16;
   const double *qsc = gk.qsc + p * 8, *qof = gk.qof + p * 8;
   double *ks = gk.KS + (int64_t)p * gk.Npad * gk.Bcap + b0;
   const KstarDirect none{nullptr, nullptr};
   switch (gk.kind) {
-    case 0: return kstar_mfma_block<0, 2, JTW, 2, KSTAR_TB>(s_q, s_tab, s_red, Xa, alf, qsc, qof, c, d, (int64_t)chunk * JT, gk.N, ks, gk.Bcap, none, lane, wave);
-    case 1: return kstar_mfma_block<1, 2, JTW, 2, KSTAR_TB>(s_q, s_tab, s_red, Xa, alf, qsc, qof, c, d, (int64_t)chunk * JT, gk.N, ks, gk.Bcap,
+    case 0: return kstar_mfma_block<0, 2, JTW, 2, KSTAR_TB>(s_q, s_tab, s_red, fr, qsc, qof, c, d, (int64_t)chunk * JT, gk.N, ks, gk.Bcap, none, lane, wave);
+    case 1: return kstar_mfma_block<1, 2, JTW, 2, KSTAR_TB>(s_q, s_tab, s_red, fr, qsc, qof, c, d, (int64_t)chunk * JT, gk.N, ks, gk.Bcap,
                                                            KstarDirect{gk.Xs + (int64_t)p * gk.Npad * DPAD, gk.inv_ls + p * DPAD}, lane, wave);
-    case 2: return kstar_mfma_block<2, 2, JTW, 2, KSTAR_TB>(s_q, s_tab, s_red, Xa, alf, qsc, qof, c, d, (int64_t)chunk * JT, gk.N, ks, gk.Bcap, none, lane, wave);
-    default: return kstar_mfma_block<3, 2, JTW, 2, KSTAR_TB>(s_q, s_tab, s_red, Xa, alf, qsc, qof, c, d, (int64_t)chunk * JT, gk.N, ks, gk.Bcap, none, lane, wave);
+    case 2: return kstar_mfma_block<2, 2, JTW, 2, KSTAR_TB>(s_q, s_tab, s_red, fr, qsc, qof, c, d, (int64_t)chunk * JT, gk.N, ks, gk.Bcap, none, lane, wave);
+    default: return kstar_mfma_block<3, 2, JTW, 2, KSTAR_TB>(s_q, s_tab, s_red, fr, qsc, qof, c, d, (int64_t)chunk * JT, gk.N, ks, gk.Bcap, none, lane, wave);
   }
 }
 
@@ -265,10 +264,11 @@ __global__ __launch_bounds__(256, 2) void front_kernel(FrontArgs fa) {
   const int p = rest / gk.nchunk;
   const int64_t b = (int64_t)cb * 64 + lane;
   const bool does_kstar = fa.have_next && g < fa.nkstar;
+  const bool does_ll = fa.have_prev && g < fa.n_llwg;
   if (does_kstar && threadIdx.x < (1 << KSTAR_TB)) s_tab[threadIdx.x] = gk.etab[threadIdx.x];
 
   // (A) + (B): likelihood of the previous half's proposals of this rank (first workgroups), stored to every rank
-  if (fa.have_prev && g < fa.n_llwg) {
+  if (does_ll) {
     const int i = g * 4 + wave;
     if (i < fa.prev_cnt) {
       bool in = true;
@@ -294,6 +294,13 @@ __global__ __launch_bounds__(256, 2) void front_kernel(FrontArgs fa) {
   }
   if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 1] = __builtin_amdgcn_s_memrealtime();
   if (!does_kstar) return;
+  // the workgroup's training fragments.  Requested here, not at the top: held across the waits below they cost 12-24
+  // VGPRs (174 / 186 instead of 162) and with them the third resident workgroup per CU -- measured slower at 2 and 4
+  // ranks (0.175 / 0.115 vs 0.170 / 0.109 ms per step), equal at 8
+  KstarFrags<2, JTW> fr;
+  const int64_t njt = gk.Npad / 16;
+  kstar_load_frags<2, JTW, 2>(fr, gk.Xa + (int64_t)p * njt * 2 * 64, gk.alf + (int64_t)p * njt * 16, (int64_t)chunk * (2 * JTW),
+                              lane, wave);
 
   // (C) the two walkers of this column's proposal, as they stand after the previous half; wave 0: the proposing
   // walker, wave 1: its partner of the complementary set
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void front_kernel(FrontArgs fa) {
     s_q[lane * DPAD + c1] = q1;
   }
   __syncthreads();
-  const double sum = front_kstar_block<JTW>(gk, s_q, s_tab, red, p, chunk, (int64_t)cb * 64, fa.d, lane, wave);
+  const double sum = front_kstar_block<JTW>(gk, fr, s_q, s_tab, red, p, chunk, (int64_t)cb * 64, fa.d, lane, wave);
   if (wave == 0) gk.mean_part_next[(b * gk.k + p) * gk.nchunk + chunk] = sum;
   if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 4] = __builtin_amdgcn_s_memrealtime();
 }

@@ -36,6 +36,8 @@ struct KstarArgs {
   double *KS, *mean_part;
   int64_t N, Npad, Bcap;
   int has_const, d;
+  int k, nchunk, ncb64;                // grid = ncb64 * nchunk * k workgroups (1-D)
+  int gper;                            // > 0: XCD-aware placement, gper (PC, 128-column block) groups per XCD
 };
 
 template <int KIND, int KS, int JTW, int NBW>
@@ -46,12 +48,31 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(KstarArgs ka, ProposeArgs
   constexpr int WC = 4 / NBW, WR = 4 / WC, JT = WR * JTW;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int p = blockIdx.z;
-  const int chunk = blockIdx.y;
-  const int nchunk = gridDim.y;
-  const int64_t b0 = (int64_t)blockIdx.x * 64;
+  // Workgroups are dispatched round-robin over the 8 XCDs (workgroup i runs on XCD i % 8).  The triangular GEMM that
+  // consumes K_*^T deals whole (PC, 128-column block) groups to XCDs (build_trmm_schedule: group g -> XCD g / gper), and
+  // the L2s are kept coherent by hardware: a store to a line that ANOTHER XCD's L2 still holds from the GEMM's reads has
+  // to invalidate it there first (measured: this kernel takes 13.5 us without the GEMM in between, 19.6 us behind it).
+  // So each group's rows are written by the XCD that will read them: same L2, no cross-XCD traffic.
+  int p, chunk, cb;
+  const int nchunk = ka.nchunk;
+  if (ka.gper > 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int half = slot & 1, rest = slot >> 1;
+    chunk = rest % nchunk;
+    const int g = xcd * ka.gper + rest / nchunk, ncb128 = ka.ncb64 >> 1;
+    p = g / ncb128;
+    cb = 2 * (g - p * ncb128) + half;
+  } else {
+    cb = blockIdx.x % ka.ncb64;
+    const int rest = blockIdx.x / ka.ncb64;
+    chunk = rest % nchunk;
+    p = rest / nchunk;
+  }
+  const int64_t b0 = (int64_t)cb * 64;
   const int64_t b = b0 + lane;
   const int c0 = wave, c1 = wave + 4;                // this thread's two components of query b
+  const int64_t njt = ka.Npad / 16;
+  KstarFrags<KS, JTW> fr;
   if (threadIdx.x < (1 << KSTAR_TB)) s_tab[threadIdx.x] = ka.etab[threadIdx.x];
   const bool keeper = chunk == 0 && p == 0;          // the workgroup that stores the padded rows of its columns
   double q0 = 0.0, q1 = 0.0;
@@ -87,15 +108,16 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(KstarArgs ka, ProposeArgs
   s_q[lane * DPAD + c0] = q0;
   s_q[lane * DPAD + c1] = q1;
   __syncthreads();
-  const int64_t njt = ka.Npad / 16;
+  // (requesting the fragments ahead of the proposal's loads was measured: 16.45 vs 16.1 us, slower)
+  kstar_load_frags<KS, JTW, NBW>(fr, ka.Xa + (int64_t)p * njt * KS * 64, ka.alf + (int64_t)p * njt * 16, (int64_t)chunk * JT,
+                                 lane, wave);
   const double c = ka.has_const ? ka.constv[p] : 0.0;
   KstarDirect dir{nullptr, nullptr};
   if (KIND == 1) dir = KstarDirect{ka.Xs + (int64_t)p * ka.Npad * DPAD, ka.inv_ls + p * DPAD};
   const double sum = kstar_mfma_block<KIND, KS, JTW, NBW, KSTAR_TB>(
-      s_q, s_tab, s_red, ka.Xa + (int64_t)p * njt * KS * 64, ka.alf + (int64_t)p * njt * 16, ka.qsc + p * 4 * KS,
-      ka.qof + p * 4 * KS, c, ka.d, (int64_t)chunk * JT, ka.N, ka.KS + (int64_t)p * ka.Npad * ka.Bcap + b0, ka.Bcap, dir,
+      s_q, s_tab, s_red, fr, ka.qsc + p * 4 * KS, ka.qof + p * 4 * KS, c, ka.d, (int64_t)chunk * JT, ka.N, ka.KS + (int64_t)p * ka.Npad * ka.Bcap + b0, ka.Bcap, dir,
       lane, wave);
-  if (wave == 0) ka.mean_part[(b * gridDim.z + p) * nchunk + chunk] = sum;
+  if (wave == 0) ka.mean_part[(b * ka.k + p) * nchunk + chunk] = sum;
 }
 
 int launch_kstar(gpemu_model *m, int64_t B, double *dXq, hipStream_t st, const ProposeArgs *pa) {
@@ -110,11 +132,15 @@ int launch_kstar(gpemu_model *m, int64_t B, double *dXq, hipStream_t st, const P
   // column blocks of 64 queries: whole 128-column tiles for the triangular GEMM, except that a batch of at most
   // 64 (always served by the small-batch kernel's 64-column items) needs only its first block
   const int64_t ncols = (B <= 64) ? 64 : round_up(B, TILE);
-  dim3 grid((unsigned)(ncols / 64), (unsigned)w.cur_nchunk, (unsigned)m->k), block(256);
+  const int ncb64 = (int)(ncols / 64);
+  dim3 grid((unsigned)(ncb64 * w.cur_nchunk * (int)m->k)), block(256);
+  // XCD-aware placement where the large-batch GEMM's schedule is (whole groups per XCD: build_trmm_schedule)
+  const int ngroups = (int)m->k * (ncb64 / 2);
+  const int gper = (B > 128 && ncb64 % 2 == 0 && ngroups % 8 == 0 && m->num_cu % 8 == 0) ? ngroups / 8 : 0;
   const int pe0 = prof_mark(m, st);
   const int kind = kstar_kind(m);
   KstarArgs ka{dXq, m->Xa, m->alf, m->qsc, m->qof, m->etab, m->constv, m->Xs, m->inv_ls, w.KS, w.mean_part,
-               m->N, m->Npad, w.Bcap, m->has_const, (int)m->d};
+               m->N, m->Npad, w.Bcap, m->has_const, (int)m->d, (int)m->k, w.cur_nchunk, ncb64, gper};
 #define GP_LAUNCH_KSTAR2(KD, KSV)                                                                       \
   do {                                                                                                  \
     if (small) hipLaunchKernelGGL((kstar_kernel<KD, KSV, 1, 2>), grid, block, 0, st, ka, pargs);        \

@@ -164,58 +164,71 @@ __device__ __forceinline__ kd4 kstar_value4(kd4 acc, double hq, const double *ta
   return v;
 }
 
-// one j-tile (16 training rows) against the wave's NBW b-tiles: all MFMAs first (k-step major, so that no MFMA waits
-// for the one before it), then the kernel values, the stores and the mean's FMAs tile by tile
-template <int KIND, int KS, int NBW, int TB, bool RAGGED, int ABL = 0>   // ABL: probe ablations (1: no stores, 2: no exponential)
-__device__ __forceinline__ void kstar_mfma_jtile(const double (&a)[KS], const double (&bq)[NBW][KS], const double (&hq)[NBW],
-                                                 kd4 al, double c, const double *s_tab, int64_t row0, int64_t N,
-                                                 double *__restrict__ krow, int64_t Bcap, double (&macc)[NBW],
-                                                 const KstarDirect &dir, const double *s_q, int col0) {
-  kd4 acc[NBW];
+// the augmented product of one 16 x 16 tile of (training row, query) pairs: KS chained MFMAs
+template <int KS>
+__device__ __forceinline__ kd4 kstar_tile_product(const double (&a)[KS], const double (&bq)[KS]) {
+  kd4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int bt = 0; bt < NBW; ++bt) acc[bt] = kd4{0.0, 0.0, 0.0, 0.0};
+  for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bq[s], acc, 0, 0, 0);
+  return acc;
+}
+
+// kernel values, stores and the mean's FMAs of one tile from its accumulator
+template <int KIND, int TB, int ABL = 0>   // ABL: probe ablations (1: no stores, 2: no exponential, 3: nontemporal stores)
+__device__ __forceinline__ void kstar_tile_finish(kd4 acc, double hq, kd4 al, double c, const double *s_tab, bool ragged,
+                                                  int64_t row0, int64_t N, double *__restrict__ kout, int64_t Bcap, double &macc,
+                                                  const KstarDirect &dir, const double *s_q, int col) {
+  kd4 v = (ABL == 2) ? acc : kstar_value4<KIND, TB>(acc, hq, s_tab, dir, s_q, row0, col);
 #pragma unroll
-  for (int s = 0; s < KS; ++s)
+  for (int r = 0; r < 4; ++r) v[r] += c;
+  if (ragged) {                                           // wave-uniform: only the tiles that hold padded training rows
 #pragma unroll
-    for (int bt = 0; bt < NBW; ++bt) acc[bt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bq[bt][s], acc[bt], 0, 0, 0);
+    for (int r = 0; r < 4; ++r)
+      if (row0 + 4 * r >= N) v[r] = 0.0;                  // ... which contribute nothing
+  }
 #pragma unroll
-  for (int bt = 0; bt < NBW; ++bt) {
-    kd4 v = (ABL == 2) ? acc[bt] : kstar_value4<KIND, TB>(acc[bt], hq[bt], s_tab, dir, s_q, row0, col0 + bt * 16);
+  for (int r = 0; r < 4; ++r) {
+    if (ABL == 3) __builtin_nontemporal_store(v[r], &kout[(int64_t)(4 * r) * Bcap]);
+    else if (ABL != 1) kout[(int64_t)(4 * r) * Bcap] = v[r];
+    macc = fma(al[r], v[r], macc);
+  }
+}
+
+// The A fragments and alpha of a wave's j-tiles (loaded by the caller: where in its instruction stream is its choice).
+template <int KS, int JTW>
+struct KstarFrags {
+  double a[JTW][KS];
+  kd4 al[JTW];
+};
+template <int KS, int JTW, int NBW>
+__device__ __forceinline__ void kstar_load_frags(KstarFrags<KS, JTW> &f, const double *__restrict__ Xa,
+                                                 const double *__restrict__ alf, int64_t jt0, int lane, int wave) {
+  constexpr int WC = 4 / NBW, WR = 4 / WC;
+  const int wr = wave % WR, lq = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[r] += c;
-      if (RAGGED && row0 + 4 * r >= N) v[r] = 0.0;         // padded training rows contribute nothing
-      if (ABL != 1) krow[(int64_t)(4 * r) * Bcap + bt * 16] = v[r];
-      macc[bt] = fma(al[r], v[r], macc[bt]);
-    }
+  for (int jj = 0; jj < JTW; ++jj) {
+    const int64_t jt = jt0 + wr * JTW + jj;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) f.a[jj][s] = Xa[(jt * KS + s) * 64 + lane];
+    f.al[jj] = *reinterpret_cast<const kd4 *>(alf + jt * 16 + lq * 4);
   }
 }
 
 // One workgroup (4 waves) of the cross-kernel: WR JTW j-tiles of 16 training rows x 64 query columns.
 //   wave w: wave row wr = w % WR, wave column wc = w / WR (WC = 4 / NBW, WR = 4 / WC);
 //           j-tiles jt0 + wr JTW .. + JTW - 1, b-tiles wc NBW .. + NBW - 1
-//   NBW = 4, JTW = 2: 128 rows per workgroup (large batches);  NBW = 2, JTW = 1: 32 rows (small batches)
+//   NBW = 2, JTW = 2: 64 rows per workgroup (large batches);  NBW = 2, JTW = 1: 32 rows (small batches)
 // s_q: LDS [64][8] raw (unscaled, zero-padded) query rows of the workgroup's columns; s_red: LDS [4][64].
 // Returns, in wave 0, the workgroup's partial mean  sum_j alpha_j K[j][b]  of column b = lane (NaN if the query has one).
 template <int KIND, int KS, int JTW, int NBW, int TB, int ABL = 0>
 __device__ __forceinline__ double kstar_mfma_block(const double *s_q, const double *s_tab, double *s_red,
-                                                   const double *__restrict__ Xa, const double *__restrict__ alf,
+                                                   const KstarFrags<KS, JTW> &fr,
                                                    const double *__restrict__ qsc, const double *__restrict__ qof,
                                                    double c, int d, int64_t jt0, int64_t N, double *__restrict__ ks,
                                                    int64_t Bcap, const KstarDirect &dir, int lane, int wave) {
   constexpr int WC = 4 / NBW, WR = 4 / WC;
   const int wr = wave % WR, wc = wave / WR;
   const int ln = lane & 15, lq = lane >> 4;
-  // the A fragments and alpha of the wave's j-tiles first: their latency overlaps the query side below
-  double a[JTW][KS];
-  kd4 al[JTW];
-#pragma unroll
-  for (int jj = 0; jj < JTW; ++jj) {
-    const int64_t jt = jt0 + wr * JTW + jj;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) a[jj][s] = Xa[(jt * KS + s) * 64 + lane];
-    al[jj] = *reinterpret_cast<const kd4 *>(alf + jt * 16 + lq * 4);
-  }
   // B fragments: this lane's two (three) components of its NBW queries, scaled and centred; |q'|^2 per query
   double bq[NBW][KS], hq[NBW];
   double sc[KS], of[KS];
@@ -241,16 +254,20 @@ __device__ __forceinline__ double kstar_mfma_block(const double *s_q, const doub
 #pragma unroll
   for (int bt = 0; bt < NBW; ++bt) macc[bt] = 0.0;
   double *kcol = ks + (int64_t)lq * Bcap + wc * NBW * 16 + ln;
+  // the wave's JTW x NBW tiles as one software-pipelined sequence: the MFMAs of tile i + 1 are issued before the
+  // kernel values of tile i are formed, so their latency (and the wait states in front of the first read of an
+  // accumulator) hides behind ~90 vector instructions instead of stalling the wave
+  constexpr int NT = JTW * NBW;
+  kd4 acc = kstar_tile_product<KS>(fr.a[0], bq[0]);
 #pragma unroll
-  for (int jj = 0; jj < JTW; ++jj) {
+  for (int i = 0; i < NT; ++i) {
+    const int jj = i / NBW, bt = i % NBW;
+    kd4 nxt = acc;
+    if (i + 1 < NT) nxt = kstar_tile_product<KS>(fr.a[(i + 1) / NBW], bq[(i + 1) % NBW]);
     const int64_t jt = jt0 + wr * JTW + jj;
-    double *krow = kcol + jt * 16 * Bcap;
-    if ((jt + 1) * 16 > N)      // wave-uniform: only the tiles that hold padded rows
-      kstar_mfma_jtile<KIND, KS, NBW, TB, true, ABL>(a[jj], bq, hq, al[jj], c, s_tab, jt * 16 + lq, N, krow, Bcap, macc, dir,
-                                                s_q, wc * NBW * 16 + ln);
-    else
-      kstar_mfma_jtile<KIND, KS, NBW, TB, false, ABL>(a[jj], bq, hq, al[jj], c, s_tab, jt * 16 + lq, N, krow, Bcap, macc, dir,
-                                                s_q, wc * NBW * 16 + ln);
+    kstar_tile_finish<KIND, TB, ABL>(acc, hq[bt], fr.al[jj], c, s_tab, (jt + 1) * 16 > N, jt * 16 + lq, N,
+                                     kcol + jt * 16 * Bcap + bt * 16, Bcap, macc[bt], dir, s_q, wc * NBW * 16 + ln + bt * 16);
+    acc = nxt;
   }
   // column sums: over the four lane groups, then over the wave rows in a fixed order
 #pragma unroll

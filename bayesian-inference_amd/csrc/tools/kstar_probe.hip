@@ -86,21 +86,48 @@ __global__ __launch_bounds__(256, 2) void kstar_mfma(const double *Xq, const dou
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int p = blockIdx.z, chunk = blockIdx.y, nchunk = gridDim.y;
   const int64_t b0 = (int64_t)blockIdx.x * 64;
+  const int64_t njt = Npad / 16;
+  KstarFrags<KS, JTW> fr;
+  kstar_load_frags<KS, JTW, NBW>(fr, Xa + (int64_t)p * njt * KS * 64, alf + (int64_t)p * njt * 16, (int64_t)chunk * JT, lane, wave);
   for (int i = threadIdx.x; i < (1 << TB); i += 256) s_tab[i] = tab[i];
   reinterpret_cast<d2 *>(s_q)[threadIdx.x] = reinterpret_cast<const d2 *>(Xq + b0 * 8)[threadIdx.x];
   __syncthreads();
-  const int64_t njt = Npad / 16;
   const double sum = kstar_mfma_block<KIND, KS, JTW, NBW, TB, ABL>(
-      s_q, s_tab, s_red, Xa + (int64_t)p * njt * KS * 64, alf + (int64_t)p * njt * 16, qsc + p * 4 * KS, qof + p * 4 * KS, c, d,
+      s_q, s_tab, s_red, fr, qsc + p * 4 * KS, qof + p * 4 * KS, c, d,
       (int64_t)chunk * JT, N, KSo + (int64_t)p * Npad * Bcap + b0, Bcap, KstarDirect{Xs + (int64_t)p * Npad * 8, inv + p * 8}, lane, wave);
   if (wave == 0) mean_part[((b0 + lane) * gridDim.z + p) * nchunk + chunk] = sum;
+}
+
+// stands in for the triangular GEMM between two cross-kernel launches of the sampler: streams K_*^T and a W-sized
+// buffer through every XCD's L2 (kstar_probe ... mix; kernel times from rocprofv3 --kernel-trace --stats)
+__global__ __launch_bounds__(256) void reader_kernel(const double *a, size_t na, const double *b, size_t nb, double *sink) {
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na; i += (size_t)gridDim.x * 256) s += a[i];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (size_t)gridDim.x * 256) s += b[i];
+  if (s == 1.2345e300) *sink = s;
+}
+
+// ~95 us of back-to-back f64 MFMAs on every SIMD (2 waves each): the power state the triangular GEMM leaves behind
+__global__ __launch_bounds__(512) void mfma_burn_kernel(double *sink, int iters) {
+  typedef double v4 __attribute__((ext_vector_type(4)));
+  v4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+  }
+  const double s = a0[0] + a1[1] + a2[2] + a3[3];
+  if (s == 1.2345e300) *sink = s;
 }
 
 int main(int argc, char **argv) {
   const int64_t N = argc > 1 ? atoll(argv[1]) : 1000, B = argc > 2 ? atoll(argv[2]) : 512;
   const int64_t k = argc > 3 ? atoll(argv[3]) : 10, d = argc > 4 ? atoll(argv[4]) : 6;
   const int kind = argc > 5 ? atoi(argv[5]) : 0;
-  const int64_t Npad = (N + 127) / 128 * 128, Bcap = (B + 127) / 128 * 128;
+  const int64_t Npad = (N + 127) / 128 * 128, Bcols = (B + 127) / 128 * 128;
+  const int64_t Bcap = getenv("PROBE_BCAP") ? atoll(getenv("PROBE_BCAP")) : Bcols;   // row stride of K_*^T (>= the columns written)
   const double lo[8] = {0.1, 1, 0.0067, 0.0067, 0, 0.05, 0.3, 2}, hi[8] = {0.5, 10, 10, 10, 1.5, 100, 0.9, 7};
   unsigned long long s = 88172645463325252ull;
   auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) / 9007199254740992.0; };
@@ -175,7 +202,7 @@ int main(int argc, char **argv) {
   const bool small = B <= 256;
   dim3 blk(256);
   {
-    dim3 grid((unsigned)(Bcap / 64), (unsigned)(Npad / (small ? 32 : 128)), (unsigned)k);
+    dim3 grid((unsigned)(Bcols / 64), (unsigned)(Npad / (small ? 32 : 128)), (unsigned)k);
 #define LV(KD) if (small) hipLaunchKernelGGL((kstar_valu<KD, 8>), grid, blk, 0, 0, dQ, dXs, dinv, dalp, KS0, mp0, N, Npad, Bcap, cval); \
                else hipLaunchKernelGGL((kstar_valu<KD, 32>), grid, blk, 0, 0, dQ, dXs, dinv, dalp, KS0, mp0, N, Npad, Bcap, cval)
     timeit("vector-ALU distance (round 3)", [&]() { switch (kind) { case 0: LV(0); break; case 1: LV(1); break; case 2: LV(2); break; default: LV(3); } });
@@ -187,7 +214,7 @@ int main(int argc, char **argv) {
     build_kstar_operands(N, Npad, d, k, kind, X.data(), ls.data(), al.data(), h, TBV);                                      \
     double *dXa = up(h.Xa), *dalf = up(h.alf), *dqsc = up(h.qsc), *dqof = up(h.qof), *dtab = up(h.tab);                      \
     constexpr int JT = (4 / (4 / NBWV)) * JTWV;                                                                             \
-    dim3 grid((unsigned)(Bcap / 64), (unsigned)(Npad / (16 * JT)), (unsigned)k);                                            \
+    dim3 grid((unsigned)(Bcols / 64), (unsigned)(Npad / (16 * JT)), (unsigned)k);                                            \
     auto go = [&]() {                                                                                                       \
       if (h.ksteps == 2) { switch (kind) {                                                                                  \
         case 0: hipLaunchKernelGGL((kstar_mfma<0, 2, JTWV, NBWV, TBV>), grid, blk, 0, 0, dQ, dXa, dalf, dqsc, dqof, dtab, KS1, mp1, N, Npad, Bcap, cval, (int)d, dXs, dinv); break; \
@@ -205,10 +232,30 @@ int main(int argc, char **argv) {
     KstarHost h;
     build_kstar_operands(N, Npad, d, k, kind, X.data(), ls.data(), al.data(), h, 6);
     double *dXa = up(h.Xa), *dalf = up(h.alf), *dqsc = up(h.qsc), *dqof = up(h.qof), *dtab = up(h.tab);
-    dim3 grid((unsigned)(Bcap / 64), (unsigned)(Npad / 64), (unsigned)k);
+    dim3 grid((unsigned)(Bcols / 64), (unsigned)(Npad / 64), (unsigned)k);
     timeit("ablation: 2 x 2 waves, no stores", [&]() { hipLaunchKernelGGL((kstar_mfma<0, 2, 2, 2, 6, 1>), grid, blk, 0, 0, dQ, dXa, dalf, dqsc, dqof, dtab, KS1, mp1, N, Npad, Bcap, cval, (int)d, dXs, dinv); });
     timeit("ablation: 2 x 2 waves, no exponential", [&]() { hipLaunchKernelGGL((kstar_mfma<0, 2, 2, 2, 6, 2>), grid, blk, 0, 0, dQ, dXa, dalf, dqsc, dqof, dtab, KS1, mp1, N, Npad, Bcap, cval, (int)d, dXs, dinv); });
     timeit("hipMemsetAsync of the K_* workspace", [&]() { (void)hipMemsetAsync(KS1, 0, 8 * nks, 0); });
+  }
+  if (argc > 6 && kind == 0 && d <= 7) {
+    // mode "mix": the sampler's rhythm, [cross-kernel, reader] x 300, for rocprofv3
+    const int st_mode = atoi(argv[6]);    // 0 plain stores, 1 nontemporal
+    KstarHost h;
+    build_kstar_operands(N, Npad, d, k, kind, X.data(), ls.data(), al.data(), h, 6);
+    double *dXa = up(h.Xa), *dalf = up(h.alf), *dqsc = up(h.qsc), *dqof = up(h.qof), *dtab = up(h.tab);
+    dim3 grid((unsigned)(Bcols / 64), (unsigned)(Npad / 64), (unsigned)k);
+    double *Wbuf, *sink; const size_t nw = (size_t)k * Npad * Npad;
+    CK(hipMalloc(&Wbuf, 8 * nw)); CK(hipMemset(Wbuf, 0, 8 * nw)); CK(hipMalloc(&sink, 8));
+    for (int i = 0; i < 600; ++i) {
+      if (st_mode % 10 == 0) hipLaunchKernelGGL((kstar_mfma<0, 2, 2, 2, 6, 0>), grid, blk, 0, 0, dQ, dXa, dalf, dqsc, dqof, dtab, KS1, mp1, N, Npad, Bcap, cval, (int)d, dXs, dinv);
+      else if (st_mode % 10 == 2) hipLaunchKernelGGL((kstar_mfma<0, 2, 2, 2, 6, 2>), grid, blk, 0, 0, dQ, dXa, dalf, dqsc, dqof, dtab, KS1, mp1, N, Npad, Bcap, cval, (int)d, dXs, dinv);
+      else hipLaunchKernelGGL((kstar_mfma<0, 2, 2, 2, 6, 3>), grid, blk, 0, 0, dQ, dXa, dalf, dqsc, dqof, dtab, KS1, mp1, N, Npad, Bcap, cval, (int)d, dXs, dinv);
+      if (st_mode < 10) hipLaunchKernelGGL(reader_kernel, dim3(2048), blk, 0, 0, KS1, nks, Wbuf, nw, sink);
+      else hipLaunchKernelGGL(mfma_burn_kernel, dim3(256), dim3(512), 0, 0, sink, 800);
+    }
+    CK(hipDeviceSynchronize());
+    printf("mix done (store mode %d)\n", st_mode);
+    return 0;
   }
   RUN(5, 2, 4, "matrix cores, table 32, 128 rows / wg");
   RUN(6, 2, 4, "matrix cores, table 64, 128 rows / wg");
