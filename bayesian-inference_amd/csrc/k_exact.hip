@@ -402,22 +402,43 @@ __global__ __launch_bounds__(1024 / CBW) void predict_cov_mfma_kernel(
   if (DBG >= 2 && smem[lane] + dbg_acc == -1.2345e300) pend_dst[0] = 0.0;
 }
 
-// central value (ref: emulation.py:508-509) for the matrix-core writer: cv[b][g] = (sum_p mean[b][p] S[p][g]) s_g + mean_g
+// central value (ref: emulation.py:508-509) for the matrix-core writer: cv[b][g] = (sum_p mean[b][p] S[p][g]) s_g + mean_g.
+// One workgroup per CV_NB samples: their k GP means are summed from the partial sums ONCE (CV_NB k threads, contiguous
+// reads) into LDS, then every thread forms its features' values from them.  Round 3's form had every thread of every
+// workgroup re-sum all k x nchunk partials of its samples: 33 us for 4 MB of output.
+constexpr int CV_NB = 4;
 __global__ __launch_bounds__(256) void central_value_kernel(GpParts gp, const double *__restrict__ comp,
                                                             const double *__restrict__ smean, const double *__restrict__ sscale,
                                                             double *__restrict__ cv, int64_t B, int F, int k) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= F) return;
-  double cg[16];
+  __shared__ double s_mu[CV_NB][16];
+  const int64_t b0 = (int64_t)blockIdx.x * CV_NB;
+  if ((int)threadIdx.x < CV_NB * 16) {
+    const int ib = threadIdx.x >> 4, p = threadIdx.x & 15;
+    s_mu[ib][p] = (b0 + ib < B && p < k) ? gp_mean_of(gp, b0 + ib, p, k) : 0.0;
+  }
+  // this thread's features: their components, scale and mean (independent of the sums above: loaded meanwhile)
+  double cg[2][16], sg[2], mg[2];
 #pragma unroll
-  for (int p = 0; p < 16; ++p) cg[p] = p < k ? comp[(int64_t)p * F + g] : 0.0;
-  const double sg = sscale[g], mg = smean[g];
-  for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
-    double sacc = 0.0;
+  for (int t = 0; t < 2; ++t) {
+    const int g = threadIdx.x + 256 * t;
+    sg[t] = g < F ? sscale[g] : 0.0;
+    mg[t] = g < F ? smean[g] : 0.0;
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
-      if (p < k) sacc = fma(gp_mean_of(gp, b, p, k), cg[p], sacc);
-    cv[b * F + g] = sacc * sg + mg;
+    for (int p = 0; p < 16; ++p) cg[t][p] = (g < F && p < k) ? comp[(int64_t)p * F + g] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ib = 0; ib < CV_NB; ++ib) {
+    if (b0 + ib >= B) break;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int g = threadIdx.x + 256 * t;
+      double sacc = 0.0;
+#pragma unroll
+      for (int p = 0; p < 16; ++p)
+        if (p < k) sacc = fma(s_mu[ib][p], cg[t][p], sacc);
+      if (g < F) cv[(b0 + ib) * F + g] = sacc * sg[t] + mg[t];
+    }
   }
 }
 
@@ -455,6 +476,9 @@ int launch_predict_full(gpemu_model *m, int64_t B, double n_div, double *dcv, do
     if (pm_cbw == 2) GP_LAUNCH_PM2(KSV, 2, DB);                                                                    \
     else GP_LAUNCH_PM2(KSV, 1, DB);                                                                                \
   } while (0)
+    // the central values first (a few us, their inputs -- the GP stage's partial sums -- still in cache), then the writer
+    hipLaunchKernelGGL(central_value_kernel, dim3((unsigned)((B + CV_NB - 1) / CV_NB)), dim3(256), 0, st, parts, m->comp,
+                       m->smean, m->sscale, dcv, B, F, k);
     static const int pm_dbg = getenv("GPEMU_PM_DBG") ? atoi(getenv("GPEMU_PM_DBG")) : 0;
     if (pm_dbg == 1) GP_LAUNCH_PM(3, 1);
     else if (pm_dbg == 2) GP_LAUNCH_PM(3, 2);
@@ -466,8 +490,6 @@ int launch_predict_full(gpemu_model *m, int64_t B, double n_div, double *dcv, do
     else GP_LAUNCH_PM(4, 0);
 #undef GP_LAUNCH_PM2
 #undef GP_LAUNCH_PM
-    hipLaunchKernelGGL(central_value_kernel, dim3((unsigned)((F + 255) / 256), (unsigned)std::min<int64_t>(B, 256)), dim3(256),
-                       0, st, parts, m->comp, m->smean, m->sscale, dcv, B, F, k);
     GP_HIP(hipGetLastError());
     return GPEMU_OK;
   }

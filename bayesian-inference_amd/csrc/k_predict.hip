@@ -37,7 +37,8 @@ struct KstarArgs {
   int64_t N, Npad, Bcap;
   int has_const, d;
   int k, nchunk, ncb64;                // grid = ncb64 * nchunk * k workgroups (1-D)
-  int gper;                            // > 0: XCD-aware placement, gper (PC, 128-column block) groups per XCD
+  int gper, ncbp;                      // gper > 0: XCD-aware placement, gper of the k ncbp (PC, 128-column block) groups
+                                       // of each piece of ncbp column blocks per XCD
 };
 
 template <int KIND, int KS, int JTW, int NBW>
@@ -56,12 +57,15 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(KstarArgs ka, ProposeArgs
   int p, chunk, cb;
   const int nchunk = ka.nchunk;
   if (ka.gper > 0) {
+    // the GEMM runs one launch per piece of ncbp 128-column blocks (launch_trmm_vsq: at most 512 columns each), every
+    // launch dealing its k ncbp groups to the XCDs in (PC, column block) order, gper per XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int half = slot & 1, rest = slot >> 1;
     chunk = rest % nchunk;
-    const int g = xcd * ka.gper + rest / nchunk, ncb128 = ka.ncb64 >> 1;
-    p = g / ncb128;
-    cb = 2 * (g - p * ncb128) + half;
+    const int rest2 = rest / nchunk;
+    const int piece = rest2 / ka.gper, g = xcd * ka.gper + rest2 % ka.gper;
+    p = g / ka.ncbp;
+    cb = 2 * (piece * ka.ncbp + g % ka.ncbp) + half;
   } else {
     cb = blockIdx.x % ka.ncb64;
     const int rest = blockIdx.x / ka.ncb64;
@@ -120,6 +124,19 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(KstarArgs ka, ProposeArgs
   if (wave == 0) ka.mean_part[(b * ka.k + p) * nchunk + chunk] = sum;
 }
 
+// Columns per launch of the large-batch triangular GEMM.  More than 512 columns (emulation.predict on a large batch) go
+// one launch per 512 columns: K_*^T of 1024 columns is 82 MB, and with W_p it no longer streams through the XCDs' L2s the
+// way the 512-column schedule is built for (one launch of 1024 columns takes 228 us, two of 512 take 2 x 93 us).  Only
+// when the pieces are equally wide (one cached schedule); else, and for stacked chains, the whole batch in one launch.
+static int64_t trmm_piece_cols(const gpemu_model *m, int64_t B) {
+  constexpr int64_t max_cols = 512;
+  if (m->variant_B == 0 && B > max_cols) {
+    const int64_t n = (B + max_cols - 1) / max_cols, per = round_up((B + n - 1) / n, TILE), last = B - (n - 1) * per;
+    if (last > 0 && round_up(last, TILE) == per) return per;
+  }
+  return round_up(B, TILE);
+}
+
 int launch_kstar(gpemu_model *m, int64_t B, double *dXq, hipStream_t st, const ProposeArgs *pa) {
   const ProposeArgs pargs = pa ? *pa : ProposeArgs();
   // only the column tiles that hold real queries; without a proposal / raw rows, the rows of dXq up to
@@ -134,13 +151,16 @@ int launch_kstar(gpemu_model *m, int64_t B, double *dXq, hipStream_t st, const P
   const int64_t ncols = (B <= 64) ? 64 : round_up(B, TILE);
   const int ncb64 = (int)(ncols / 64);
   dim3 grid((unsigned)(ncb64 * w.cur_nchunk * (int)m->k)), block(256);
-  // XCD-aware placement where the large-batch GEMM's schedule is (whole groups per XCD: build_trmm_schedule)
-  const int ngroups = (int)m->k * (ncb64 / 2);
-  const int gper = (B > 128 && ncb64 % 2 == 0 && ngroups % 8 == 0 && m->num_cu % 8 == 0) ? ngroups / 8 : 0;
+  // XCD-aware placement where the large-batch GEMM's schedule is (whole groups per XCD: build_trmm_schedule), piece by
+  // piece of the columns as launch_trmm_vsq will cut them
+  const int ncbp = (int)(trmm_piece_cols(m, B) / TILE);
+  const int ngroups = (int)m->k * ncbp;
+  const bool xcd_aware = Bv > 128 && ncb64 % 2 == 0 && (ncb64 / 2) % ncbp == 0 && ngroups % 8 == 0 && m->num_cu % 8 == 0;
+  const int gper = xcd_aware ? ngroups / 8 : 0;
   const int pe0 = prof_mark(m, st);
   const int kind = kstar_kind(m);
   KstarArgs ka{dXq, m->Xa, m->alf, m->qsc, m->qof, m->etab, m->constv, m->Xs, m->inv_ls, w.KS, w.mean_part,
-               m->N, m->Npad, w.Bcap, m->has_const, (int)m->d, (int)m->k, w.cur_nchunk, ncb64, gper};
+               m->N, m->Npad, w.Bcap, m->has_const, (int)m->d, (int)m->k, w.cur_nchunk, ncb64, gper, ncbp};
 #define GP_LAUNCH_KSTAR2(KD, KSV)                                                                       \
   do {                                                                                                  \
     if (small) hipLaunchKernelGGL((kstar_kernel<KD, KSV, 1, 2>), grid, block, 0, st, ka, pargs);        \
@@ -460,25 +480,18 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
   Workspace &w = m->ws;
   constexpr int64_t smallb_max = 128;
   const int64_t Bv = m->variant_B > 0 ? m->variant_B : B;   // a chain stacked with others is evaluated as it would be alone
-  // More than 512 columns (emulation.predict on a large batch): one launch per 512 columns.  K_*^T of 1024 columns is
-  // 82 MB, and with W_p it no longer streams through the XCDs' L2s the way the 512-column schedule is built for: one
-  // launch of 1024 columns takes 228 us, two of 512 take 2 x 93 us.  Only when the pieces are equally wide (one
-  // cached schedule); the column partials of a piece land where the single launch would put them.
-  constexpr int64_t max_cols = 512;
-  if (m->variant_B == 0 && B > max_cols) {
-    const int64_t n = (B + max_cols - 1) / max_cols, per = round_up((B + n - 1) / n, TILE), last = B - (n - 1) * per;
-    if (last > 0 && round_up(last, TILE) == per) {
-      double *const KS0 = w.KS, *const V0 = w.vsq_part;
-      int rc = GPEMU_OK;
-      for (int64_t c0 = 0; c0 < B && rc == GPEMU_OK; c0 += per) {
-        w.KS = KS0 + c0;
-        w.vsq_part = V0 + c0 * m->k * m->vsq_nrb;
-        rc = launch_trmm_vsq(m, std::min(per, B - c0), st);
-      }
-      w.KS = KS0;
-      w.vsq_part = V0;
-      return rc;
+  const int64_t per = trmm_piece_cols(m, B);
+  if (per < round_up(B, TILE)) {     // one launch per piece; the column partials of a piece land where a single launch would put them
+    double *const KS0 = w.KS, *const V0 = w.vsq_part;
+    int rc = GPEMU_OK;
+    for (int64_t c0 = 0; c0 < B && rc == GPEMU_OK; c0 += per) {
+      w.KS = KS0 + c0;
+      w.vsq_part = V0 + c0 * m->k * m->vsq_nrb;
+      rc = launch_trmm_vsq(m, std::min(per, B - c0), st);
     }
+    w.KS = KS0;
+    w.vsq_part = V0;
+    return rc;
   }
   if (Bv <= smallb_max) {  // small batch: persistent 32 x 32 items, operands straight into registers
     const int rc = launch_trmm_vsq_small(m, B, st);
