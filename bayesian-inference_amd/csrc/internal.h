@@ -180,6 +180,8 @@ static inline int kstar_kind(const gpemu_model *m) {
 // dXq_padded is read, or -- with pa->enabled -- written (rows [0, round_up(B, 128))) by the kernel
 int launch_kstar(gpemu_model *m, int64_t B, double *dXq_padded, hipStream_t st, const ProposeArgs *pa = nullptr);
 int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st);
+int small_trmm_xcd_of(const gpemu_model *m, int64_t B, int p, int64_t col);
+int trmm_xcd_of(const gpemu_model *m, int64_t B, int p, int64_t col);   // XCD that reads K_*^T rows (p, col) in launch_trmm_vsq(m, B); -1: any
 int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st);   // B <= 128; GPEMU_ERR_UNSUPPORTED if the shape does not fit
 int launch_reduce_mean_var(gpemu_model *m, int64_t B, double *dmean, double *dvar, hipStream_t st);
 int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq_padded, double *dout,

@@ -137,6 +137,16 @@ static int64_t trmm_piece_cols(const gpemu_model *m, int64_t B) {
   return round_up(B, TILE);
 }
 
+// XCD whose workers will read rows (PC p, column col) of K_*^T in launch_trmm_vsq(m, B), or -1 if that launch places
+// nothing XCD-aware: mirrors build_trmm_schedule / build_small_schedule (k_trmm_small.hip)
+int trmm_xcd_of(const gpemu_model *m, int64_t B, int p, int64_t col) {
+  const int64_t Bv = m->variant_B > 0 ? m->variant_B : B;
+  if (Bv <= 128) return small_trmm_xcd_of(m, B, p, col);
+  const int ncbp = (int)(trmm_piece_cols(m, B) / TILE), ngroups = (int)m->k * ncbp;
+  if (ngroups % 8 != 0 || m->num_cu % 8 != 0) return -1;
+  return (p * ncbp + (int)(col / TILE) % ncbp) / (ngroups / 8);
+}
+
 int launch_kstar(gpemu_model *m, int64_t B, double *dXq, hipStream_t st, const ProposeArgs *pa) {
   const ProposeArgs pargs = pa ? *pa : ProposeArgs();
   // only the column tiles that hold real queries; without a proposal / raw rows, the rows of dXq up to

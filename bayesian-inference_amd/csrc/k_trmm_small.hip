@@ -238,6 +238,17 @@ static void build_small_schedule(const gpemu_model *m, int ncb, std::vector<Smal
   }
 }
 
+// XCD on which build_small_schedule places the items of (PC p, the 32-column block holding column col), or -1 (the
+// left-over groups, or no XCD-aware placement): the cross-kernel writes those rows from the same XCD (k_front.hip)
+int small_trmm_xcd_of(const gpemu_model *m, int64_t B, int p, int64_t col) {
+  const int nrb = (int)(m->Npad / ST_M), k = (int)m->k, ncb = (int)(round_up(B, ST_N) / ST_N);
+  const int64_t nitems = (int64_t)nrb * k * ncb;
+  const int ncu = m->num_cu, nxcd = 8, ngroups = k * ncb;
+  if (nitems < ncu || ncu % nxcd != 0 || ngroups < nxcd) return -1;
+  const int gper = ngroups / nxcd, g = p * ncb + (int)(col / ST_N);
+  return g < gper * nxcd ? g / gper : -1;
+}
+
 // returns GPEMU_ERR_UNSUPPORTED (without setting an error) when the shape needs more items per worker than the
 // kernel holds; the caller then uses the general small-batch kernel
 int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st) {

@@ -62,6 +62,9 @@ struct gpemu_sampler {
   int peer_world = 0, peer_rank = 0;
   int device_share = 1;        // ranks of the job whose samplers run on this device (gpemu_sampler_peer_share)
   uint64_t front_count = 0;    // fused launches so far (gather slot and buffer parity)
+  // XCD-aware order of the front kernel's cross-kernel workgroups, per (share size, group): device tables (k_front.hip)
+  struct FrontPerm { int64_t cnt; int group, wg0; int *dperm; };
+  std::vector<FrontPerm> front_perms;
   // autocorrelation estimate (k_acf.hip): scratch kept between the lag blocks of one estimate
   double *acf_part = nullptr, *acf_acf = nullptr, *acf_mean = nullptr, *acf_acf0 = nullptr;
   size_t acf_part_bytes = 0;

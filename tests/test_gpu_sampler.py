@@ -130,7 +130,7 @@ def test_c3_sampler_bookkeeping_and_statistics():
 
 
 # ---- sharded device sampler: 2 ranks on the one GPU, log-probabilities exchanged over gloo ----------
-def _sharded_worker(rank, world, port, out_dir, transport):
+def _sharded_worker(rank, world, port, out_dir, transport, W=26):
     import os
     import sys
     import torch.distributed as dist
@@ -142,7 +142,7 @@ def _sharded_worker(rank, world, port, out_dir, transport):
     g = GU.load("g1_rbf_noise")
     dm = GU.device_model(GU.group_model(g))
     dm.likelihood_setup(g["y_exp"], g["y_err"], g["lo"], g["hi"], 1.0)
-    W = 26     # halves of 13: ragged shards
+    # W = 26: halves of 13 (ragged shards);  W = 66 at 4 / 5 ranks: shares of 9, 9, 9, 6 and 7, 7, 7, 7, 5
     ds = DeviceSampler([dm], W, seed=99)
     ds.set_state(synthetic.make_walkers(W, seed=3, lo=g["lo"], hi=g["hi"]))
     # many short back-to-back runs (9 steps in all): the exchange slots and their hand-back carry over from run to
@@ -188,6 +188,84 @@ def test_sharded_device_sampler_two_ranks_equals_single(tmp_path, transport):
     np.testing.assert_array_equal(ds.counts()[0], np.load(tmp_path / "nacc_0.npy"))
     ds.close()
     dm.close()
+
+
+@pytest.mark.parametrize("world", [4, 5])
+@pytest.mark.parametrize("transport", ["peer", "torch"])
+def test_sharded_device_sampler_many_ranks_equals_single(tmp_path, transport, world):
+    """More than two ranks (every sharded test had world = 2): 4 and 5 processes on the one GPU -- the pool
+    allows at most 6 processes on a card including this one, so the 8-way arithmetic is covered by the slice test
+    below -- with ragged shares (66 walkers: halves of 33 -> 9, 9, 9, 6 and 7, 7, 7, 7, 5), fused peer-store run and
+    per-phase run: every rank ends with the single-GPU chain, bit for bit."""
+    import os
+    import torch.multiprocessing as mp
+    from gpemu import synthetic
+    from gpemu.sampler import DeviceSampler
+    W = 66
+    port = 29800 + (os.getpid() % 1500) + 11 * world + (5 if transport == "peer" else 0)
+    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path), transport, W), nprocs=world, join=True)
+    chains = [np.load(tmp_path / f"chain_{r}.npy") for r in range(world)]
+    lps = [np.load(tmp_path / f"lp_{r}.npy") for r in range(world)]
+    for r in range(1, world):
+        np.testing.assert_array_equal(chains[0], chains[r])
+        np.testing.assert_array_equal(lps[0], lps[r])
+    g, model, dm, _ = _setup()
+    ds = DeviceSampler([dm], W, seed=99)
+    ds.set_state(synthetic.make_walkers(W, seed=3, lo=g["lo"], hi=g["hi"]))
+    ds.run(9)
+    chain, lp1 = ds.get_chain()
+    np.testing.assert_array_equal(chain, chains[0])
+    np.testing.assert_array_equal(lp1, lps[0])
+    np.testing.assert_array_equal(ds.counts()[0], np.load(tmp_path / "nacc_0.npy"))
+    ds.close()
+    dm.close()
+
+
+@pytest.mark.parametrize("world", [8, 5])
+def test_phase_api_slices_of_eight_ranks_equal_single(world):
+    """The 8-way share arithmetic (shard_bounds / the C side's share_of: ceil(n / world) per rank, the last ranks short
+    or EMPTY) through the per-phase C ABI: one process plays every rank of an 8-rank (and a 5-rank) job in turn --
+    gpemu_sampler_half_propose_eval on each rank's slice, the "all-gather" a concatenation -- and must reproduce the
+    undivided chain bit for bit.  70 walkers: halves of 35 -> 8 ranks: 5, 5, 5, 5, 5, 5, 5, 0."""
+    import ctypes as C
+    import torch
+    from gpemu import _lib, synthetic
+    from gpemu.sampler import DeviceSampler, shard_bounds
+    L = _lib.lib()
+    g, model, dm, _ = _setup()
+    W, steps = 70, 6
+    X0 = synthetic.make_walkers(W, seed=3, lo=g["lo"], hi=g["hi"])
+    ref = DeviceSampler([dm], W, seed=31)
+    ref.set_state(X0)
+    ref.run(steps)
+    cref, lref = ref.get_chain()
+    a = DeviceSampler([dm], W, seed=31)
+    a.set_state(X0)
+    dev = torch.device("cuda", a.device)
+    _lib.check(L.gpemu_sampler_reserve_chain(a._h, steps))
+    sizes = []
+    for _ in range(steps):
+        _lib.check(L.gpemu_sampler_begin_step(a._h))
+        for h in (0, 1):
+            n = a.ns[h]
+            per = shard_bounds(n, world, 0)[2]
+            full = torch.zeros(per * world, dtype=torch.float64, device=dev)
+            for r in range(world):
+                lo, hi, _ = shard_bounds(n, world, r)
+                sizes.append(hi - lo)
+                mine = torch.zeros(per, dtype=torch.float64, device=dev)
+                _lib.check(L.gpemu_sampler_half_propose_eval(a._h, h, lo, hi, C.c_void_p(mine.data_ptr())))
+                torch.cuda.synchronize()
+                full[r * per:(r + 1) * per] = mine
+            _lib.check(L.gpemu_sampler_half_accept(a._h, h, C.c_void_p(full.data_ptr()), 1))
+        _lib.check(L.gpemu_sampler_end_step(a._h, 1))
+    assert L.gpemu_sampler_check(a._h) == 0
+    assert min(sizes) == 0 if world == 8 else min(sizes) > 0          # the 8-rank job has an empty share
+    ca, la = a.get_chain()
+    # shares and the undivided half (35 proposals) are all served by the small-batch kernel family: same bits
+    np.testing.assert_array_equal(la, lref)
+    np.testing.assert_array_equal(ca, cref)
+    a.close(); ref.close(); dm.close()
 
 
 def _rccl_worker(rank, port, out_dir):
