@@ -154,10 +154,18 @@ def test_fit_emulator_group_end_to_end_c2(tmp_path):
     np.testing.assert_array_equal(res["PCA"]["pca"].flip_argmax_[:5], g["flip_argmax"][:5])
     assert relerr(res["PCA"]["Y_pca_truncated"], g["Y_pca_truncated"]) < 1e-9
     assert relerr(res["PCA"]["Y_reconstructed_truncated_unscaled"], g["Y_reconstructed_truncated_unscaled"]) < 1e-9
-    for i, e in enumerate(res["emulators"]):
-        assert abs(e.log_marginal_likelihood_value_ - g["lml_value"][i]) < 1e-4 * abs(g["lml_value"][i])
-        assert e.log_marginal_likelihood_value_ >= g["lml_value"][i] - 1e-5 * abs(g["lml_value"][i])
+    agree, dth = DU.check_fit_against_reference(res["emulators"], g["theta"], g["lml_value"], "C2 fit (G2)")
     cu = emulation.compute_emulator_group_cov_unexplained(cfg, res)
     assert relerr(cu, g["cov_unexplained"]) < 1e-9
-    p = emulation.predict_emulation_group(g["Xq"], res, cfg, emulator_group_cov_unexplained=cu)
-    assert relerr(p["central_value"], g["batch_central_value"]) < 2e-3
+    # per GP: where the optimiser stopped at the reference's theta, that PC's predictive mean / variance at 1e-6
+    Xq = g["Xq"]
+    for i, e in enumerate(res["emulators"]):
+        if agree[i]:
+            m, sd = e.predict(Xq, return_std=True)
+            assert np.max(np.abs(m - g["gp_mean"][:, i])) < 1e-6 * max(1.0, np.max(np.abs(g["gp_mean"][:, i])))
+            assert np.max(np.abs(sd ** 2 - g["gp_var"][:, i])) < 1e-6 * max(1.0, np.max(np.abs(g["gp_var"][:, i])))
+    p = emulation.predict_emulation_group(Xq, res, cfg, emulator_group_cov_unexplained=cu)
+    nh = g["batch_cov_head"].shape[0]
+    tol = DU.prediction_tolerance(agree, dth)       # 1e-6 when every GP is at the reference's optimum
+    assert relerr(p["central_value"], g["batch_central_value"]) < tol
+    assert relerr(p["cov"][:nh], g["batch_cov_head"]) < tol
