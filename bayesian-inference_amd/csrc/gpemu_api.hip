@@ -171,6 +171,17 @@ int gpemu_device_bus_id(int device, char *buf, int64_t buflen) {
   return GPEMU_OK;
 }
 
+int gpemu_device_memory(int device, int64_t *free_bytes, int64_t *total_bytes) {
+  GP_TRY(check_device(device));
+  GP_ARG(free_bytes && total_bytes, "null pointer");
+  GP_HIP(hipSetDevice(device));
+  size_t f = 0, t = 0;
+  GP_HIP(hipMemGetInfo(&f, &t));
+  *free_bytes = (int64_t)f;
+  *total_bytes = (int64_t)t;
+  return GPEMU_OK;
+}
+
 int gpemu_model_create(gpemu_model **out, int device, int64_t N, int64_t d, int64_t F, int64_t k,
                        int kernel_kind, double nu, int has_const, int has_noise,
                        const double *X_train, const double *ls, const double *constv,

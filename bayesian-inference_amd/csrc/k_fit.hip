@@ -543,6 +543,12 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
     return launch_gemm(u, false, false, nb, st);
   };
   bool side_pending = false;
+  // an early return (a failed launch, a HIP error) with a side update in flight: the caller may reuse or free A at once,
+  // so the side stream is drained first; the regular exit clears the flag after making `st` wait for it
+  struct SideDrain {
+    const CholOverlap *ov; const bool &pending;
+    ~SideDrain() { if (pending && ov && ov->side) (void)hipStreamSynchronize(ov->side); }
+  } side_drain{ov, side_pending};
   // one launch per panel (chol_panel_kernel) where the caller provides its flags and the strips of all problems fit on
   // the chip a few times over; GPEMU_CHOL_PANEL=0: the three-launch steps (same bits)
   const int panel_on = getenv("GPEMU_CHOL_PANEL") ? atoi(getenv("GPEMU_CHOL_PANEL")) : 1;      // read per call (tests)
@@ -611,6 +617,7 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
     }
   }
   if (side_pending) GP_HIP(hipStreamWaitEvent(st, ov->rest_done, 0));
+  side_pending = false;
   return GPEMU_OK;
 }
 

@@ -67,8 +67,8 @@ struct gpemu_sampler {
   std::vector<FrontPerm> front_perms;
   // autocorrelation estimate (k_acf.hip): scratch kept between the lag blocks of one estimate
   double *acf_part = nullptr, *acf_acf = nullptr, *acf_mean = nullptr, *acf_acf0 = nullptr;
-  size_t acf_part_bytes = 0;
-  int64_t acf_first = -1, acf_n = -1;
+  size_t acf_part_bytes = 0, acf_acf_bytes = 0, acf_mean_bytes = 0;   // capacity of acf_part / acf_acf / acf_mean + acf_acf0
+  int64_t acf_first = -1, acf_n = -1, acf_w0 = -1, acf_nw = -1;       // the estimate the scratch belongs to
 };
 
 namespace gpemu {

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "gpemu_device_count": (C.c_int, []),
     "gpemu_device_name": (C.c_int, [C.c_int, C.c_char_p, c_i64]),
     "gpemu_device_bus_id": (C.c_int, [C.c_int, C.c_char_p, c_i64]),
+    "gpemu_device_memory": (C.c_int, [C.c_int, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "gpemu_model_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, c_i64, c_i64, c_i64, c_i64,
                                      C.c_int, C.c_double, C.c_int, C.c_int] + [C.c_void_p] * 10),
     "gpemu_model_destroy": (C.c_int, [C.c_void_p]),
@@ -175,6 +176,18 @@ def require_device():
     if n <= 0:
         raise GpemuError(-3, "no HIP device visible; libgpemu has no CPU implementation")
     return n
+
+
+def device_free_bytes(device=None):
+    """Free device memory in bytes (hipMemGetInfo), or None where it cannot be asked (no device: the caller's own
+    limits apply and the compute call that follows fails loudly)."""
+    try:
+        free, total = c_i64(0), c_i64(0)
+        if lib().gpemu_device_memory(int(resolve_device(device)), C.byref(free), C.byref(total)) != 0:
+            return None
+        return int(free.value)
+    except Exception:
+        return None
 
 
 def as_f64(a, shape=None):

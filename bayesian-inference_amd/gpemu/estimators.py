@@ -19,6 +19,7 @@ import numpy as np
 
 logger = logging.getLogger(__name__)
 
+from . import _lib
 from . import fit as _fit
 from .model import DeviceModel
 
@@ -423,7 +424,7 @@ class _LbfgsbRun:
         return 1 if (self.nfev > self.maxfun or self.nit >= self.maxiter) else 2
 
 
-def fit_batch_size(n_design, requested=None):
+def fit_batch_size(n_design, requested=None, device=None):
     """Problems (target, theta) evaluated through one launch chain: ``GPEMU_FIT_BATCH`` (default 64), within a memory
     budget -- every problem of a batch owns ~6 N x N f64 work matrices on the device, and a batch may take a quarter of
     the MI355X's 288 GB (``GPEMU_FIT_BATCH_GB``, default 72): 64 problems up to N ~ 4800, 58 at N = 5000.  The serial
@@ -432,6 +433,11 @@ def fit_batch_size(n_design, requested=None):
     if requested is None:
         requested = int(os.environ.get("GPEMU_FIT_BATCH", "64"))
     budget = float(os.environ.get("GPEMU_FIT_BATCH_GB", "72")) * 1e9
+    # never more than half of what the device has FREE right now (a smaller part, or memory already held by chains and
+    # models): the reservation would fail with GPEMU_ERR_HIP and abort the fit instead of shrinking the batch
+    free = _lib.device_free_bytes(device)
+    if free is not None:
+        budget = min(budget, 0.5 * free)
     n_pad = -(-int(n_design) // 64) * 64
     return max(1, min(int(requested), int(budget // (6 * 8 * n_pad * n_pad))))
 
@@ -513,7 +519,7 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
             for _ in range(n_restarts_optimizer):
                 starts[i].append(rng.uniform(bounds[:, 0], bounds[:, 1]))
     if n_streams is None:
-        n_streams = fit_batch_size(X.shape[0])
+        n_streams = fit_batch_size(X.shape[0], device=device)
     tasks = [(i, j) for i in range(k_gp) for j in range(len(starts[i]))]
     n_threads = max(1, min(int(n_streams), max(len(tasks), 1)))
     shared = _fit.DeviceFit(X, kk.kind, kk.nu, kk.has_const, kk.has_noise, alpha, device)

@@ -13,6 +13,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import logging
 import os
 
 import numpy as np
@@ -101,12 +102,14 @@ def integrated_time(x, c=5, tol=50, quiet=False):
         windows[d] = np.argmin(m) if np.any(m) else len(taus) - 1
         tau_est[d] = taus[windows[d]]
     flag = tol * tau_est > n_t
-    if np.any(flag) and not quiet:
+    if np.any(flag):
         msg = ("The chain is shorter than {0} times the integrated autocorrelation time for {1} "
                "parameter(s). Use this estimate with caution and run a longer chain!\n"
                ).format(tol, np.sum(flag))
         msg += "N/{0} = {1:.0f};\ntau: {2}".format(tol, n_t / tol, tau_est)
-        raise AutocorrError(tau_est, msg)
+        if not quiet:
+            raise AutocorrError(tau_est, msg)
+        logging.getLogger(__name__).warning(msg)            # emcee logs the message when quiet (autocorr.py)
     return tau_est
 
 
@@ -243,20 +246,24 @@ class DeviceSampler:
                     windows[dd] = lag0 + m
                     tau_est[dd] = taus[m, dd]
                 elif lag0 + nl >= n_t:
-                    # never closed: emcee's auto_window takes np.argmin of an all-True mask, i.e. window 0 and
-                    # tau = taus[0] = 1 (which then fails the tol test: the short-chain AutocorrError)
+                    # never closed (idx < c tau at every lag): emcee's auto_window takes np.argmin of an all-True mask,
+                    # i.e. window 0 and tau = taus[0] (which then fails the tol test: the short-chain AutocorrError).
+                    # (A NaN series is the other case: its mask has no True entry, emcee returns len - 1 there and a
+                    # NaN tau; here the window "closes" at lag 0 with the same NaN.)
                     windows[dd] = 0
                     tau_est[dd] = tau_first[dd]
             run = cs[-1]
             lag0 += nl
             block = min(block * 2, 4096)
         flag = tol * tau_est > n_t
-        if np.any(flag) and not quiet:
+        if np.any(flag):
             msg = ("The chain is shorter than {0} times the integrated autocorrelation time for {1} "
                    "parameter(s). Use this estimate with caution and run a longer chain!\n"
                    ).format(tol, np.sum(flag))
             msg += "N/{0} = {1:.0f};\ntau: {2}".format(tol, n_t / tol, tau_est)
-            raise AutocorrError(tau_est, msg)
+            if not quiet:
+                raise AutocorrError(tau_est, msg)
+            logging.getLogger(__name__).warning(msg)        # emcee logs the message when quiet (autocorr.py)
         return tau_est
 
     # -- multi-GPU: one process per GPU, the ensemble replicated, proposals sharded -------------

@@ -57,6 +57,8 @@ int gpemu_device_name(int device, char *buf, int64_t buflen);
 /* PCI bus id of the device ("0000:c1:00.0"): with the host name it tells whether two ranks of a job share a GPU
  * (gpemu_sampler_peer_share) */
 int gpemu_device_bus_id(int device, char *buf, int64_t buflen);
+/* free / total device memory in bytes (hipMemGetInfo): the fit sizes its batches within what is free */
+int gpemu_device_memory(int device, int64_t *free_bytes, int64_t *total_bytes);
 
 /* ---- model: one emulation group --------------------------------------------------------- */
 /* Replaces the per-worker state of ref: log_posterior.py:26-38 (initialize_pool_variables) and
