@@ -458,8 +458,7 @@ int launch_predict_full(gpemu_model *m, int64_t B, double n_div, double *dcv, do
     const int ncu = m->num_cu;
     const int workers = std::min(ncu, total);
     const size_t shm_pm = sizeof(double) * (2 * 16 * (size_t)F + PM_NB * 16);
-    // 16 waves x 32 columns (GPEMU_PM_CBW=2: 8 waves x 64 columns, within 1 % on the whole chip, slower on a share)
-    static const int pm_cbw = getenv("GPEMU_PM_CBW") ? atoi(getenv("GPEMU_PM_CBW")) : 1;
+    // 16 waves x 32 columns (CBW = 2, 8 waves x 64 columns, measured within 1 % on the whole chip: not instantiated)
 #define GP_LAUNCH_PM2(KSV, CB, DB)                                                                                 \
   do {                                                                                                             \
     static bool attr_set = false;                                                                                  \
@@ -471,20 +470,11 @@ int launch_predict_full(gpemu_model *m, int64_t B, double n_div, double *dcv, do
     hipLaunchKernelGGL((predict_cov_mfma_kernel<KSV, CB, DB>), dim3((unsigned)workers), dim3(1024 / CB), shm_pm,   \
                        st, parts, m->comp, m->sscale, m->cunexpl, dcov, B, F, k, 1.0 / n_div, ngroups, total);     \
   } while (0)
-#define GP_LAUNCH_PM(KSV, DB)                                                                                      \
-  do {                                                                                                             \
-    if (pm_cbw == 2) GP_LAUNCH_PM2(KSV, 2, DB);                                                                    \
-    else GP_LAUNCH_PM2(KSV, 1, DB);                                                                                \
-  } while (0)
+#define GP_LAUNCH_PM(KSV, DB) GP_LAUNCH_PM2(KSV, 1, DB)
     // the central values first (a few us, their inputs -- the GP stage's partial sums -- still in cache), then the writer
     hipLaunchKernelGGL(central_value_kernel, dim3((unsigned)((B + CV_NB - 1) / CV_NB)), dim3(256), 0, st, parts, m->comp,
                        m->smean, m->sscale, dcv, B, F, k);
-    static const int pm_dbg = getenv("GPEMU_PM_DBG") ? atoi(getenv("GPEMU_PM_DBG")) : 0;
-    if (pm_dbg == 1) GP_LAUNCH_PM(3, 1);
-    else if (pm_dbg == 2) GP_LAUNCH_PM(3, 2);
-    else if (pm_dbg == 3) GP_LAUNCH_PM(3, 3);
-    else if (pm_dbg == 4) GP_LAUNCH_PM(3, 4);
-    else if (k <= 4) GP_LAUNCH_PM(1, 0);
+    if (k <= 4) GP_LAUNCH_PM(1, 0);
     else if (k <= 8) GP_LAUNCH_PM(2, 0);
     else if (k <= 12) GP_LAUNCH_PM(3, 0);
     else GP_LAUNCH_PM(4, 0);

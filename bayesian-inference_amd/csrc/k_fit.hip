@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void scatter_diag_blocks_kernel(const double *
 // rank-64 update per step (the update is HBM bound at K = 64: 8 FLOP per byte moved).
 int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hipStream_t st, int nb, const CholOverlap *ov) {
   const int nblk = (int)(Np / NB);
-  static const int chol_q = getenv("GPEMU_CHOL_PANEL_BLOCKS") ? std::max(1, atoi(getenv("GPEMU_CHOL_PANEL_BLOCKS"))) : 4;
+  constexpr int chol_q = 4;
   // A[rows r0 ..][cols c0 .. c1) -= A[rows r0 ..][k0 .. k1) . A[rows c0 .. c1)[k0 .. k1)^T, lower tiles only
   auto update = [&](int64_t r0, int64_t c0, int64_t c1, int64_t k0, int64_t k1, hipStream_t st) -> int {
     const int M = (int)(Np - r0), N = (int)(c1 - c0);
@@ -552,7 +552,7 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
   // one launch per panel (chol_panel_kernel) where the caller provides its flags and the strips of all problems fit on
   // the chip a few times over; GPEMU_CHOL_PANEL=0: the three-launch steps (same bits)
   const int panel_on = getenv("GPEMU_CHOL_PANEL") ? atoi(getenv("GPEMU_CHOL_PANEL")) : 1;      // read per call (tests)
-  static const int panel_max_wg = getenv("GPEMU_CHOL_PANEL_MAX_WG") ? atoi(getenv("GPEMU_CHOL_PANEL_MAX_WG")) : 320;
+  constexpr int panel_max_wg = 320;
   const bool fused = panel_on && chol_q == CHOL_Q && ov && ov->flags && (int64_t)nblk * nb <= panel_max_wg;
   const int fault = getenv("GPEMU_CHOL_FAULT") ? atoi(getenv("GPEMU_CHOL_FAULT")) : 0;     // tests: a head that never publishes
   if (fused) GP_HIP(hipMemsetAsync(ov->flags, 0, sizeof(int) * (size_t)CHOL_FLAGS * nb, st));
@@ -589,7 +589,7 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
     const int64_t t1 = std::min<int64_t>(Np, t0 + (int64_t)chol_q * NB);       // the next panel's columns: [t0, t1)
     // (worth its two cross-stream events -- ~12 us per panel -- only while the side update is long: measured per panel
     // -43 us with 60 tile rows left, break-even at ~38: profiles/r03_chol_lookahead.txt)
-    static const int la_min = getenv("GPEMU_CHOL_LOOKAHEAD_MIN") ? atoi(getenv("GPEMU_CHOL_LOOKAHEAD_MIN")) : 40;
+    constexpr int la_min = 40;
     if (!ov || !ov->side || !fused || Np - t1 < (int64_t)la_min * NB) {
       if (side_pending) GP_HIP(hipStreamWaitEvent(st, ov->rest_done, 0));
       side_pending = false;
@@ -1103,7 +1103,7 @@ int gpemu_fit_create(gpemu_fit **out, int device, int64_t N, int64_t d, const do
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, device);
     const int ncu = prop.multiProcessorCount;
-    const int reserve = getenv("GPEMU_CHOL_RESERVE") ? atoi(getenv("GPEMU_CHOL_RESERVE")) : 4;
+    constexpr int reserve = 4;
     if (e == hipSuccess && reserve > 0 && ncu % 8 == 0 && 8 * reserve < ncu) {
       std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
       for (int i = 8 * reserve; i < ncu; ++i) mask[i / 32] |= 1u << (i % 32);

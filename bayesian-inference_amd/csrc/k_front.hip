@@ -74,7 +74,6 @@ struct FrontArgs {
   double *reset;                       // gather entries handed back to "not arrived"
   int reset_lo, reset_cnt;
   int slow_polls;                      // long naps before an exchange is declared lost
-  unsigned long long *stamps;          // diagnostic: per-workgroup time stamps (GPEMU_FRONT_STAMPS), else null
 };
 
 // Polls before an exchange is declared lost: GATHER_FAST_POLLS short naps (the normal case: the value is at most a
@@ -226,7 +225,6 @@ __global__ __launch_bounds__(256, 2) void front_kernel(FrontArgs fa) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = blockIdx.x;
-  if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 0] = __builtin_amdgcn_s_memrealtime();
 
   if (g >= fa.nks) {
     // ---- state workgroups: the ensemble after the previous half, counters, chain row, gather hand-back ----
@@ -248,7 +246,6 @@ __global__ __launch_bounds__(256, 2) void front_kernel(FrontArgs fa) {
     if (x < fa.reset_cnt)
       __hip_atomic_store(reinterpret_cast<unsigned long long *>(fa.reset + fa.reset_lo + x), GATHER_EMPTY,
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     return;
   }
 
@@ -296,7 +293,6 @@ __global__ __launch_bounds__(256, 2) void front_kernel(FrontArgs fa) {
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
-  if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 1] = __builtin_amdgcn_s_memrealtime();
   if (!does_kstar) return;
   // the workgroup's training fragments.  Requested here, not at the top: held across the waits below they cost 12-24
   // VGPRs (174 / 186 instead of 162) and with them the third resident workgroup per CU -- measured slower at 2 and 4
@@ -322,9 +318,7 @@ __global__ __launch_bounds__(256, 2) void front_kernel(FrontArgs fa) {
 #pragma unroll
     for (int dd = 0; dd < DPAD; ++dd) s_eff[wave][lane][dd] = px[dd];
   }
-  if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 2] = __builtin_amdgcn_s_memrealtime();
   __syncthreads();
-  if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 3] = __builtin_amdgcn_s_memrealtime();
 
   // stretch proposal q = c - (c - s) z  (emcee moves/stretch.py), two components per thread, stored once per column
   {
@@ -349,7 +343,6 @@ __global__ __launch_bounds__(256, 2) void front_kernel(FrontArgs fa) {
   __syncthreads();
   const double sum = front_kstar_block<JTW>(gk, fr, s_q, s_tab, red, p, chunk, (int64_t)cb * 64, fa.d, lane, wave);
   if (wave == 0) gk.mean_part_next[(b * gk.k + p) * gk.nchunk + chunk] = sum;
-  if (fa.stamps && threadIdx.x == 0) fa.stamps[g * 8 + 4] = __builtin_amdgcn_s_memrealtime();
 }
 
 __global__ void gather_fill_kernel(double *p, int64_t n, unsigned long long bits) {
@@ -635,14 +628,6 @@ static int launch_front(gpemu_sampler *s, const Pending &pv, bool have_next, int
   }
   const int nstate = (int)((std::max<int64_t>(W, fa.reset_cnt) + 255) / 256);
   const dim3 grid((unsigned)(fa.nks + nstate)), block(256);
-  static const char *stamp_path = getenv("GPEMU_FRONT_STAMPS");
-  static unsigned long long *dstamps = nullptr;
-  static int stamp_calls = 0;
-  if (stamp_path && !dstamps) {
-    GP_HIP(hipMalloc((void **)&dstamps, sizeof(unsigned long long) * 8 * 4096));
-    GP_HIP(hipMemset(dstamps, 0, sizeof(unsigned long long) * 8 * 4096));
-  }
-  fa.stamps = (stamp_path && grid.x <= 4096) ? dstamps : nullptr;
   const size_t dyn = front_dyn_lds(s);
   if (dyn > 40 * 1024 && front_set_lds_limit() != GPEMU_OK) return GPEMU_ERR_HIP;
   const int pe0 = prof_mark(m0, st);
@@ -650,23 +635,6 @@ static int launch_front(gpemu_sampler *s, const Pending &pv, bool have_next, int
   else hipLaunchKernelGGL((front_kernel<2>), grid, block, dyn, st, fa);
   GP_HIP(hipGetLastError());
   prof_pair(m0, 1, pe0, prof_mark(m0, st));
-  if (fa.stamps && ++stamp_calls == 400) {
-    GP_HIP(hipStreamSynchronize(st));
-    std::vector<unsigned long long> hst(8 * (size_t)grid.x);
-    GP_HIP(hipMemcpy(hst.data(), dstamps, sizeof(unsigned long long) * hst.size(), hipMemcpyDeviceToHost));
-    if (FILE *f = fopen(stamp_path, "w")) {
-      unsigned long long t0 = ~0ull;
-      for (unsigned wg = 0; wg < grid.x; ++wg) t0 = std::min(t0, hst[wg * 8]);
-      fprintf(f, "# nks %d nkstar %d n_llwg %d grid %u: wg start afterA afterwait aftersync end (us)\n", fa.nks, fa.nkstar,
-              fa.n_llwg, grid.x);
-      for (unsigned wg = 0; wg < grid.x; ++wg) {
-        fprintf(f, "%u", wg);
-        for (int i = 0; i < 5; ++i) fprintf(f, " %.2f", hst[wg * 8 + i] >= t0 ? (double)(hst[wg * 8 + i] - t0) / 100.0 : -1.0);
-        fprintf(f, "\n");
-      }
-      fclose(f);
-    }
-  }
   // bookkeeping
   s->cur ^= 1;
   s->X = s->Xbuf + (size_t)s->cur * W * DPAD;

@@ -213,38 +213,33 @@ int launch_gemm(const GemmArgs &g, bool a_kmajor, bool b_kmajor, int batch, hipS
     return GPEMU_ERR_ARG;
   }
   if (g.M == 0 || g.N == 0) return GPEMU_OK;
-  // 128 x 128 tiles from this size on; 0 = never, the default: with one or two workgroups per CU (74 KiB of LDS, ~200
-  // VGPRs) the big tile hides its LDS and global latencies worse than four co-resident 64 x 64 workgroups do -- batched
-  // N = 1000: 5.2 vs 4.25 ms per 64 problems, N = 5000: 7.8 vs 6.4 ms (GPEMU_GEMM_BIG_MIN=256 to measure)
-  static const int big_min = getenv("GPEMU_GEMM_BIG_MIN") ? atoi(getenv("GPEMU_GEMM_BIG_MIN")) : 0;
-  const bool big = big_min > 0 && g.M >= big_min && g.N >= big_min;
+  // (128 x 128 tiles -- the kernel's R = 4 form, still instantiated by tools/gemm_probe -- lose at every size: with one
+  // or two workgroups per CU (74 KiB of LDS, ~200 VGPRs) the big tile hides its LDS and global latencies worse than four
+  // co-resident 64 x 64 workgroups do: batched N = 1000 5.2 vs 4.25 ms per 64 problems, N = 5000 7.8 vs 6.4 ms)
+  constexpr bool big = false;
   GemmArgs gs = g;
   // fold the tile grid where a triangular operand makes the K range run along one dimension only (see the kernel)
-  static const int pair_on = getenv("GPEMU_GEMM_PAIR") ? atoi(getenv("GPEMU_GEMM_PAIR")) : 1;
   gs.pair = 0;
   // ... when there are enough tiles to fill the chip at least half (fewer: a launch lasts as long as its longest tile
   // either way, and folding only halves the workgroups -- b = 256 pairs batched: 17 -> 22 us)
   const int64_t tiles = (int64_t)(g.M / GT) * (g.N / GT) * batch;
-  if (pair_on && !big && !g.lower_only && tiles >= 400) {
+  if (!big && !g.lower_only && tiles >= 400) {
     if (g.k_from_n && !g.k_from_m && !g.k_to_m && g.N >= 128) gs.pair = 1;
     else if (g.k_to_m && !g.k_from_n && !g.k_from_m && g.M >= 128) gs.pair = 2;
   }
   const int T = big ? 128 : 64;
   {
-    static const int xcd_on = getenv("GPEMU_GEMM_XCD") ? atoi(getenv("GPEMU_GEMM_XCD")) : 1;
     const int problems = g.batch1 > 0 ? batch / g.batch1 : batch;
-    gs.xcd_batch = (xcd_on && problems >= 8 && problems % 8 == 0 && (g.batch1 <= 0 || batch % g.batch1 == 0)) ? 1 : 0;
+    gs.xcd_batch = (problems >= 8 && problems % 8 == 0 && (g.batch1 <= 0 || batch % g.batch1 == 0)) ? 1 : 0;
   }
   dim3 grid((unsigned)((g.N + T - 1) / T), (unsigned)((g.M + T - 1) / T), (unsigned)batch), block(256);
   if (gs.pair == 1) grid.x = (grid.x + 1) / 2;
   if (gs.pair == 2) grid.y = (grid.y + 1) / 2;
-  static const int packed_on = getenv("GPEMU_GEMM_PACKED") ? atoi(getenv("GPEMU_GEMM_PACKED")) : 1;
-  gs.packed = (packed_on && g.lower_only && !big && g.M == g.N) ? 1 : 0;
+  gs.packed = (g.lower_only && !big && g.M == g.N) ? 1 : 0;
   if (gs.packed) { grid.x = grid.x * (grid.x + 1) / 2; grid.y = 1; }
 #define GP_LAUNCH_GEMM(AK, BK)                                                                  \
   do {                                                                                          \
-    if (big) hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, 4>), grid, block, 0, st, gs);          \
-    else hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, 2>), grid, block, 0, st, gs);              \
+    hipLaunchKernelGGL((gemm_f64_kernel<AK, BK, 2>), grid, block, 0, st, gs);                   \
   } while (0)
   if (a_kmajor && b_kmajor) GP_LAUNCH_GEMM(true, true);
   else if (a_kmajor && !b_kmajor) GP_LAUNCH_GEMM(true, false);

@@ -595,8 +595,7 @@ extern "C" int gpemu_pca_fit(int device, int64_t N, int64_t F, const double *Y, 
   GP_HIP(hipSetDevice(device));
   const bool tw = N < F;                          // work on the transpose when there are fewer rows
   const int m = (int)(tw ? F : N), n = (int)(tw ? N : F);
-  int PB = n <= 1024 ? 16 : 32;                                     // columns per block (more, smaller pairs keep a small matrix's rounds short)
-  if (const char *e = getenv("GPEMU_PCA_PB")) PB = atoi(e) == 32 ? 32 : 16;
+  const int PB = n <= 1024 ? 16 : 32;                                     // columns per block (more, smaller pairs keep a small matrix's rounds short)
   const int PP = 2 * PB;
   const int nb = std::max(2, (int)(round_up(n, 2 * PB) / PB));      // blocks of PB columns, an even number of them
   const int ncols = nb * PB, npairs = nb / 2;
@@ -605,9 +604,8 @@ extern "C" int gpemu_pca_fit(int device, int64_t N, int64_t F, const double *Y, 
   const int nstrips = (int)((mpad + round_up(n, 16)) / 16);
   const int chunks = mpad / 64;
   const int nsplit = std::max(1, std::min(chunks, std::min(8, 256 / npairs)));
-  int inner = PB == 16 ? 1 : 2;                                     // inner sweeps per encounter of two blocks
+  const int inner = PB == 16 ? 1 : 2;                                     // inner sweeps per encounter of two blocks
   const bool trace = getenv("GPEMU_PCA_TRACE") != nullptr;
-  if (const char *e = getenv("GPEMU_PCA_INNER")) inner = std::max(1, atoi(e));
   double *dY = nullptr, *dYs = nullptr, *dmean = nullptr, *dvar = nullptr, *dscale = nullptr, *dpm = nullptr,
          *dW = nullptr, *dpart = nullptr, *dJ = nullptr, *dss = nullptr;
   int *dflags = nullptr, *dtickets = nullptr;
@@ -646,8 +644,7 @@ extern "C" int gpemu_pca_fit(int device, int64_t N, int64_t F, const double *Y, 
       if (e == hipSuccess) e = hipMemcpy(hss.data(), dss, sizeof(double) * F, hipMemcpyDeviceToHost);
       double fro2 = 0.0;
       for (double v : hss) fro2 += v;
-      double noise_c = 4.0;
-      if (const char *ev = getenv("GPEMU_PCA_NOISE")) noise_c = atof(ev);
+      const double noise_c = 4.0;
       const double lim = noise_c * std::sqrt((double)m) * 2.220446049250313e-16;
       noise2 = lim * lim * fro2;
     }

@@ -36,13 +36,12 @@ struct SmallItem {
   int p, rb, col0, pad;
 };
 
-// dbg: compile-time ablation switch (2: no operand loads, i.e. the bare MFMA stream); 0 in production.
 // ST_RING: k-tiles in flight per wave (two 16-byte loads each)
-template <int dbg, int ST_RING>
+template <int ST_RING>
 __global__ __launch_bounds__(512, 2) void trmm_vsq_small_kernel(
     const double *__restrict__ Wt, const double *__restrict__ KS, double *__restrict__ out,
     const SmallItem *__restrict__ sched, const int *__restrict__ sched_cnt, int max_items, int64_t Npad,
-    int64_t Bcap, int k, int nrb, unsigned long long *__restrict__ stamps) {
+    int64_t Bcap, int k, int nrb) {
   __shared__ __attribute__((aligned(16))) double scratch[4 * 4 * 64 * 4];   // K-slice partial tiles, 32 KiB
   __shared__ SmallItem s_items[ST_MAX_ITEMS];
 
@@ -51,8 +50,6 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_small_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane & 15, lk = lane >> 4;
 
-  if (stamps && tid == 0) stamps[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memrealtime();
-  const unsigned long long clk0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
   const int nitems = __builtin_amdgcn_readfirstlane(sched_cnt[blockIdx.x]);
   if (tid < nitems) s_items[tid] = sched[(int64_t)blockIdx.x * max_items + tid];
   __syncthreads();
@@ -61,7 +58,6 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_small_kernel(
   auto item_p = [&](int i) { return __builtin_amdgcn_readfirstlane(s_items[i].p); };
   auto item_rb = [&](int i) { return __builtin_amdgcn_readfirstlane(s_items[i].rb); };
   auto item_col0 = [&](int i) { return __builtin_amdgcn_readfirstlane(s_items[i].col0); };
-  if (stamps && tid == 0) stamps[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime();
 
   // ---- load cursor: ST_RING k-tiles ahead of the compute cursor, across item boundaries ----
   const int64_t laneA = (int64_t)(4 * wave + lk) * Npad + 2 * q;     // this lane's k-row and row pair in a k-tile
@@ -77,10 +73,8 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_small_kernel(
     l_t = 0;
   };
   auto issue = [&](d2 &ra, d2 &rb) {
-    if (!(dbg & 2)) {
-      ra = *reinterpret_cast<const d2 *>(l_pa);
-      rb = *reinterpret_cast<const d2 *>(l_pb);
-    }
+    ra = *reinterpret_cast<const d2 *>(l_pa);
+    rb = *reinterpret_cast<const d2 *>(l_pb);
     if (l_item < nitems) {
       if (++l_t == l_nt) {
         if (++l_item < nitems) l_open();            // else: stay on the last k-tile (harmless re-read)
@@ -98,7 +92,6 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_small_kernel(
   l_open();
 #pragma unroll
   for (int u = 0; u < ST_RING; ++u) issue(ra[u], rb[u]);
-  if (stamps && tid == 0) stamps[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime();
 
   // two accumulator sets, taken in turn by successive k-tiles: eight independent MFMA chains per wave
   d4 acc[2][2], acc2[2][2];
@@ -116,15 +109,13 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_small_kernel(
     for (int u = 0; u < ST_RING; ++u) {
       const d2 av = ra[u], bv = rb[u];
       issue(ra[u], rb[u]);                          // the slot's next occupant: k-tile + ST_RING
-      if (!(dbg & 1)) {
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+      for (int x = 0; x < 2; ++x)
 #pragma unroll
-          for (int y = 0; y < 2; ++y) {
-            if (u & 1) acc2[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc2[x][y], 0, 0, 0);
-            else acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
-          }
-      }
+        for (int y = 0; y < 2; ++y) {
+          if (u & 1) acc2[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc2[x][y], 0, 0, 0);
+          else acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
+        }
       if (++c_t == c_nt) {
 #pragma unroll
         for (int x = 0; x < 2; ++x)
@@ -176,7 +167,6 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_small_kernel(
         for (int x = 0; x < 2; ++x)
 #pragma unroll
           for (int y = 0; y < 2; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
-        if (stamps && tid == 0 && c_item < 12) stamps[blockIdx.x * 16 + 3 + c_item] = __builtin_amdgcn_s_memrealtime();
         if (++c_item == nitems) { done = true; break; }
         cur_p = item_p(c_item); cur_rb = item_rb(c_item); cur_col0 = item_col0(c_item);
         c_nt = cur_rb + 1;
@@ -185,7 +175,6 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_small_kernel(
     }
     if (done) break;
   }
-  if (stamps && tid == 0) stamps[blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime() - clk0;
 }
 
 // host side: LPT schedule, XCD-aware.  Workgroups are dispatched round-robin over the 8 XCDs (worker w on XCD
@@ -273,44 +262,11 @@ int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st) {
     m->sm_ncb = ncb; m->sm_cap = cap; m->sm_max_items = max_items; m->sm_workers = nworkers;
   }
   w.cur_nrb = nrb;
-  static const int dbg = getenv("GPEMU_SMALL_DBG") ? atoi(getenv("GPEMU_SMALL_DBG")) : 0;   // ablation switches
-  static const char *stamp_path = getenv("GPEMU_SMALL_STAMPS");                             // per-worker time stamps
-  static unsigned long long *dstamps = nullptr;
-  static int stamp_calls = 0;
-  if (stamp_path && !dstamps) {
-    GP_HIP(hipMalloc((void **)&dstamps, sizeof(unsigned long long) * 16 * 1024));
-    GP_HIP(hipMemset(dstamps, 0, sizeof(unsigned long long) * 16 * 1024));
-  }
   const int pe0 = prof_mark(m, st);
-#define GP_LAUNCH_SMALL(D)                                                                                          \
-  hipLaunchKernelGGL((trmm_vsq_small_kernel<D, 4>), dim3((unsigned)m->sm_workers), dim3(512), 0, st, m->Wt, w.KS, w.vsq_part, \
-                     (const SmallItem *)m->sm_items, m->sm_cnt, m->sm_max_items, m->Npad, w.Bcap, (int)m->k, nrb, dstamps)
-  switch (dbg) {
-    case 2: GP_LAUNCH_SMALL(2); break;
-    default: GP_LAUNCH_SMALL(0); break;
-  }
-#undef GP_LAUNCH_SMALL
+  hipLaunchKernelGGL((trmm_vsq_small_kernel<4>), dim3((unsigned)m->sm_workers), dim3(512), 0, st, m->Wt, w.KS, w.vsq_part,
+                     (const SmallItem *)m->sm_items, m->sm_cnt, m->sm_max_items, m->Npad, w.Bcap, (int)m->k, nrb);
   GP_HIP(hipGetLastError());
   prof_pair(m, 0, pe0, prof_mark(m, st));
-  if (stamp_path && ++stamp_calls == 500) {
-    GP_HIP(hipStreamSynchronize(st));
-    std::vector<unsigned long long> h(16 * 1024);
-    GP_HIP(hipMemcpy(h.data(), dstamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
-    std::vector<int> cnt(m->sm_workers);
-    GP_HIP(hipMemcpy(cnt.data(), m->sm_cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost));
-    FILE *f = fopen(stamp_path, "w");
-    if (f) {
-      unsigned long long t0 = ~0ull;
-      for (int wk = 0; wk < m->sm_workers; ++wk) t0 = std::min(t0, h[wk * 16]);
-      for (int wk = 0; wk < m->sm_workers; ++wk) {
-        fprintf(f, "%d %d", wk, cnt[wk]);
-        for (int i = 0; i < 3 + std::min(cnt[wk], 12); ++i) fprintf(f, " %.2f", (double)(h[wk * 16 + i] - t0) / 100.0);
-        fprintf(f, " cycles %llu", h[wk * 16 + 15]);
-        fprintf(f, "\n");
-      }
-      fclose(f);
-    }
-  }
   return GPEMU_OK;
 }
 

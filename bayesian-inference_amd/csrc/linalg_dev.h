@@ -59,26 +59,33 @@ __device__ inline void wg_cholesky_lower(double *A, int n, int ld, double *PT, i
       if (c <= r) A[(int64_t)(j0 + r) * ld + j0 + c] = D[r][c];
     }
     const int r0 = j0 + nb;  // first trailing row
-    // panel: X D^T = A[r0:, j0:j0+nb]
+    // panel: X D^T = A[r0:, j0:j0+nb], one thread per row, eight columns at a time in registers; the columns of the
+    // earlier groups are read back from PT (coalesced over the rows, just written by this thread).  Same operation
+    // order per element as a straight 32-column register solve -- which held x[32] plus the hoisted D operands of 496
+    // unrolled FMAs and spilled 800-940 VGPRs in the kernels that inline this (lik_setup_kernel, loglik_exact_kernel).
+    constexpr int PG = 8;
     for (int i = r0 + tid; i < n; i += nthr) {
-      double x[CHOL_NB];
       double *Ai = A + (int64_t)i * ld + j0;
+      for (int c0 = 0; c0 < nb; c0 += PG) {
+        double x[PG];
 #pragma unroll
-      for (int c = 0; c < CHOL_NB; ++c) x[c] = (c < nb) ? Ai[c] : 0.0;
+        for (int j = 0; j < PG; ++j) x[j] = (c0 + j < nb) ? Ai[c0 + j] : 0.0;
+        for (int mm = 0; mm < c0; ++mm) {
+          const double xm = PT[(int64_t)mm * ldp + i];
 #pragma unroll
-      for (int c = 0; c < CHOL_NB; ++c) {
-        if (c < nb) {
-          double s = x[c];
-#pragma unroll
-          for (int mm = 0; mm < c; ++mm) s = fma(-x[mm], D[c][mm], s);
-          x[c] = s / D[c][c];
+          for (int j = 0; j < PG; ++j)
+            if (c0 + j < nb) x[j] = fma(-xm, D[c0 + j][mm], x[j]);
         }
-      }
 #pragma unroll
-      for (int c = 0; c < CHOL_NB; ++c) {
-        if (c < nb) {
-          Ai[c] = x[c];
-          PT[(int64_t)c * ldp + i] = x[c];
+        for (int j = 0; j < PG; ++j) {
+          if (c0 + j < nb) {
+            double sacc = x[j];
+#pragma unroll
+            for (int mm = 0; mm < j; ++mm) sacc = fma(-x[mm], D[c0 + j][c0 + mm], sacc);
+            x[j] = sacc / D[c0 + j][c0 + j];
+            Ai[c0 + j] = x[j];
+            PT[(int64_t)(c0 + j) * ldp + i] = x[j];
+          }
         }
       }
     }

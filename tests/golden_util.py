@@ -64,24 +64,7 @@ def g7_models(g, use_golden_L=True):
             for n in g7_groups(g)[0]}
 
 
-def fixed_theta_model(N, F, k, seed=0, ls_factor=0.5, noise=0.05, jitter=1e-10, kind=O.RBF, nu=np.inf):
-    """The C3-style model of SURVEY 8(d): synthetic data, fixed hyper-parameters, built with the
-    oracle only (no sklearn) -- regenerates what g4_c3_fixed_theta.npz was produced from."""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN_DIR), "..", "bayesian-inference_amd"))
-    from gpemu import synthetic
-    prob = synthetic.make_problem(N, F, seed=seed)
-    mean, scale, var = O.scaler_fit(prob["Y"])
-    Ys = (prob["Y"] - mean) / scale
-    pca = O.pca_fit(Ys)
-    spec = O.KernelSpec(kind=kind, nu=nu, has_const=False, has_noise=True)
-    ls = (prob["hi"] - prob["lo"]) * ls_factor
-    theta = np.log(np.r_[ls, noise])
-    gps = [O.gp_fit_at_theta(prob["design"], pca["Y_pca"][:, i], theta, spec, jitter) for i in range(k)]
-    model = O.GroupModel(X_train=prob["design"], spec=spec, gps=gps, components=pca["components"],
-                         explained_variance=pca["explained_variance"], scaler_mean=mean,
-                         scaler_scale=scale, n_pc=k)
-    return model, prob, pca
+from oracle.workloads import fixed_theta_model  # noqa: E402,F401  (kept under this name for the tests)
 
 
 def device_model(model, device=0, with_cov_unexplained=True):
