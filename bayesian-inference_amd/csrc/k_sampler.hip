@@ -41,6 +41,14 @@ __host__ __device__ static inline u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint
   }
   return c;
 }
+// LDS bitonic sort of the split keys (rng_step_kernel): power-of-two size for W walkers, 0 if it would not fit
+constexpr int RNG_SORT_MAX = 2048;
+__host__ __device__ static inline int rng_sort_size(int W) {
+  if (W > RNG_SORT_MAX) return 0;
+  int P = 2;
+  while (P < W) P <<= 1;
+  return P;
+}
 __host__ __device__ static inline double u01_from(uint32_t hi, uint32_t lo) {
   uint64_t v = ((uint64_t)hi << 32) | lo;
   return (double)(v >> 11) * (1.0 / 9007199254740992.0);  // [0,1), 53 bits
@@ -89,21 +97,50 @@ __global__ __launch_bounds__(1024) void rng_step_kernel(int *inds_r, int *idx_r,
   double *fac = fac_r + (size_t)slot * 2 * Wt;
   int *pos = pos_r + (size_t)slot * Wt + woff;
 
-  for (int w = tid; w < W; w += nthr) {
-    u32x4 r = philox4x32_10(u32x4{(uint32_t)w, 0u, step_lo, step_hi}, k0, k1);
-    keys[w] = ((unsigned long long)r.x << 32) | (unsigned)w;
+  // keys[w] = (32 random bits << 32) | w: unique, so the rank of every walker's key is defined.  Up to RNG_SORT_MAX
+  // walkers the ranks come from a bitonic sort of the keys in LDS (P = next power of two, padded with all-ones
+  // sentinels: 55 compare-exchange passes at P = 1024) instead of W comparisons per thread (one workgroup per step did
+  // 1024^2 comparisons on a single CU: 41 us per batch of 16 steps with the rest of the chip idle); the sorted position of
+  // key (r, w) is w's rank, written back into keys[w]'s slot of a second array.
+  const int P = rng_sort_size(W);                   // 0: too many walkers for the LDS sort
+  unsigned long long *ranks = keys + (P ? P : W);   // [W] (only with the sort)
+  for (int w = tid; w < (P ? P : W); w += nthr) {
+    if (w < W) {
+      u32x4 r = philox4x32_10(u32x4{(uint32_t)w, 0u, step_lo, step_hi}, k0, k1);
+      keys[w] = ((unsigned long long)r.x << 32) | (unsigned)w;
+    } else {
+      keys[w] = ~0ull;
+    }
   }
   __syncthreads();
+  if (P) {
+    for (int kk = 2; kk <= P; kk <<= 1)
+      for (int j = kk >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < P / 2; i += nthr) {
+          const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+          const unsigned long long a = keys[lo], b = keys[hi];
+          const bool up = (lo & kk) == 0;
+          if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+        }
+        __syncthreads();
+      }
+    for (int r = tid; r < W; r += nthr) ranks[(unsigned)keys[r]] = (unsigned long long)r;   // low word = walker
+    __syncthreads();
+  }
   // split[w] = rank(w) & 1  == (arange(W) % 2) after a uniform shuffle; lists in ascending w
   int base0 = 0, base1 = 0;
   for (int c0 = 0; c0 < W; c0 += nthr) {
     const int w = c0 + tid;
     int sp = -1;
     if (w < W) {
-      const unsigned long long kw = keys[w];
       int rank = 0;
+      if (P) {
+        rank = (int)ranks[w];
+      } else {
+        const unsigned long long kw = keys[w];
 #pragma unroll 8
-      for (int jx = 0; jx < W; ++jx) rank += (keys[jx] < kw) ? 1 : 0;
+        for (int jx = 0; jx < W; ++jx) rank += (keys[jx] < kw) ? 1 : 0;
+      }
       sp = rank & 1;
       inds[w] = sp;
     }
@@ -237,7 +274,8 @@ static int ensure_chain(gpemu_sampler *s, int64_t need) {
 
 static int launch_rng_batch(gpemu_sampler *s, hipStream_t st, uint64_t first, int64_t n) {
   const int C = s->nchains, Wc = (int)(s->W / C);
-  size_t shm = sizeof(unsigned long long) * Wc;
+  const int P = rng_sort_size(Wc);
+  size_t shm = sizeof(unsigned long long) * (P ? (size_t)P + Wc : (size_t)Wc);   // keys (+ ranks with the LDS sort)
   hipLaunchKernelGGL(rng_step_kernel, dim3((unsigned)n, (unsigned)C), dim3(1024), shm, st, s->inds, s->idx, s->zz,
                      s->logu, s->rint, s->fac, s->pos, Wc, (int)(s->ns[0] / C), (int)(s->ns[1] / C), (int)s->d, s->a,
                      s->seeds, (int)s->W, (unsigned long long)first);
