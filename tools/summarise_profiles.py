@@ -34,6 +34,7 @@ for name, out in (("bench_default.json", f"{prefix}_bench_default.json"), ("emul
                   ("fit_lml.txt", f"{prefix}_fit_lml.txt"), ("predict_gbps.txt", f"{prefix}_predict_gbps.txt"),
                   ("closure_batch.txt", f"{prefix}_closure_batch.txt"), ("pca.txt", f"{prefix}_pca.txt"),
                   ("fit_batch.txt", f"{prefix}_fit_batch.txt"), ("fit_probes.txt", f"{prefix}_fit_probes.txt"),
+                  ("kstar_probe.txt", f"{prefix}_kstar_probe.txt"), ("time_exact.txt", f"{prefix}_time_exact.txt"),
                   ("dropin_c3_end_to_end.txt", f"{prefix}_dropin_c3_end_to_end.txt")):
     f = os.path.join(src, name)
     if os.path.exists(f):

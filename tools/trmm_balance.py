@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-worker finish times of the dominant kernel (in-kernel stamps) and the step time, for one LPT item-overhead value
-(GPEMU_TRMM_OV from the environment)."""
+"""Per-worker finish times of the dominant kernel (in-kernel stamps of launch 600, GPEMU_TRMM_STAMP_FILE) and the step
+time of the same bench run."""
 import json, os, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +11,6 @@ out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps",
 d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 rows = [l.split() for l in open(stamp)]
 fin = np.array([float(r[-1]) for r in rows]); n = np.array([int(r[1]) for r in rows])
-print(f"OV={os.environ.get('GPEMU_TRMM_OV')}: step {d['ms_per_step']:.4f} ms, trmm {d['roofline']['avg_launch_us']:.2f} us (events), frac {d['roofline']['frac']:.3f}; "
+print(f"step {d['ms_per_step']:.4f} ms, trmm {d['roofline']['avg_launch_us']:.2f} us (events), frac {d['roofline']['frac']:.3f}; "
       f"workers finish min {fin.min():.1f} med {np.median(fin):.1f} max {fin.max():.1f}; by items " +
       ", ".join(f"{c}: {fin[n == c].mean():.1f} ({int((n == c).sum())})" for c in np.unique(n)), flush=True)
