@@ -31,6 +31,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int ST_M = 32, ST_N = 32, ST_K = 32;
 constexpr int ST_MAX_ITEMS = 256;
+constexpr int ST_WPC = 2;          // persistent workers per CU
 
 struct SmallItem {
   int p, rb, col0, pad;
@@ -194,7 +195,10 @@ static void build_small_schedule(const gpemu_model *m, int ncb, std::vector<Smal
       for (int cb = 0; cb < ncb; ++cb) items.push_back({nt + ov, SmallItem{p, rb, cb * ST_N, 0}, p * ncb + cb});
   }
   std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.cost > b.cost; });
-  const int ncu = m->num_cu;
+  // Two workers per CU (36 KB of LDS and 121 VGPRs each: both are resident): what bounds this kernel is each wave's own
+  // load -> MFMA dependency, not the operand bytes (profiles/r04_small_gemm_64col_negative.txt), so four waves per SIMD
+  // instead of two hide more of it: 22.9 -> 21.5 us at 64 columns, 36.4 -> 34.5 us at 128.
+  const int ncu = m->num_cu * ST_WPC;
   nworkers = ncu < (int)items.size() ? ncu : (int)items.size();
   std::vector<std::vector<SmallItem>> per(nworkers);
   std::vector<double> load(nworkers, 0.0);
@@ -232,7 +236,7 @@ static void build_small_schedule(const gpemu_model *m, int ncb, std::vector<Smal
 int small_trmm_xcd_of(const gpemu_model *m, int64_t B, int p, int64_t col) {
   const int nrb = (int)(m->Npad / ST_M), k = (int)m->k, ncb = (int)(round_up(B, ST_N) / ST_N);
   const int64_t nitems = (int64_t)nrb * k * ncb;
-  const int ncu = m->num_cu, nxcd = 8, ngroups = k * ncb;
+  const int ncu = m->num_cu * ST_WPC, nxcd = 8, ngroups = k * ncb;
   if (nitems < ncu || ncu % nxcd != 0 || ngroups < nxcd) return -1;
   const int gper = ngroups / nxcd, g = p * ncb + (int)(col / ST_N);
   return g < gper * nxcd ? g / gper : -1;
