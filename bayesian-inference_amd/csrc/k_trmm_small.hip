@@ -31,15 +31,24 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int ST_M = 32, ST_N = 32, ST_K = 32;
 constexpr int ST_MAX_ITEMS = 256;
-constexpr int ST_WPC = 2;          // persistent workers per CU
+// persistent workers per CU for `nitems` items: what bounds this kernel is each wave's own load -> MFMA dependency, not the
+// operand bytes (profiles/r04_small_gemm_64col_negative.txt), so more waves per SIMD hide more of it -- as long as every
+// worker still gets ~1.6 items for the LPT schedule to balance (measured at C3: 64 columns = 640 items: 22.9 / 21.6 / 27.4
+// us with 1 / 2 / 3 workers per CU; 128 columns = 1280 items: 36.4 / 34.5 / 31.9 us)
+static inline int small_workers_per_cu(int64_t nitems, int num_cu) {
+  if (nitems >= (int64_t)5 * num_cu) return 3;
+  if (nitems >= (int64_t)2 * num_cu) return 2;
+  return 1;
+}
 
 struct SmallItem {
   int p, rb, col0, pad;
 };
 
-// ST_RING: k-tiles in flight per wave (two 16-byte loads each)
-template <int ST_RING>
-__global__ __launch_bounds__(512, 2) void trmm_vsq_small_kernel(
+// ST_RING: k-tiles in flight per wave (two 16-byte loads each); WPE: waves per SIMD the register budget is cut for
+// (4: two workgroups per CU, ring of 4; 6: three per CU, 80 VGPRs, ring of 3).  Same arithmetic in both.
+template <int ST_RING, int WPE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void trmm_vsq_small_kernel(
     const double *__restrict__ Wt, const double *__restrict__ KS, double *__restrict__ out,
     const SmallItem *__restrict__ sched, const int *__restrict__ sched_cnt, int max_items, int64_t Npad,
     int64_t Bcap, int k, int nrb) {
@@ -94,12 +103,13 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_small_kernel(
 #pragma unroll
   for (int u = 0; u < ST_RING; ++u) issue(ra[u], rb[u]);
 
-  // two accumulator sets, taken in turn by successive k-tiles: eight independent MFMA chains per wave
-  d4 acc[2][2], acc2[2][2];
+  // one accumulator set: four independent MFMA chains per wave (a second set, taken in turn by successive k-tiles, made
+  // no difference in time and costs 32 VGPRs; with one set every variant of this kernel sums in the same order)
+  d4 acc[2][2];
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
-    for (int y = 0; y < 2; ++y) acc[x][y] = acc2[x][y] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int y = 0; y < 2; ++y) acc[x][y] = d4{0.0, 0.0, 0.0, 0.0};
   int c_item = 0, c_t = 0;
   int cur_p = item_p(0), cur_rb = item_rb(0), cur_col0 = item_col0(0);
   int c_nt = cur_rb + 1;
@@ -114,17 +124,9 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_small_kernel(
       for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 2; ++y) {
-          if (u & 1) acc2[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc2[x][y], 0, 0, 0);
-          else acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
         }
       if (++c_t == c_nt) {
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-          for (int y = 0; y < 2; ++y) {
-            acc[x][y] = acc[x][y] + acc2[x][y];
-            acc2[x][y] = d4{0.0, 0.0, 0.0, 0.0};
-          }
         // Item finished: sum the eight K-slices (fixed order: deterministic) and reduce V^2 over the 32 rows.
         // Slot of a value: [wave][tile x + 2 y][lane][reg]  (8 KiB per wave).  Tile (x, y), lane (lr, lk'), register r
         // is row i0 + 2 (lk' + 4 r) + x, column col0 + 2 lr + y.
@@ -195,10 +197,7 @@ static void build_small_schedule(const gpemu_model *m, int ncb, std::vector<Smal
       for (int cb = 0; cb < ncb; ++cb) items.push_back({nt + ov, SmallItem{p, rb, cb * ST_N, 0}, p * ncb + cb});
   }
   std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.cost > b.cost; });
-  // Two workers per CU (36 KB of LDS and 121 VGPRs each: both are resident): what bounds this kernel is each wave's own
-  // load -> MFMA dependency, not the operand bytes (profiles/r04_small_gemm_64col_negative.txt), so four waves per SIMD
-  // instead of two hide more of it: 22.9 -> 21.5 us at 64 columns, 36.4 -> 34.5 us at 128.
-  const int ncu = m->num_cu * ST_WPC;
+  const int ncu = m->num_cu * small_workers_per_cu((int64_t)items.size(), m->num_cu);
   nworkers = ncu < (int)items.size() ? ncu : (int)items.size();
   std::vector<std::vector<SmallItem>> per(nworkers);
   std::vector<double> load(nworkers, 0.0);
@@ -236,7 +235,7 @@ static void build_small_schedule(const gpemu_model *m, int ncb, std::vector<Smal
 int small_trmm_xcd_of(const gpemu_model *m, int64_t B, int p, int64_t col) {
   const int nrb = (int)(m->Npad / ST_M), k = (int)m->k, ncb = (int)(round_up(B, ST_N) / ST_N);
   const int64_t nitems = (int64_t)nrb * k * ncb;
-  const int ncu = m->num_cu * ST_WPC, nxcd = 8, ngroups = k * ncb;
+  const int ncu = m->num_cu * small_workers_per_cu(nitems, m->num_cu), nxcd = 8, ngroups = k * ncb;
   if (nitems < ncu || ncu % nxcd != 0 || ngroups < nxcd) return -1;
   const int gper = ngroups / nxcd, g = p * ncb + (int)(col / ST_N);
   return g < gper * nxcd ? g / gper : -1;
@@ -267,8 +266,12 @@ int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st) {
   }
   w.cur_nrb = nrb;
   const int pe0 = prof_mark(m, st);
-  hipLaunchKernelGGL((trmm_vsq_small_kernel<4>), dim3((unsigned)m->sm_workers), dim3(512), 0, st, m->Wt, w.KS, w.vsq_part,
-                     (const SmallItem *)m->sm_items, m->sm_cnt, m->sm_max_items, m->Npad, w.Bcap, (int)m->k, nrb);
+  if (m->sm_workers > 2 * m->num_cu)
+    hipLaunchKernelGGL((trmm_vsq_small_kernel<3, 6>), dim3((unsigned)m->sm_workers), dim3(512), 0, st, m->Wt, w.KS, w.vsq_part,
+                       (const SmallItem *)m->sm_items, m->sm_cnt, m->sm_max_items, m->Npad, w.Bcap, (int)m->k, nrb);
+  else
+    hipLaunchKernelGGL((trmm_vsq_small_kernel<4, 4>), dim3((unsigned)m->sm_workers), dim3(512), 0, st, m->Wt, w.KS, w.vsq_part,
+                       (const SmallItem *)m->sm_items, m->sm_cnt, m->sm_max_items, m->Npad, w.Bcap, (int)m->k, nrb);
   GP_HIP(hipGetLastError());
   prof_pair(m, 0, pe0, prof_mark(m, st));
   return GPEMU_OK;
