@@ -88,9 +88,20 @@ class DeviceModel:
             raise ValueError(f"expected {self.d} parameters per row, got {X.shape[1]}")
         return X
 
+    @staticmethod
+    def _finite(X):
+        """sklearn's GaussianProcessRegressor.predict validates its input (check_array: ValueError on NaN / inf; skl
+        utils/validation.py), which is what the reference's predict path goes through (ref: emulation.py:497).  The
+        cross-kernel on the matrix cores does not propagate a NaN coordinate into K_* (only into the mean), so the
+        host entry points refuse non-finite queries the way the reference does.  log_posterior is not affected: a NaN
+        parameter fails the box prior (-inf), as in ref: log_posterior.py:63-64."""
+        if not np.isfinite(X).all():
+            raise ValueError("Input X contains NaN or infinity.")
+        return X
+
     def gp_predict(self, X):
         """(B,k) predictive means and variances of the k PCs (ref: emulation.py:494-499)."""
-        X = self._X(X)
+        X = self._finite(self._X(X))
         B = X.shape[0]
         mean = np.empty((B, self.k))
         var = np.empty((B, self.k))
@@ -99,7 +110,7 @@ class DeviceModel:
 
     def predict_full(self, X, n_div=None):
         """central_value (B,F), cov (B,F,F) as ref: emulation.py:466-548 (n_div defaults to B)."""
-        X = self._X(X)
+        X = self._finite(self._X(X))
         B = X.shape[0]
         cv = np.empty((B, self.F))
         cov = np.empty((B, self.F, self.F))

@@ -195,6 +195,29 @@ def test_argument_errors():
     dm.close()
 
 
+def test_non_finite_queries():
+    """predict refuses NaN / inf parameters the way sklearn's check_array does for the reference (ref: emulation.py:497);
+    log_posterior gives -inf for such a row -- it fails the box prior, ref: log_posterior.py:63-64 -- and the other rows
+    of the batch are what they are without it."""
+    g, model = _load("g2_rbf_noise")
+    dm = GU.device_model(model)
+    X = g["Xq"][:40].copy()
+    bad = X.copy()
+    bad[3, 2] = np.nan
+    bad[17, 0] = np.inf
+    with pytest.raises(ValueError):
+        dm.gp_predict(bad)
+    with pytest.raises(ValueError):
+        dm.predict_full(bad[:8])
+    dm.likelihood_setup(g["y_exp"], g["y_err"], g["lo"], g["hi"], 1.0)
+    lp_bad, lp = dm.logpost(bad), dm.logpost(X)
+    assert lp_bad[3] == -np.inf and lp_bad[17] == -np.inf
+    keep = np.ones(40, dtype=bool)
+    keep[[3, 17]] = False
+    np.testing.assert_array_equal(lp_bad[keep], lp[keep])
+    dm.close()
+
+
 def test_one_hip_runtime_with_torch_imported_after_the_library():
     """libgpemu loaded first must not leave the process with two HIP runtimes (torch bundles its own
     libamdhip64): torch imported afterwards still sees the GPU."""
