@@ -579,8 +579,8 @@ int gpemu_sampler_run(gpemu_sampler *s, int64_t steps, int store_chain) {
   GP_ARG(s && steps >= 0, "sampler / steps");
   GP_HIP(hipSetDevice(s->device));
   hipStream_t st = s->stream;
-  // On one GPU the three-launch half-step below is the faster form (0.262 vs 0.265 ms per step at C3: the fused
-  // front kernel runs its likelihood and cross-kernel phases back to back); the two-launch form at one rank is
+  // On one GPU the three-launch half-step below is the faster form (0.2275 vs 0.2516 ms per step at C3,
+  // tools/time_fused_single.py: the fused front kernel runs its likelihood and cross-kernel phases back to back); the two-launch form at one rank is
   // reachable through gpemu_sampler_run_peer with a one-rank import (test_fused_run_world1_equals_three_launch_run).
   if (store_chain) GP_TRY(ensure_chain(s, s->chain_len + steps));
   for (int64_t it = 0; it < steps; ++it) {
