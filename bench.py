@@ -347,6 +347,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fit", action="store_true", help="skip the fit-side legs (fit_c5, fit_c3)")
+    ap.add_argument("--no-predict", action="store_true", help="skip metric 2 (gp_predict); for kernel profiles of the sampler alone")
     ap.add_argument("--transport", default="both", choices=["both", "peer", "rccl", "torch"],
                     help="N > 1: how the new log-probabilities are exchanged; 'both' times the RCCL all-gather run and "
                          "the peer-store run in one invocation and reports the faster as `value`")
@@ -522,7 +523,7 @@ def main():
             weak = {"error": repr(e)}
 
     predict = None
-    if rank == 0:
+    if rank == 0 and not args.no_predict:
         try:
             predict = measure_predict(dm)
         except Exception as e:

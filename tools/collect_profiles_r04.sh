@@ -10,14 +10,14 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo bench done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-fit > $OUT/stats_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-fit --no-predict > $OUT/stats_bench.log 2>&1
 echo stats_bench done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_predict -- python3 $R/tools/prof_predict.py 1024 200 > $OUT/stats_predict.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_predict -- python3 $R/tools/prof_predict.py 1024 3 > $OUT/pmc_write_predict.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_predict -- python3 $R/tools/prof_predict.py 1024 3 > $OUT/pmc_fetch_predict.log 2>&1
 echo predict done
-for w in 2 4 8; do python3 $R/bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-fit --emulate-world $w 2>/dev/null | grep '^{' >> $OUT/emulated_sharding.jsonl; done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_emu8 -- python3 $R/bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-fit --emulate-world 8 > $OUT/stats_emu8.log 2>&1
+for w in 2 4 8; do python3 $R/bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-fit --no-predict --emulate-world $w 2>/dev/null | grep '^{' >> $OUT/emulated_sharding.jsonl; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_emu8 -- python3 $R/bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-fit --no-predict --emulate-world 8 > $OUT/stats_emu8.log 2>&1
 echo emu done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_512 -- python3 $R/tools/prof_driver.py 512 5 > $OUT/pmc_fetch_512.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_512 -- python3 $R/tools/prof_driver.py 512 5 > $OUT/pmc_write_512.log 2>&1
