@@ -62,6 +62,32 @@ int main(int argc, char **argv) {
     g.M = g.N = n - 256; g.K = 256; g.alpha = -1.0; g.beta = 1.0; g.lower_only = 1;
     report("syrk   rank-256 update of (Np - 256)^2, lower tiles", g, false, false, 1, (double)g.M * g.M * 256.0);
   }
+  {  // the same update with the tile -> XCD ownership of C shifting from launch to launch, as it does in the blocked
+     // Cholesky (the trailing matrix shrinks by one panel per update): every tile of C is then read-modify-written by a
+     // different XCD than the one whose L2 holds it from the launch before
+    hipEvent_t ea, eb;
+    hipEventCreate(&ea); hipEventCreate(&eb);
+    for (int shift = 0; shift < 2; ++shift) {
+      const int reps = 10;
+      auto one = [&](int r) {
+        const int64_t off = shift ? (int64_t)(r & 3) * 64 : 0;      // start the trailing matrix 0..3 tile rows further down
+        GemmArgs g; g.A = A + (256 + off) * Np; g.B = A + (256 + off) * Np; g.C = C + off * Np + off; g.lda = g.ldb = g.ldc = Np;
+        g.M = g.N = n - 256 - 256; g.K = 256; g.alpha = -1.0; g.beta = 1.0; g.lower_only = 1;
+        launch_gemm(g, false, false, 1, nullptr);
+      };
+      one(0); one(1); one(2); one(3);
+      hipDeviceSynchronize();
+      hipEventRecord(ea, nullptr);
+      for (int r = 0; r < reps; ++r) one(r);
+      hipEventRecord(eb, nullptr);
+      hipEventSynchronize(eb);
+      float ms = 0;
+      hipEventElapsedTime(&ms, ea, eb);
+      ms /= reps;
+      const double flop = (double)(n - 512) * (n - 512) * 256.0;
+      printf("%-58s %8.3f ms  %6.2f TFLOP/s  (%.3f of peak)\n", shift ? "syrk   rank-256, tile ownership shifting every launch" : "syrk   rank-256, same ownership every launch", ms, flop / ms / 1e9, flop / ms / 1e9 / 78.6);
+    }
+  }
   {  // panel solve and in-panel update
     GemmArgs g; g.A = A + 64 * Np; g.B = B; g.C = C + 64 * Np; g.lda = Np; g.ldb = 64; g.ldc = Np;
     g.M = n - 64; g.N = 64; g.K = 64;
