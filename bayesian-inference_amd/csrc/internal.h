@@ -37,7 +37,8 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 constexpr int DPAD = 8;        // parameter dimensions padded to 8 (reference uses d = 6 or 7)
 constexpr int TILE = 128;      // row / column tile of the triangular GEMM
 constexpr int KSTAR_ROWS_BIG = 64;    // training rows per workgroup of the cross-kernel: batches of more than 256 columns
-constexpr int KSTAR_ROWS_SMALL = 32;  // ... and of at most 256
+constexpr int KSTAR_ROWS_SMALL = 32;  // ... and of at most KSTAR_SMALL_MAX
+constexpr int KSTAR_SMALL_MAX = 128;  // (256 until round 4: at 129 .. 256 columns the 32-row form is 1 280 front workgroups against 768 resident)
 
 // ---- device model -----------------------------------------------------------------------------
 struct Workspace {

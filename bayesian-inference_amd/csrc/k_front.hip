@@ -488,7 +488,7 @@ static const int *front_perm_for(gpemu_sampler *s, int g, int64_t cnt, int wg0, 
 
 // workgroups a front launch needs for `cnt` proposals of this rank
 static int64_t front_grid(const gpemu_sampler *s, int64_t cnt) {
-  const int rows_per_wg = cnt <= 256 ? KSTAR_ROWS_SMALL : KSTAR_ROWS_BIG;
+  const int rows_per_wg = cnt <= KSTAR_SMALL_MAX ? KSTAR_ROWS_SMALL : KSTAR_ROWS_BIG;
   const int64_t ncolblk = ((cnt <= 64) ? 64 : round_up(cnt, TILE)) / 64;
   int64_t nkstar = 0;
   for (const gpemu_model *m : s->groups) nkstar += ncolblk * (m->Npad / rows_per_wg) * m->k;
@@ -509,7 +509,7 @@ bool front_eligible(const gpemu_sampler *s) {
 static bool front_fits(const gpemu_sampler *s, int64_t cnt) {
   if (s->device_share <= 1) return true;
   cnt = std::max<int64_t>(cnt, 1);
-  return front_grid(s, cnt) * s->device_share <= front_capacity(s, cnt <= 256);
+  return front_grid(s, cnt) * s->device_share <= front_capacity(s, cnt <= KSTAR_SMALL_MAX);
 }
 
 bool front_eligible_for(const gpemu_sampler *s, int world) {
@@ -543,7 +543,7 @@ static int launch_front(gpemu_sampler *s, const Pending &pv, bool have_next, int
   fa.ngroups = ng;
   fa.lds_k = front_lds_k(s);
   fa.d = (int)s->d; fa.W = (int)W;
-  const bool small = cnt <= 256;
+  const bool small = cnt <= KSTAR_SMALL_MAX;
   const int rows_per_wg = small ? KSTAR_ROWS_SMALL : KSTAR_ROWS_BIG;
   const int64_t ncols = (cnt <= 64) ? 64 : round_up(cnt, TILE);
   fa.ncolblk = (int)(ncols / 64);

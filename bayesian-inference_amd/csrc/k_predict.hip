@@ -153,7 +153,7 @@ int launch_kstar(gpemu_model *m, int64_t B, double *dXq, hipStream_t st, const P
   // round_up(B, TILE) must be finite (the sampler's proposal buffer zeroes them)
   Workspace &w = m->ws;
   const int64_t Bv = m->variant_B > 0 ? m->variant_B : B;   // a chain stacked with others is evaluated as it would be alone
-  const bool small = Bv <= 256;                      // few columns: more, shorter workgroups
+  const bool small = Bv <= KSTAR_SMALL_MAX;          // few columns: more, shorter workgroups
   const int rows_per_wg = small ? KSTAR_ROWS_SMALL : KSTAR_ROWS_BIG;
   w.cur_nchunk = (int)(m->Npad / rows_per_wg);
   // column blocks of 64 queries: whole 128-column tiles for the triangular GEMM, except that a batch of at most
