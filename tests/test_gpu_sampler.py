@@ -268,6 +268,121 @@ def test_phase_api_slices_of_eight_ranks_equal_single(world):
     a.close(); ref.close(); dm.close()
 
 
+# ---- BASELINE configs[3] ("C4") at its full size: the C3 model, 1024 walkers, shares of 128 / 64 proposals ----------
+def _c4_reference(dm, prob, steps):
+    from gpemu import synthetic
+    from gpemu.sampler import DeviceSampler
+    W = 1024
+    ref = DeviceSampler([dm], W, seed=5)
+    ref.set_state(synthetic.make_walkers(W, seed=1, lo=prob["lo"], hi=prob["hi"]))
+    ref.run(steps)
+    c, l = ref.get_chain()
+    nacc = ref.counts()[0]
+    ref.close()
+    return c, l, nacc
+
+
+def _c4_compare(chain, lps, cref, lref):
+    """A rank's share (64 or 128 columns) goes through the small-batch GEMM, the undivided half (512 columns) through
+    the large-batch one: different summation order of the 64-row partial sums, log-probabilities equal to ~1e-13
+    relative.  The positions depend on them only through the accept decisions: identical."""
+    np.testing.assert_array_equal(chain, cref)
+    np.testing.assert_allclose(lps, lref, rtol=1e-11, atol=0)
+
+
+def test_c4_full_size_eight_slices_equal_single_gpu_chain():
+    """1024 walkers of the C3 model cut into the 8 shares of configs[3] (64 proposals per rank and half-step) through the
+    per-phase C ABI, one process playing the eight ranks in turn: the chain of the undivided run."""
+    import ctypes as C
+    import torch
+    from gpemu import _lib, synthetic
+    from gpemu.sampler import DeviceSampler, shard_bounds
+    L = _lib.lib()
+    model, prob, _ = GU.fixed_theta_model(1000, 500, 10, seed=0)
+    dm = GU.device_model(model)
+    dm.likelihood_setup(prob["y_exp"], prob["y_err"], prob["lo"], prob["hi"], 1.0)
+    W, steps, world = 1024, 4, 8
+    cref, lref, _ = _c4_reference(dm, prob, steps)
+    a = DeviceSampler([dm], W, seed=5)
+    a.set_state(synthetic.make_walkers(W, seed=1, lo=prob["lo"], hi=prob["hi"]))
+    dev = torch.device("cuda", a.device)
+    _lib.check(L.gpemu_sampler_reserve_chain(a._h, steps))
+    for _ in range(steps):
+        _lib.check(L.gpemu_sampler_begin_step(a._h))
+        for h in (0, 1):
+            n = a.ns[h]
+            per = shard_bounds(n, world, 0)[2]
+            assert per == 64
+            full = torch.zeros(per * world, dtype=torch.float64, device=dev)
+            for r in range(world):
+                lo, hi, _ = shard_bounds(n, world, r)
+                mine = torch.zeros(per, dtype=torch.float64, device=dev)
+                _lib.check(L.gpemu_sampler_half_propose_eval(a._h, h, lo, hi, C.c_void_p(mine.data_ptr())))
+                torch.cuda.synchronize()
+                full[r * per:(r + 1) * per] = mine
+            _lib.check(L.gpemu_sampler_half_accept(a._h, h, C.c_void_p(full.data_ptr()), 1))
+        _lib.check(L.gpemu_sampler_end_step(a._h, 1))
+    assert L.gpemu_sampler_check(a._h) == 0
+    ca, la = a.get_chain()
+    _c4_compare(ca, la, cref, lref)
+    a.close(); dm.close()
+
+
+def _c4_worker(rank, world, port, out_dir, transport):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gpemu import synthetic
+    from gpemu.sampler import DeviceSampler
+    model, prob, _ = GU.fixed_theta_model(1000, 500, 10, seed=0)
+    dm = GU.device_model(model)
+    dm.likelihood_setup(prob["y_exp"], prob["y_err"], prob["lo"], prob["hi"], 1.0)
+    W = 1024
+    ds = DeviceSampler([dm], W, seed=5)
+    ds.set_state(synthetic.make_walkers(W, seed=1, lo=prob["lo"], hi=prob["hi"]))
+    for n_steps in (1, 3):
+        ds.run_sharded(n_steps, transport=transport)
+    chain, lps = ds.get_chain()
+    np.save(os.path.join(out_dir, f"chain_{rank}.npy"), chain)
+    np.save(os.path.join(out_dir, f"lp_{rank}.npy"), lps)
+    np.save(os.path.join(out_dir, f"nacc_{rank}.npy"), ds.counts()[0])
+    with open(os.path.join(out_dir, f"transport_{rank}.txt"), "w") as fh:
+        fh.write(ds.last_transport)
+    dist.barrier()
+    dist.destroy_process_group()
+    ds.close()
+    dm.close()
+
+
+@pytest.mark.parametrize("transport", ["torch", "peer"])
+def test_c4_full_size_four_ranks_equal_single_gpu_chain(tmp_path, transport):
+    """configs[3] as processes: 4 ranks (the pool's limit of GPU processes per card is 6) x 128 proposals of the
+    1024-walker C3 job on the one GPU.  "torch": per-phase C ABI + all-gather.  "peer": four full-size front launches do
+    not fit one device together, so the ranks must agree on the fall-back (no time-out) and still end with the
+    same chain -- on a node with one rank per GPU the fused run is taken instead."""
+    import os
+    import torch.multiprocessing as mp
+    world = 4
+    port = 30200 + (os.getpid() % 1500) + (3 if transport == "peer" else 0)
+    mp.spawn(_c4_worker, args=(world, port, str(tmp_path), transport), nprocs=world, join=True)
+    chains = [np.load(tmp_path / f"chain_{r}.npy") for r in range(world)]
+    lps = [np.load(tmp_path / f"lp_{r}.npy") for r in range(world)]
+    taken = [(tmp_path / f"transport_{r}.txt").read_text() for r in range(world)]
+    assert len(set(taken)) == 1, taken                         # every rank ran the same transport
+    for r in range(1, world):
+        np.testing.assert_array_equal(chains[0], chains[r])    # and holds the same ensemble, bit for bit
+        np.testing.assert_array_equal(lps[0], lps[r])
+    model, prob, _ = GU.fixed_theta_model(1000, 500, 10, seed=0)
+    dm = GU.device_model(model)
+    dm.likelihood_setup(prob["y_exp"], prob["y_err"], prob["lo"], prob["hi"], 1.0)
+    cref, lref, nacc = _c4_reference(dm, prob, 4)
+    _c4_compare(chains[0], lps[0], cref, lref)
+    np.testing.assert_array_equal(nacc, np.load(tmp_path / "nacc_0.npy"))
+    dm.close()
+
+
 def _rccl_worker(rank, port, out_dir):
     import os
     import torch
