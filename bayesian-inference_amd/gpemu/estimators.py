@@ -442,40 +442,84 @@ def fit_batch_size(n_design, requested=None, device=None):
     return max(1, min(int(requested), int(budget // (6 * 8 * n_pad * n_pad))))
 
 
-def _lockstep_minimise(dfit, problems, bounds, max_batch):
-    """``problems``: list of (target y, start theta).  All minimisations advance together on one host thread: every
-    round takes the next requested point of each run in flight (at most ``max_batch``), evaluates them in ONE launch
-    chain (``gpemu_fit_lml_batch``) and hands the values back.  Returns [(theta, minimum)] in the order given."""
+def _lockstep_minimise(dfit, problems, bounds, max_batch, groups=None):
+    """``problems``: list of (target y, start theta).  All minimisations advance together: every round takes the next
+    requested point of each run of a group (at most ``max_batch``), evaluates them in ONE launch chain
+    (``gpemu_fit_lml_batch``) and hands the values back.  Returns [(theta, minimum)] in the order given.
+
+    ``groups`` = 2 (default when there is more than one batch of problems; GPEMU_FIT_GROUPS): two groups of runs
+    alternate -- while the device evaluates the points of one (a worker thread inside the C call, the GIL released), this
+    thread hands the other group's values back and advances its optimisers to their next requests.  At C3 the host side
+    of a round (64 ``setulb`` steps) is a quarter of the evaluation time, which was added to it before.  The runs are
+    independent and a batched evaluation has the bits of a single one, so every run visits the points it visits alone,
+    whatever group it is in."""
+    import concurrent.futures
+    if groups is None:
+        groups = int(os.environ.get("GPEMU_FIT_GROUPS", "2"))
+    groups = max(1, min(int(groups), 2)) if len(problems) > max_batch else 1
     runs = [None] * len(problems)
     results = [None] * len(problems)
-    nxt, active = 0, []
-    while True:
-        while len(active) < max_batch and nxt < len(problems):
-            runs[nxt] = _LbfgsbRun(problems[nxt][1], bounds)
-            active.append(nxt)
-            nxt += 1
-        if not active:
-            break
-        ask, still = [], []
-        for idx in active:
-            x = runs[idx].advance()
-            if x is None:
-                r = runs[idx]
-                if r.status != 0:
-                    warnings.warn(f"lbfgs failed to converge (status={r.status})", ConvergenceWarning)
-                results[idx] = (r.x, r.f)
-            else:
-                ask.append((idx, x))
-                still.append(idx)
-        active = still
-        if not ask:
-            continue
-        lml, grad, info = dfit.lml_batch(np.stack([problems[i][0] for i, _ in ask]), np.stack([x for _, x in ask]))
+    nxt = 0
+    active = [[] for _ in range(groups)]
+    pending = [None] * groups            # (future of the evaluation in flight, the points it was asked for)
+
+    def hand_back(g):
+        fut, ask = pending[g]
+        pending[g] = None
+        lml, grad, info = fut.result()
         for j, (idx, x) in enumerate(ask):
             if int(info[j]) != 0:       # skl _gpr.py:586-590: not positive definite -> +inf, zero gradient
                 runs[idx].supply(x, np.inf, np.zeros_like(x))
             else:
                 runs[idx].supply(x, -lml[j], -grad[j])
+
+    def advance(g):
+        """refill the group, run its optimisers to their next requests; the points asked for (may be empty)"""
+        nonlocal nxt
+        while True:
+            while len(active[g]) < max_batch and nxt < len(problems):
+                runs[nxt] = _LbfgsbRun(problems[nxt][1], bounds)
+                active[g].append(nxt)
+                nxt += 1
+            ask, still = [], []
+            for idx in active[g]:
+                x = runs[idx].advance()
+                if x is None:
+                    r = runs[idx]
+                    if r.status != 0:
+                        warnings.warn(f"lbfgs failed to converge (status={r.status})", ConvergenceWarning)
+                    results[idx] = (r.x, r.f)
+                else:
+                    ask.append((idx, x))
+                    still.append(idx)
+            active[g] = still
+            if ask or nxt >= len(problems):
+                return ask
+            # every run of the group finished in this round and there are problems left: start them right away
+
+    # The device thread needs the interpreter lock for a few microseconds between two evaluations, while this thread is
+    # in the middle of a round of optimiser steps: with the default switch interval (5 ms) it would get it when the round
+    # is over, the device idle meanwhile.
+    import sys
+    switch_interval = sys.getswitchinterval()
+    if groups > 1:
+        sys.setswitchinterval(2e-5)
+    try:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=1) as device:     # one evaluation on the device at a time
+            g = 0
+            while True:
+                if pending[g] is not None:
+                    hand_back(g)
+                ask = advance(g)
+                if ask:
+                    ys = np.stack([problems[i][0] for i, _ in ask])
+                    xs = np.stack([x for _, x in ask])
+                    pending[g] = (device.submit(dfit.lml_batch, ys, xs), ask)
+                if all(p is None for p in pending) and not any(active) and nxt >= len(problems):
+                    break
+                g = (g + 1) % groups
+    finally:
+        sys.setswitchinterval(switch_interval)
     return results
 
 
@@ -548,7 +592,7 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
     try:
         if n_threads > 1 and optimise and _setulb_driver_ok():
             # one host thread drives all L-BFGS-B runs through the routine's reverse-communication interface
-            driver = "lockstep (scipy.optimize._lbfgsb.setulb, one host thread)"
+            driver = "lockstep (scipy.optimize._lbfgsb.setulb, one host thread, two groups alternating on the device)"
             optima = _lockstep_minimise(shared, [(columns[i], starts[i][j]) for i, j in tasks], kk.bounds, n_threads)
         else:
             driver = ("sequential (scipy.optimize.minimize)" if n_threads == 1 else

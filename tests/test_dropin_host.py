@@ -249,3 +249,50 @@ def test_lbfgsb_lockstep_driver_equals_scipy_minimize():
         assert len(calls) == len(ref_calls) and all(np.array_equal(a, c) for a, c in zip(calls, ref_calls))
         np.testing.assert_array_equal(run.x, ref.x)
         assert run.f == ref.fun and run.nit == ref.nit and run.nfev == ref.nfev and run.status == ref.status
+
+
+def test_lockstep_groups_alternating_on_the_device_give_the_sequential_results():
+    """_lockstep_minimise with two groups of runs alternating on the "device" (a host stand-in evaluating an analytic
+    objective per target, called from the driver's worker thread): every run ends where scipy.optimize.minimize ends
+    on its own, the results come back in the order given, and every batch respects max_batch."""
+    import threading
+    import scipy.optimize
+    from gpemu import estimators as E
+    if not E._setulb_driver_ok():
+        pytest.skip("scipy's setulb has another signature here")
+    rng = np.random.default_rng(4)
+    n, d = 23, 5
+    mats = [(lambda M: M @ M.T + np.eye(d))(rng.normal(size=(d, d))) for _ in range(n)]
+    vecs = [rng.normal(size=d) for _ in range(n)]
+    bounds = np.array([[-1.5, 1.0]] * d)
+    starts = [rng.uniform(-1.5, 1.0, d) for _ in range(n)]
+
+    def objective(t, x):        # minimised; the driver is handed (lml, grad) = (-f, -g)
+        A, b = mats[t], vecs[t]
+        return 0.5 * x @ A @ x - b @ x + 0.05 * np.sum(x ** 4), A @ x - b + 0.2 * x ** 3
+
+    class Device:
+        def __init__(self):
+            self.sizes, self.threads = [], set()
+
+        def lml_batch(self, ys, thetas):
+            self.sizes.append(len(ys))
+            self.threads.add(threading.get_ident())
+            out = [objective(int(y[0]), x) for y, x in zip(ys, thetas)]
+            return (np.array([-f for f, _ in out]), np.array([-g for _, g in out]), np.zeros(len(ys), dtype=np.int32))
+
+    problems = [(np.array([float(t)]), starts[t]) for t in range(n)]
+    ref = [scipy.optimize.minimize(lambda x, t=t: objective(t, x), starts[t], method="L-BFGS-B", jac=True, bounds=bounds)
+           for t in range(n)]
+    for groups in (1, 2):
+        dev = Device()
+        got = E._lockstep_minimise(dev, problems, bounds, max_batch=4, groups=groups)
+        assert max(dev.sizes) <= 4 and len(got) == n
+        assert threading.get_ident() not in dev.threads            # evaluated on the driver's device thread
+        for t in range(n):
+            np.testing.assert_array_equal(got[t][0], ref[t].x)
+            assert got[t][1] == ref[t].fun
+    # fewer problems than one batch: one group, nothing to alternate with
+    dev = Device()
+    got = E._lockstep_minimise(dev, problems[:3], bounds, max_batch=4)
+    assert all(np.array_equal(got[t][0], ref[t].x) for t in range(3))
