@@ -47,7 +47,7 @@ struct FrontGroup {
 struct FrontArgs {
   FrontGroup grp[FRONT_MAX_GROUPS];
   int ngroups;
-  int lds_k;                           // largest k > 16 among the groups (0: none): that likelihood's matrix is in LDS
+  int lds_k;                           // largest k > 32 among the groups (0: none): that likelihood's matrix is in LDS
   int d, W;
   int ncolblk;                         // cross-kernel workgroups per group: (column block, row chunk, PC)
   int nkstar, nks;                     // all groups' / nks = max(nkstar, likelihood workgroups): the state workgroups follow
@@ -168,23 +168,26 @@ __device__ __forceinline__ void state_after_prev(const FrontArgs &fa, int x, dou
   lp = acc ? nlp : oldlp;
 }
 
-// one group's low-rank log-likelihood of proposal b (a wave per proposal), k <= 16: the arithmetic of
-// loglik_lowrank_kernel<KMAX>
+// one group's low-rank log-likelihood of proposal b (a wave per proposal), k <= 32: the arithmetic of
+// loglik_lowrank_kernel<KMAX> (whose value does not depend on KMAX: one instantiation serves 17 <= k <= 32 here)
 template <int KMAX>
 __device__ __forceinline__ double front_loglik(const FrontGroup &gr, bool inside, int64_t b, int lane) {
-  double gpre[KMAX];
+  constexpr bool PRE = KMAX <= 16;
+  double gpre[PRE ? KMAX : 1];
+  if (PRE) {
 #pragma unroll
-  for (int q = 0; q < KMAX; ++q) gpre[q] = (q < gr.k && lane < gr.k) ? gr.G[q * gr.k + lane] : 0.0;
+    for (int q = 0; q < KMAX; ++q) gpre[q] = (q < gr.k && lane < gr.k) ? gr.G[q * gr.k + lane] : 0.0;
+  }
   const double gl_pre = (lane < gr.k) ? gr.g0[lane] : 0.0;
   const double sc0_pre = gr.scal[0], sc1_pre = gr.scal[1];
   double mu, sd;
-  walker_mean_sd<16>(gr.mean_part_prev, gr.vsq_part, gr.kdiag, nullptr, nullptr, b, gr.Bcap, gr.k, gr.nchunk_prev,
-                     gr.nrb_prev, lane, mu, sd);
-  return walker_loglik_lowrank<KMAX>(inside, mu, sd, gpre, gl_pre, sc0_pre, sc1_pre, gr.G, gr.g0, gr.scal, gr.k,
-                                     gr.nblk, lane);
+  walker_mean_sd<(KMAX <= 16 ? 16 : 32)>(gr.mean_part_prev, gr.vsq_part, gr.kdiag, nullptr, nullptr, b, gr.Bcap, gr.k,
+                                         gr.nchunk_prev, gr.nrb_prev, lane, mu, sd);
+  return walker_loglik_lowrank<KMAX, PRE>(inside, mu, sd, gpre, gl_pre, sc0_pre, sc1_pre, gr.G, gr.g0, gr.scal, gr.k,
+                                          gr.nblk, lane);
 }
 
-// 16 < k <= 64: the arithmetic of loglik_lowrank_lds_kernel, the wave's k x (k + 1) matrix in `M`
+// 32 < k <= 64: the arithmetic of loglik_lowrank_lds_kernel, the wave's k x (k + 1) matrix in `M`
 __device__ __forceinline__ double front_loglik_lds(const FrontGroup &gr, bool inside, int64_t b, int lane, double *M) {
   double mu, sd;
   if (gr.k <= 32)
@@ -215,13 +218,16 @@ __device__ __forceinline__ double front_kstar_block(const FrontGroup &gk, const 
   }
 }
 
-template <int JTW>   // j-tiles per wave of the cross-kernel workgroups: 1 = 32 training rows per workgroup, 2 = 64
-__global__ __launch_bounds__(256, 2) void front_kernel(FrontArgs fa) {
+// JTW: j-tiles per wave of the cross-kernel workgroups: 1 = 32 training rows per workgroup, 2 = 64.  KBIG: a group has
+// 17 ... 32 PCs -- its likelihood in registers like the smaller ones (walker_loglik_lowrank<32>: 256 VGPRs; the
+// instantiation without it keeps the 168 of the C3-sized run)
+template <int JTW, bool KBIG>
+__global__ __launch_bounds__(256, 3) void front_kernel(FrontArgs fa) {
   __shared__ double s_tab[1 << KSTAR_TB];
   __shared__ __attribute__((aligned(16))) double s_q[64 * DPAD];
   __shared__ double s_eff[2][64][DPAD];
   __shared__ double red[4 * 64];
-  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];   // [4 waves][lds_k (lds_k + 1)]: likelihood, k > 16
+  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];   // [4 waves][lds_k (lds_k + 1)]: likelihood, k > 32
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = blockIdx.x;
@@ -284,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void front_kernel(FrontArgs fa) {
         else if (gr.k <= 8) lp = front_loglik<8>(gr, inside, i, lane);
         else if (gr.k <= 12) lp = front_loglik<12>(gr, inside, i, lane);
         else if (gr.k <= 16) lp = front_loglik<16>(gr, inside, i, lane);
+        else if (KBIG && gr.k <= 32) lp = front_loglik<32>(gr, inside, i, lane);
         else lp = front_loglik_lds(gr, inside, i, lane, dyn_lds + (size_t)wave * fa.lds_k * (fa.lds_k + 1));
         total = (t == 0) ? lp : lp + total;
       }
@@ -417,18 +424,27 @@ static int peer_timeout_polls() {        // read per launch: a getenv, nothing n
 static int front_lds_k(const gpemu_sampler *s) {
   int lds_k = 0;
   for (const gpemu_model *m : s->groups)
-    if (m->k > 16) lds_k = std::max(lds_k, (int)m->k);
+    if (m->k > 32) lds_k = std::max(lds_k, (int)m->k);
   return lds_k;
 }
 static size_t front_dyn_lds(const gpemu_sampler *s) {
   const int lds_k = front_lds_k(s);
   return sizeof(double) * 4 * (size_t)lds_k * (lds_k + 1);
 }
+static bool front_kbig(const gpemu_sampler *s) {
+  for (const gpemu_model *m : s->groups)
+    if (m->k > 16 && m->k <= 32) return true;
+  return false;
+}
+static const void *front_kernel_ptr(bool small, bool kbig) {
+  if (small) return kbig ? (const void *)front_kernel<1, true> : (const void *)front_kernel<1, false>;
+  return kbig ? (const void *)front_kernel<2, true> : (const void *)front_kernel<2, false>;
+}
 static int front_set_lds_limit() {
   static bool attr_set = false;
   if (!attr_set) {
-    GP_HIP(hipFuncSetAttribute((const void *)front_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-    GP_HIP(hipFuncSetAttribute((const void *)front_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+    for (int v = 0; v < 4; ++v)
+      GP_HIP(hipFuncSetAttribute(front_kernel_ptr(v & 1, v & 2), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
     attr_set = true;
   }
   return GPEMU_OK;
@@ -438,8 +454,12 @@ static int64_t front_capacity(const gpemu_sampler *s, bool small) {
   const size_t dyn = front_dyn_lds(s);
   if (dyn > 40 * 1024 && front_set_lds_limit() != GPEMU_OK) return 0;
   int per_cu = 0;
-  const hipError_t e = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, front_kernel<1>, 256, dyn)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, front_kernel<2>, 256, dyn);
+  const bool kbig = front_kbig(s);
+  hipError_t e;
+  if (small) e = kbig ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, front_kernel<1, true>, 256, dyn)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, front_kernel<1, false>, 256, dyn);
+  else e = kbig ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, front_kernel<2, true>, 256, dyn)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, front_kernel<2, false>, 256, dyn);
   if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return (int64_t)per_cu * s->groups[0]->num_cu;
 }
@@ -631,8 +651,11 @@ static int launch_front(gpemu_sampler *s, const Pending &pv, bool have_next, int
   const size_t dyn = front_dyn_lds(s);
   if (dyn > 40 * 1024 && front_set_lds_limit() != GPEMU_OK) return GPEMU_ERR_HIP;
   const int pe0 = prof_mark(m0, st);
-  if (small) hipLaunchKernelGGL((front_kernel<1>), grid, block, dyn, st, fa);
-  else hipLaunchKernelGGL((front_kernel<2>), grid, block, dyn, st, fa);
+  const bool kbig = front_kbig(s);
+  if (small && kbig) hipLaunchKernelGGL((front_kernel<1, true>), grid, block, dyn, st, fa);
+  else if (small) hipLaunchKernelGGL((front_kernel<1, false>), grid, block, dyn, st, fa);
+  else if (kbig) hipLaunchKernelGGL((front_kernel<2, true>), grid, block, dyn, st, fa);
+  else hipLaunchKernelGGL((front_kernel<2, false>), grid, block, dyn, st, fa);
   GP_HIP(hipGetLastError());
   prof_pair(m0, 1, pe0, prof_mark(m0, st));
   // bookkeeping

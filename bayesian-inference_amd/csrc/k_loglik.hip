@@ -174,9 +174,10 @@ int launch_lik_setup(gpemu_model *m, const std::vector<int> &hstart, double *dA,
   return rc;
 }
 
-// k <= KMAX <= 16.  The k x k matrix M = I + D^1/2 G D^1/2 is padded to KMAX x KMAX with the identity, so
+// k <= KMAX <= 32.  The k x k matrix M = I + D^1/2 G D^1/2 is padded to KMAX x KMAX with the identity, so
 // the factorisation below is branch-free; lane = row, the row lives in registers, and every cross-lane
-// operand is a v_readlane of a compile-time lane.
+// operand is a v_readlane of a compile-time lane.  (Round 4: KMAX 20 ... 32 -- the shipped analysis has a group of 25
+// PCs, which took the LDS form below: 39.9 us per launch at 100 proposals against 7.7 us for 11 PCs here.)
 template <int KMAX>
 __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
     const double *__restrict__ Xq, const double *__restrict__ lo, const double *__restrict__ hi,
@@ -198,9 +199,12 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
   // everything that does not depend on the GP stage is requested first: the accept operands (a dependent
   // index -> state chain) and the first observable block's constants
   const AcceptOperands ao = load_accept_operands(Xq, b, lane, aa);
-  double gpre[KMAX];
+  constexpr bool PRE = KMAX <= 16;
+  double gpre[PRE ? KMAX : 1];
+  if (PRE) {
 #pragma unroll
-  for (int q = 0; q < KMAX; ++q) gpre[q] = (q < k && lane < k) ? G[q * k + lane] : 0.0;
+    for (int q = 0; q < KMAX; ++q) gpre[q] = (q < k && lane < k) ? G[q * k + lane] : 0.0;
+  }
   const double gl_pre = (lane < k) ? g0[lane] : 0.0;
   const double sc0_pre = scal[0], sc1_pre = scal[1];
 
@@ -209,12 +213,12 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
   const bool inside = __all(in);
 
   double mu, sd;
-  walker_mean_sd<16>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
-  const double total = walker_loglik_lowrank<KMAX>(inside, mu, sd, gpre, gl_pre, sc0_pre, sc1_pre, G, g0, scal, k, nblk, lane);
+  walker_mean_sd<(KMAX <= 16 ? 16 : 32)>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
+  const double total = walker_loglik_lowrank<KMAX, PRE>(inside, mu, sd, gpre, gl_pre, sc0_pre, sc1_pre, G, g0, scal, k, nblk, lane);
   finish_walker(total, out, b, d, lane, accumulate, aa, ao);
 }
 
-// General k (17..64): the k x k matrix of each walker lives in LDS (one wave per walker, lane = row).
+// General k (33..64): the k x k matrix of each walker lives in LDS (one wave per walker, lane = row).
 __global__ __launch_bounds__(256) void loglik_lowrank_lds_kernel(
     const double *__restrict__ Xq, const double *__restrict__ lo, const double *__restrict__ hi,
     const double *__restrict__ mean_part, const double *__restrict__ vsq_part,
@@ -262,6 +266,14 @@ int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq, double *
     GP_LAUNCH_LL(12);
   } else if (k <= 16) {
     GP_LAUNCH_LL(16);
+  } else if (k <= 20) {
+    GP_LAUNCH_LL(20);
+  } else if (k <= 24) {
+    GP_LAUNCH_LL(24);
+  } else if (k <= 28) {
+    GP_LAUNCH_LL(28);
+  } else if (k <= 32) {
+    GP_LAUNCH_LL(32);
   } else {
     size_t shm = sizeof(double) * 4 * (size_t)k * (k + 1);
     if (shm > 64 * 1024)

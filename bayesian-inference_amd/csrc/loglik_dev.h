@@ -118,11 +118,14 @@ __device__ __forceinline__ double sum_first_lanes(double v) {
 
 // Low-rank log-likelihood of one walker held by one wave (lane = PC index; see k_loglik.hip for the algebra):
 // `mu`, `sd` are this lane's predictive mean and standard deviation; `gpre`, `gl_pre`, `sc0_pre`, `sc1_pre` the first
-// observable block's constants, requested by the caller ahead of the GP partial sums.  k <= KMAX <= 16; the k x k
-// matrix M = I + D^1/2 G D^1/2 is padded to KMAX x KMAX with the identity so the factorisation is branch-free, row
-// `lane` lives in registers, every cross-lane operand is a v_readlane of a compile-time lane.  -inf outside the box.
-template <int KMAX>
-__device__ __forceinline__ double walker_loglik_lowrank(bool inside, double mu, double sd, const double (&gpre)[KMAX],
+// observable block's constants, requested by the caller ahead of the GP partial sums (PRE; without it `gpre` is not
+// read and the first block loads its row like the others: KMAX > 16, where the prefetched row would cost 2 KMAX
+// registers more).  k <= KMAX <= 32; the k x k matrix M = I + D^1/2 G D^1/2 is padded to KMAX x KMAX with the identity
+// so the factorisation is branch-free, row `lane` lives in registers, every cross-lane operand is a v_readlane of a
+// compile-time lane.  The padding adds exact zeros and pivots of exactly 1: the value does not depend on KMAX.
+// -inf outside the box.
+template <int KMAX, bool PRE = true>
+__device__ __forceinline__ double walker_loglik_lowrank(bool inside, double mu, double sd, const double *gpre,
                                                         double gl_pre, double sc0_pre, double sc1_pre,
                                                         const double *__restrict__ G, const double *__restrict__ g0,
                                                         const double *__restrict__ scal, int k, int nblk, int lane) {
@@ -134,11 +137,20 @@ __device__ __forceinline__ double walker_loglik_lowrank(bool inside, double mu, 
       // row `lane` of G_o (symmetric: read column-wise so that the wave's loads coalesce)
       double row[KMAX];
       double h = 0.0;
+      // KMAX > 16: every lane loads from a clamped, valid position and the select follows -- scalar base per q plus ONE
+      // vector offset, where the predicated form keeps an address per q in vector registers (2 KMAX of them)
+      const double *Gl = Go + ((lane < k) ? lane : k - 1);
+      // ... and the lane index is made opaque per block, or the KMAX unit-matrix terms (lane == q ? 1 : 0) are kept in
+      // 2 KMAX registers across the loop over the blocks (KMAX = 32: 262 -> 200 -> 136 VGPRs)
+      int lane_q = lane;
+      if (!PRE) asm volatile("" : "+v"(lane_q));
 #pragma unroll
       for (int q = 0; q < KMAX; ++q) {
-        const double gq = (o == 0) ? gpre[q] : ((q < k && lane < k) ? Go[q * k + lane] : 0.0);
+        double gq;
+        if (PRE) gq = (o == 0) ? gpre[q] : ((q < k && lane < k) ? Go[q * k + lane] : 0.0);
+        else gq = (q < k && lane < k) ? Gl[((q < k) ? q : k - 1) * k] : 0.0;
         h = fma(gq, readlane_f64(mu, q), h);
-        row[q] = ((lane == q) ? 1.0 : 0.0) + sd * gq * readlane_f64(sd, q);
+        row[q] = ((lane_q == q) ? 1.0 : 0.0) + sd * gq * readlane_f64(sd, q);
       }
       const double gl = (o == 0) ? gl_pre : ((lane < k) ? g0[(int64_t)o * k + lane] : 0.0);
       const double sc0 = (o == 0) ? sc0_pre : scal[2 * o], sc1 = (o == 0) ? sc1_pre : scal[2 * o + 1];
@@ -173,7 +185,7 @@ __device__ __forceinline__ double walker_loglik_lowrank(bool inside, double mu, 
   return total;
 }
 
-// General k (17..64), the k x k matrix of the walker in LDS (`M`, leading dimension `ldm` >= k + 1, private to the
+// General k (33..64), the k x k matrix of the walker in LDS (`M`, leading dimension `ldm` >= k + 1, private to the
 // wave): the arithmetic of loglik_lowrank_lds_kernel, shared with the fused front kernel so that a sharded run
 // reproduces the single-GPU chain bit for bit.
 __device__ __forceinline__ double walker_loglik_lowrank_lds(bool inside, double mu, double sd,

@@ -229,6 +229,8 @@ def _sharded_shipped_worker(rank, world, port, out_dir):
     np.save(os.path.join(out_dir, f"lp_{rank}.npy"), lps)
     with open(os.path.join(out_dir, f"transport_{rank}.txt"), "w") as f:
         f.write(str(ds.last_transport))
+    with open(os.path.join(out_dir, f"transport_info_{rank}.txt"), "w") as f:
+        f.write(repr(ds.transport_info))
     dist.barrier()
     dist.destroy_process_group()
     ds.close()
@@ -249,7 +251,8 @@ def test_shipped_two_rank_sharded_run_equals_single(tmp_path, monkeypatch):
     np.testing.assert_array_equal(c0, c1)
     np.testing.assert_array_equal(np.load(tmp_path / "lp_0.npy"), np.load(tmp_path / "lp_1.npy"))
     # three groups, one with 25 PCs: the fused peer run takes them since round 3
-    assert (tmp_path / "transport_0.txt").read_text() == (tmp_path / "transport_1.txt").read_text() == "peer"
+    assert (tmp_path / "transport_0.txt").read_text() == (tmp_path / "transport_1.txt").read_text() == "peer", \
+        (tmp_path / "transport_info_0.txt").read_text()
     g = GU.load("g7_shipped_config")
     names, mapping, block_start, cols = GU.g7_groups(g)
     models, dms = _device_models(g, names, block_start, cols)
