@@ -140,6 +140,38 @@ int logpost_padded(gpemu_model *m, int64_t B, double *dXq, double *dout, int acc
   if (rc != GPEMU_OK) return rc;
   return launch_loglik_lowrank(m, B, dXq, dout, accumulate, st, aa);
 }
+
+// Log-posterior of B padded query rows summed over ng >= 2 emulation groups with ONE launch per stage (cross-kernels,
+// triangular GEMMs, likelihoods + accept).  A sampler over the reference's shipped three groups (5 / 11 / 25 PCs, ~150
+// design points, 200 walkers) spends its half-step in nine ~6 us launches otherwise; the kernels' work per group is the
+// per-group launches' (same device functions, the groups' terms added in the same order): the same bits.
+// Eligible: at most 128 columns (the small-batch GEMM) evaluated as one chain, at most 32 PCs per group, one base kernel
+// and parameter count.  GPEMU_ERR_UNSUPPORTED otherwise (nothing launched): the caller goes group by group.
+int logpost_groups(gpemu_model *const *ms, int ng, int64_t B, double *dXq, double *dout, hipStream_t st,
+                   const AcceptArgs *aa, const ProposeArgs *pa) {
+  const bool off = getenv("GPEMU_NO_GROUP_MERGE") != nullptr;     // (tests: the per-group launches; read per call)
+  if (off || ng < 2 || ng > 8 || B < 1 || B > 128) return GPEMU_ERR_UNSUPPORTED;
+  if (aa && aa->chain_per != 0) return GPEMU_ERR_UNSUPPORTED;
+  for (int g = 0; g < ng; ++g) {
+    const gpemu_model *m = ms[g];
+    if (!m->lik_ready) { set_error("gpemu_likelihood_setup has not been called"); return GPEMU_ERR_STATE; }
+    const int64_t Bv = m->variant_B > 0 ? m->variant_B : B;
+    if (Bv > 128 || m->k > 32 || m->d != ms[0]->d || kstar_kind(m) != kstar_kind(ms[0]) || m->ksteps != ms[0]->ksteps ||
+        m->device != ms[0]->device || m->profiling)
+      return GPEMU_ERR_UNSUPPORTED;
+  }
+  for (int g = 0; g < ng; ++g) {
+    const int rc = ensure_workspace(ms[g], B);
+    if (rc != GPEMU_OK) return rc;
+  }
+  // (the GEMM's schedules first: the one step that can still say "unsupported", before anything is launched)
+  int rc = prepare_trmm_vsq_small_groups(ms, ng, B, st);
+  if (rc != GPEMU_OK) return rc;
+  rc = launch_kstar_groups(ms, ng, B, dXq, st, pa);
+  if (rc == GPEMU_OK) rc = launch_trmm_vsq_small_groups(ms, ng, B, st);
+  if (rc != GPEMU_OK) return rc;
+  return launch_loglik_groups(ms, ng, B, dXq, dout, 0, st, aa);
+}
 }  // namespace gpemu
 
 using namespace gpemu;

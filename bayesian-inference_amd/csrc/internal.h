@@ -189,6 +189,16 @@ int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq_padded, d
                           int accumulate, hipStream_t st, const AcceptArgs *aa = nullptr);
 int logpost_padded(gpemu_model *m, int64_t B, double *dXq, double *dout, int accumulate,
                    hipStream_t st, const AcceptArgs *aa = nullptr, const ProposeArgs *pa = nullptr);
+// several emulation groups, one launch per stage instead of one per group and stage (k_predict.hip, k_trmm_small.hip,
+// k_loglik.hip): the same arithmetic as the per-group launches.  logpost_groups returns GPEMU_ERR_UNSUPPORTED -- nothing
+// launched, no error set -- where the per-group launches must be used.
+int launch_kstar_groups(gpemu_model *const *ms, int ng, int64_t B, double *dXq_padded, hipStream_t st, const ProposeArgs *pa);
+int prepare_trmm_vsq_small_groups(gpemu_model *const *ms, int ng, int64_t B, hipStream_t st);   // the schedules only
+int launch_trmm_vsq_small_groups(gpemu_model *const *ms, int ng, int64_t B, hipStream_t st);
+int launch_loglik_groups(gpemu_model *const *ms, int ng, int64_t B, const double *dXq_padded, double *dout, int accumulate,
+                         hipStream_t st, const AcceptArgs *aa);
+int logpost_groups(gpemu_model *const *ms, int ng, int64_t B, double *dXq, double *dout, hipStream_t st,
+                   const AcceptArgs *aa, const ProposeArgs *pa);
 // fit-side building blocks (k_fit.hip): in-place blocked Cholesky of an Np x Np matrix (Np multiple of 64) with the
 // inverted diagonal blocks in Dinv [Np/64][64][64], and W = L^-1 from it (T: Np x Np scratch)
 // Optional look-ahead of the blocked Cholesky: a second (lower-priority) stream that applies a panel's update to the

@@ -248,6 +248,100 @@ __global__ __launch_bounds__(256) void loglik_lowrank_lds_kernel(
   finish_walker(total, out, b, d, lane, accumulate, aa, load_accept_operands(Xq, b, lane, aa));
 }
 
+// ---- several emulation groups in one launch ----------------------------------------------------------------------
+// The log-posterior of a proposal is the sum of its groups' log-likelihoods (block-diagonal covariance per group,
+// ref: emulation.py:346-406 -> log_posterior.py:87-101).  One launch per group adds its term to `out` in turn; here the
+// groups of a walker are taken by different WAVES of one workgroup at the same time -- their k x k factorisations are
+// the serial part of the half-step -- and summed in group order afterwards: the same additions, the same bits.
+// 3 or 4 groups: one walker per workgroup; 2: two; more: the waves take several groups each.  k <= 32 in every group.
+constexpr int LL_GROUPS_MAX = 8;
+struct LoglikGroup {
+  const double *lo, *hi, *mean_part, *vsq_part, *kdiag, *G, *g0, *scal;
+  double *mean_out, *var_out;
+  int64_t Bcap;
+  int k, nchunk, nrb, nblk;
+};
+struct LoglikGroups {
+  LoglikGroup g[LL_GROUPS_MAX];
+  int ng;
+};
+
+template <int KMAX>
+__device__ __forceinline__ double group_loglik(const LoglikGroup &gr, bool inside, int64_t b, int lane) {
+  constexpr bool PRE = KMAX <= 16;
+  const int k = gr.k;
+  double gpre[PRE ? KMAX : 1];
+  if (PRE) {
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) gpre[q] = (q < k && lane < k) ? gr.G[q * k + lane] : 0.0;
+  }
+  const double gl_pre = (lane < k) ? gr.g0[lane] : 0.0;
+  const double sc0_pre = gr.scal[0], sc1_pre = gr.scal[1];
+  double mu, sd;
+  walker_mean_sd<(KMAX <= 16 ? 16 : 32)>(gr.mean_part, gr.vsq_part, gr.kdiag, gr.mean_out, gr.var_out, b, gr.Bcap, k,
+                                         gr.nchunk, gr.nrb, lane, mu, sd);
+  return walker_loglik_lowrank<KMAX, PRE>(inside, mu, sd, gpre, gl_pre, sc0_pre, sc1_pre, gr.G, gr.g0, gr.scal, k, gr.nblk, lane);
+}
+
+__global__ __launch_bounds__(256) void loglik_groups_kernel(const double *__restrict__ Xq, LoglikGroups lg,
+                                                            double *__restrict__ out, int64_t B, int d, int accumulate,
+                                                            AcceptArgs aa) {
+  __shared__ double s_lp[2][LL_GROUPS_MAX];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wpw = (lg.ng <= 2) ? 2 : 1, wv = 4 / wpw;        // walkers per workgroup, waves per walker
+  const int slot = wave / wv, gw = wave % wv;
+  const int64_t b = (int64_t)blockIdx.x * wpw + slot;
+  const bool active = b < B;                                 // (wave-uniform; every wave reaches the barrier)
+  AcceptOperands ao;
+  if (active) {
+    if (gw == 0) ao = load_accept_operands(Xq, b, lane, aa);
+    for (int g = gw; g < lg.ng; g += wv) {
+      const LoglikGroup &gr = lg.g[g];
+      bool in = true;
+      if (lane < d) in = (Xq[b * DPAD + lane] > gr.lo[lane]) && (Xq[b * DPAD + lane] < gr.hi[lane]);
+      const bool inside = __all(in);
+      double lp;
+      // (the value does not depend on KMAX: loglik_dev.h)
+      if (gr.k <= 4) lp = group_loglik<4>(gr, inside, b, lane);
+      else if (gr.k <= 8) lp = group_loglik<8>(gr, inside, b, lane);
+      else if (gr.k <= 12) lp = group_loglik<12>(gr, inside, b, lane);
+      else if (gr.k <= 16) lp = group_loglik<16>(gr, inside, b, lane);
+      else if (gr.k <= 20) lp = group_loglik<20>(gr, inside, b, lane);
+      else if (gr.k <= 24) lp = group_loglik<24>(gr, inside, b, lane);
+      else if (gr.k <= 28) lp = group_loglik<28>(gr, inside, b, lane);
+      else lp = group_loglik<32>(gr, inside, b, lane);
+      if (lane == 0) s_lp[slot][g] = lp;
+    }
+  }
+  __syncthreads();
+  if (active && gw == 0) {
+    double total = s_lp[slot][0];
+    for (int g = 1; g < lg.ng; ++g) total = s_lp[slot][g] + total;     // (a launch per group: total_g + out[b])
+    finish_walker(total, out, b, d, lane, accumulate, aa, ao);
+  }
+}
+
+// the likelihoods of ng groups (k <= 32 each, one chain) for the B proposals whose partial sums their cross-kernel and
+// triangular GEMM launches have just written; `aa` finishes the stretch move
+int launch_loglik_groups(gpemu_model *const *ms, int ng, int64_t B, const double *dXq, double *dout, int accumulate,
+                         hipStream_t st, const AcceptArgs *aa) {
+  LoglikGroups lg;
+  lg.ng = ng;
+  for (int g = 0; g < ng; ++g) {
+    const gpemu_model *m = ms[g];
+    const Workspace &w = m->ws;
+    lg.g[g] = LoglikGroup{m->lo, m->hi, w.mean_part, w.vsq_part, m->kdiag, m->G, m->g0, m->scal, w.mean, w.var, w.Bcap,
+                          (int)m->k, w.cur_nchunk, w.cur_nrb, (int)m->nblk};
+  }
+  const AcceptArgs a = aa ? *aa : AcceptArgs();
+  const int wpw = ng <= 2 ? 2 : 1;
+  hipLaunchKernelGGL(loglik_groups_kernel, dim3((unsigned)((B + wpw - 1) / wpw)), dim3(256), 0, st, dXq, lg, dout, B,
+                     (int)ms[0]->d, accumulate, a);
+  GP_HIP(hipGetLastError());
+  return GPEMU_OK;
+}
+
 int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq, double *dout, int accumulate,
                           hipStream_t st, const AcceptArgs *aa) {
   const Workspace &w = m->ws;

@@ -41,8 +41,10 @@ struct KstarArgs {
                                        // of each piece of ncbp column blocks per XCD
 };
 
+// bidx: the workgroup's index within its group's grid; store_rows: this group's first workgroups keep the padded query
+// rows / stretch factors (the first group of a launch that serves several: the others form the same rows and store nothing)
 template <int KIND, int KS, int JTW, int NBW>
-__global__ __launch_bounds__(256, 2) void kstar_kernel(KstarArgs ka, ProposeArgs pa) {
+__device__ __forceinline__ void kstar_body(const KstarArgs &ka, const ProposeArgs &pa, const int bidx, const bool store_rows) {
   __shared__ double s_tab[1 << KSTAR_TB];
   __shared__ __attribute__((aligned(16))) double s_q[64 * DPAD];
   __shared__ double s_red[4 * 64];
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(KstarArgs ka, ProposeArgs
   if (ka.gper > 0) {
     // the GEMM runs one launch per piece of ncbp 128-column blocks (launch_trmm_vsq: at most 512 columns each), every
     // launch dealing its k ncbp groups to the XCDs in (PC, column block) order, gper per XCD
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = bidx & 7, slot = bidx >> 3;
     const int half = slot & 1, rest = slot >> 1;
     chunk = rest % nchunk;
     const int rest2 = rest / nchunk;
@@ -67,8 +69,8 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(KstarArgs ka, ProposeArgs
     p = g / ka.ncbp;
     cb = 2 * (piece * ka.ncbp + g % ka.ncbp) + half;
   } else {
-    cb = blockIdx.x % ka.ncb64;
-    const int rest = blockIdx.x / ka.ncb64;
+    cb = bidx % ka.ncb64;
+    const int rest = bidx / ka.ncb64;
     chunk = rest % nchunk;
     p = rest / nchunk;
   }
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(KstarArgs ka, ProposeArgs
   const int64_t njt = ka.Npad / 16;
   KstarFrags<KS, JTW> fr;
   if (threadIdx.x < (1 << KSTAR_TB)) s_tab[threadIdx.x] = ka.etab[threadIdx.x];
-  const bool keeper = chunk == 0 && p == 0;          // the workgroup that stores the padded rows of its columns
+  const bool keeper = store_rows && chunk == 0 && p == 0;   // the workgroup that stores the padded rows of its columns
   double q0 = 0.0, q1 = 0.0;
   if (pa.enabled) {
     // stretch-move proposal for column b (every workgroup recomputes it; one of them stores it)
@@ -124,6 +126,27 @@ __global__ __launch_bounds__(256, 2) void kstar_kernel(KstarArgs ka, ProposeArgs
   if (wave == 0) ka.mean_part[(b * ka.k + p) * nchunk + chunk] = sum;
 }
 
+template <int KIND, int KS, int JTW, int NBW>
+__global__ __launch_bounds__(256, 2) void kstar_kernel(KstarArgs ka, ProposeArgs pa) {
+  kstar_body<KIND, KS, JTW, NBW>(ka, pa, (int)blockIdx.x, true);
+}
+
+// The cross-kernels of several emulation groups in ONE launch (a sampler over the shipped three groups spends its
+// half-step in nine ~6 us launches otherwise): workgroups [start[g], start[g + 1]) are group g's grid.  Every group
+// forms the stretch proposal itself (the same arithmetic, the same rows); the first one stores it.
+constexpr int GROUPS_MAX = 8;
+struct KstarGroups {
+  KstarArgs g[GROUPS_MAX];
+  int start[GROUPS_MAX + 1];
+  int ng;
+};
+template <int KIND, int KS, int JTW, int NBW>
+__global__ __launch_bounds__(256, 2) void kstar_groups_kernel(KstarGroups kg, ProposeArgs pa) {
+  int gi = 0;
+  while (gi + 1 < kg.ng && (int)blockIdx.x >= kg.start[gi + 1]) ++gi;
+  kstar_body<KIND, KS, JTW, NBW>(kg.g[gi], pa, (int)blockIdx.x - kg.start[gi], gi == 0);
+}
+
 // Columns per launch of the large-batch triangular GEMM.  More than 512 columns (emulation.predict on a large batch) go
 // one launch per 512 columns: K_*^T of 1024 columns is 82 MB, and with W_p it no longer streams through the XCDs' L2s the
 // way the 512-column schedule is built for (one launch of 1024 columns takes 228 us, two of 512 take 2 x 93 us).  Only
@@ -147,50 +170,82 @@ int trmm_xcd_of(const gpemu_model *m, int64_t B, int p, int64_t col) {
   return (p * ncbp + (int)(col / TILE) % ncbp) / (ngroups / 8);
 }
 
-int launch_kstar(gpemu_model *m, int64_t B, double *dXq, hipStream_t st, const ProposeArgs *pa) {
-  const ProposeArgs pargs = pa ? *pa : ProposeArgs();
+// arguments and grid of one group's cross-kernel for a batch of B columns (sets the workspace's chunk count)
+static KstarArgs kstar_setup(gpemu_model *m, int64_t B, double *dXq, int &nwg, bool &small) {
   // only the column tiles that hold real queries; without a proposal / raw rows, the rows of dXq up to
   // round_up(B, TILE) must be finite (the sampler's proposal buffer zeroes them)
   Workspace &w = m->ws;
   const int64_t Bv = m->variant_B > 0 ? m->variant_B : B;   // a chain stacked with others is evaluated as it would be alone
-  const bool small = Bv <= KSTAR_SMALL_MAX;          // few columns: more, shorter workgroups
+  small = Bv <= KSTAR_SMALL_MAX;                     // few columns: more, shorter workgroups
   const int rows_per_wg = small ? KSTAR_ROWS_SMALL : KSTAR_ROWS_BIG;
   w.cur_nchunk = (int)(m->Npad / rows_per_wg);
   // column blocks of 64 queries: whole 128-column tiles for the triangular GEMM, except that a batch of at most
   // 64 (always served by the small-batch kernel's 64-column items) needs only its first block
   const int64_t ncols = (B <= 64) ? 64 : round_up(B, TILE);
   const int ncb64 = (int)(ncols / 64);
-  dim3 grid((unsigned)(ncb64 * w.cur_nchunk * (int)m->k)), block(256);
+  nwg = ncb64 * w.cur_nchunk * (int)m->k;
   // XCD-aware placement where the large-batch GEMM's schedule is (whole groups per XCD: build_trmm_schedule), piece by
   // piece of the columns as launch_trmm_vsq will cut them
   const int ncbp = (int)(trmm_piece_cols(m, B) / TILE);
   const int ngroups = (int)m->k * ncbp;
   const bool xcd_aware = Bv > 128 && ncb64 % 2 == 0 && (ncb64 / 2) % ncbp == 0 && ngroups % 8 == 0 && m->num_cu % 8 == 0;
   const int gper = xcd_aware ? ngroups / 8 : 0;
+  return KstarArgs{dXq, m->Xa, m->alf, m->qsc, m->qof, m->etab, m->constv, m->Xs, m->inv_ls, w.KS, w.mean_part,
+                   m->N, m->Npad, w.Bcap, m->has_const, (int)m->d, (int)m->k, w.cur_nchunk, ncb64, gper, ncbp};
+}
+
+#define GP_KSTAR_DISPATCH(kind, ksteps, small, LAUNCH)                  \
+  do {                                                                   \
+    if ((ksteps) == 2) {                                                 \
+      switch (kind) {                                                    \
+        case 0: if (small) LAUNCH(0, 2, 1); else LAUNCH(0, 2, 2); break; \
+        case 1: if (small) LAUNCH(1, 2, 1); else LAUNCH(1, 2, 2); break; \
+        case 2: if (small) LAUNCH(2, 2, 1); else LAUNCH(2, 2, 2); break; \
+        default: if (small) LAUNCH(3, 2, 1); else LAUNCH(3, 2, 2); break; \
+      }                                                                  \
+    } else {                                                             \
+      switch (kind) {                                                    \
+        case 0: if (small) LAUNCH(0, 3, 1); else LAUNCH(0, 3, 2); break; \
+        case 1: if (small) LAUNCH(1, 3, 1); else LAUNCH(1, 3, 2); break; \
+        case 2: if (small) LAUNCH(2, 3, 1); else LAUNCH(2, 3, 2); break; \
+        default: if (small) LAUNCH(3, 3, 1); else LAUNCH(3, 3, 2); break; \
+      }                                                                  \
+    }                                                                    \
+  } while (0)
+
+int launch_kstar(gpemu_model *m, int64_t B, double *dXq, hipStream_t st, const ProposeArgs *pa) {
+  const ProposeArgs pargs = pa ? *pa : ProposeArgs();
+  int nwg = 0;
+  bool small = false;
+  const KstarArgs ka = kstar_setup(m, B, dXq, nwg, small);
+  const dim3 grid((unsigned)nwg), block(256);
   const int pe0 = prof_mark(m, st);
-  const int kind = kstar_kind(m);
-  KstarArgs ka{dXq, m->Xa, m->alf, m->qsc, m->qof, m->etab, m->constv, m->Xs, m->inv_ls, w.KS, w.mean_part,
-               m->N, m->Npad, w.Bcap, m->has_const, (int)m->d, (int)m->k, w.cur_nchunk, ncb64, gper, ncbp};
-#define GP_LAUNCH_KSTAR2(KD, KSV)                                                                       \
-  do {                                                                                                  \
-    if (small) hipLaunchKernelGGL((kstar_kernel<KD, KSV, 1, 2>), grid, block, 0, st, ka, pargs);        \
-    else hipLaunchKernelGGL((kstar_kernel<KD, KSV, 2, 2>), grid, block, 0, st, ka, pargs);              \
-  } while (0)
-#define GP_LAUNCH_KSTAR(KD)                                \
-  do {                                                     \
-    if (m->ksteps == 2) GP_LAUNCH_KSTAR2(KD, 2);           \
-    else GP_LAUNCH_KSTAR2(KD, 3);                          \
-  } while (0)
-  switch (kind) {
-    case 0: GP_LAUNCH_KSTAR(0); break;
-    case 1: GP_LAUNCH_KSTAR(1); break;
-    case 2: GP_LAUNCH_KSTAR(2); break;
-    default: GP_LAUNCH_KSTAR(3); break;
-  }
-#undef GP_LAUNCH_KSTAR
-#undef GP_LAUNCH_KSTAR2
+#define GP_LAUNCH_ONE(KD, KSV, JT) hipLaunchKernelGGL((kstar_kernel<KD, KSV, JT, 2>), grid, block, 0, st, ka, pargs)
+  GP_KSTAR_DISPATCH(kstar_kind(m), m->ksteps, small, GP_LAUNCH_ONE);
+#undef GP_LAUNCH_ONE
   GP_HIP(hipGetLastError());
   prof_pair(m, 1, pe0, prof_mark(m, st));
+  return GPEMU_OK;
+}
+
+// one launch for the cross-kernels of ng groups on the same B query rows (same base kernel and parameter count in all
+// of them: the caller checks); `pa`: the stretch proposal, formed by every group, stored by the first
+int launch_kstar_groups(gpemu_model *const *ms, int ng, int64_t B, double *dXq, hipStream_t st, const ProposeArgs *pa) {
+  const ProposeArgs pargs = pa ? *pa : ProposeArgs();
+  KstarGroups kg;
+  kg.ng = ng;
+  kg.start[0] = 0;
+  bool small = false;
+  for (int g = 0; g < ng; ++g) {
+    int nwg = 0;
+    kg.g[g] = kstar_setup(ms[g], B, dXq, nwg, small);
+    kg.start[g + 1] = kg.start[g] + nwg;
+  }
+  const dim3 grid((unsigned)kg.start[ng]), block(256);
+#define GP_LAUNCH_GROUPS(KD, KSV, JT) hipLaunchKernelGGL((kstar_groups_kernel<KD, KSV, JT, 2>), grid, block, 0, st, kg, pargs)
+  GP_KSTAR_DISPATCH(kstar_kind(ms[0]), ms[0]->ksteps, small, GP_LAUNCH_GROUPS);
+#undef GP_LAUNCH_GROUPS
+  GP_HIP(hipGetLastError());
   return GPEMU_OK;
 }
 

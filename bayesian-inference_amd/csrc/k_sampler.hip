@@ -242,6 +242,10 @@ __global__ void unpad_rows_kernel(const double *__restrict__ src, double *__rest
 static int eval_logpost(gpemu_sampler *s, double *dq, int64_t B, double *dout, hipStream_t st,
                         const AcceptArgs *aa = nullptr, const ProposeArgs *pa = nullptr) {
   const size_t ng = s->groups.size();
+  if (ng >= 2) {     // one launch per stage for all groups where that applies (gpemu_api.hip: logpost_groups)
+    const int rc = logpost_groups(s->groups.data(), (int)ng, B, dq, dout, st, aa, pa);
+    if (rc != GPEMU_ERR_UNSUPPORTED) return rc;
+  }
   AcceptArgs chain_only;                 // groups before the last: no accept, but the rows' chains (data constants)
   if (aa) { chain_only.chain_per = aa->chain_per; chain_only.first = aa->first; }
   for (size_t g = 0; g < ng; ++g) {

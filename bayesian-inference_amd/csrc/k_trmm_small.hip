@@ -47,11 +47,12 @@ struct SmallItem {
 
 // ST_RING: k-tiles in flight per wave (two 16-byte loads each); WPE: waves per SIMD the register budget is cut for
 // (4: two workgroups per CU, ring of 4; 6: three per CU, 80 VGPRs, ring of 3).  Same arithmetic in both.
-template <int ST_RING, int WPE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void trmm_vsq_small_kernel(
+// `worker`: index of this workgroup's item list in the schedule
+template <int ST_RING>
+__device__ __forceinline__ void trmm_vsq_small_body(
     const double *__restrict__ Wt, const double *__restrict__ KS, double *__restrict__ out,
     const SmallItem *__restrict__ sched, const int *__restrict__ sched_cnt, int max_items, int64_t Npad,
-    int64_t Bcap, int k, int nrb) {
+    int64_t Bcap, int k, int nrb, const int worker) {
   __shared__ __attribute__((aligned(16))) double scratch[4 * 4 * 64 * 4];   // K-slice partial tiles, 32 KiB
   __shared__ SmallItem s_items[ST_MAX_ITEMS];
 
@@ -60,8 +61,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane & 15, lk = lane >> 4;
 
-  const int nitems = __builtin_amdgcn_readfirstlane(sched_cnt[blockIdx.x]);
-  if (tid < nitems) s_items[tid] = sched[(int64_t)blockIdx.x * max_items + tid];
+  const int nitems = __builtin_amdgcn_readfirstlane(sched_cnt[worker]);
+  if (tid < nitems) s_items[tid] = sched[(int64_t)worker * max_items + tid];
   __syncthreads();
   if (nitems == 0) return;
   // item fields as wave-uniform scalars: every branch on them is a scalar branch
@@ -180,13 +181,46 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   }
 }
 
+template <int ST_RING, int WPE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void trmm_vsq_small_kernel(
+    const double *__restrict__ Wt, const double *__restrict__ KS, double *__restrict__ out,
+    const SmallItem *__restrict__ sched, const int *__restrict__ sched_cnt, int max_items, int64_t Npad,
+    int64_t Bcap, int k, int nrb) {
+  trmm_vsq_small_body<ST_RING>(Wt, KS, out, sched, sched_cnt, max_items, Npad, Bcap, k, nrb, (int)blockIdx.x);
+}
+
+// Several emulation groups in one launch: workgroups [start[g], start[g + 1]) are the workers of group g's own schedule
+// (each worker's items belong to one group, so the body is the single-group kernel's -- the same bits)
+constexpr int SMALL_GROUPS_MAX = 8;
+struct SmallGroup {
+  const double *Wt, *KS;
+  double *out;
+  const SmallItem *sched;
+  const int *cnt;
+  int64_t Npad, Bcap;
+  int max_items, k, nrb;
+};
+struct SmallGroups {
+  SmallGroup g[SMALL_GROUPS_MAX];
+  int start[SMALL_GROUPS_MAX + 1];
+  int ng;
+};
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void trmm_vsq_small_groups_kernel(SmallGroups sg) {
+  int gi = 0;
+  while (gi + 1 < sg.ng && (int)blockIdx.x >= sg.start[gi + 1]) ++gi;
+  const SmallGroup &g = sg.g[gi];
+  trmm_vsq_small_body<4>(g.Wt, g.KS, g.out, g.sched, g.cnt, g.max_items, g.Npad, g.Bcap, g.k, g.nrb,
+                         (int)blockIdx.x - sg.start[gi]);
+}
+
 // host side: LPT schedule, XCD-aware.  Workgroups are dispatched round-robin over the 8 XCDs (worker w on XCD
 // w % 8, each with its own 4 MiB L2).  The items of one (PC, column block) group read the same K_*^T block and
 // the column blocks of one (PC, row block) the same W strip, so whole groups are dealt to XCDs in (PC, column
 // block) order -- adjacent column blocks of a PC land on the same XCD, equally long, and start together -- and
 // the groups left over when the count is not a multiple of 8 are spread over every XCD.
+// worker_cap > 0: that many workers at most (several groups sharing one launch: k_trmm_small.hip, ..._groups)
 static void build_small_schedule(const gpemu_model *m, int ncb, std::vector<SmallItem> &flat, std::vector<int> &cnt,
-                                 int &max_items, int &nworkers) {
+                                 int &max_items, int &nworkers, int worker_cap = 0) {
   const int nrb = (int)(m->Npad / ST_M), k = (int)m->k;
   struct It { double cost; SmallItem it; int group; };
   std::vector<It> items;
@@ -197,7 +231,7 @@ static void build_small_schedule(const gpemu_model *m, int ncb, std::vector<Smal
       for (int cb = 0; cb < ncb; ++cb) items.push_back({nt + ov, SmallItem{p, rb, cb * ST_N, 0}, p * ncb + cb});
   }
   std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.cost > b.cost; });
-  const int ncu = m->num_cu * small_workers_per_cu((int64_t)items.size(), m->num_cu);
+  const int ncu = worker_cap > 0 ? worker_cap : m->num_cu * small_workers_per_cu((int64_t)items.size(), m->num_cu);
   nworkers = ncu < (int)items.size() ? ncu : (int)items.size();
   std::vector<std::vector<SmallItem>> per(nworkers);
   std::vector<double> load(nworkers, 0.0);
@@ -243,16 +277,15 @@ int small_trmm_xcd_of(const gpemu_model *m, int64_t B, int p, int64_t col) {
 
 // returns GPEMU_ERR_UNSUPPORTED (without setting an error) when the shape needs more items per worker than the
 // kernel holds; the caller then uses the general small-batch kernel
-int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st) {
-  Workspace &w = m->ws;
-  const int nrb = (int)(m->Npad / ST_M);
+// the schedule for B columns on the device (m->sm_*); GPEMU_ERR_UNSUPPORTED as below
+static int small_schedule_ready(gpemu_model *m, int64_t B, hipStream_t st, int worker_cap = 0) {
   const int ncb = (int)(round_up(B, ST_N) / ST_N);
-  const int cap = m->num_cu;
+  const int cap = worker_cap > 0 ? -worker_cap : m->num_cu;      // (key of the one cached schedule)
   if (m->sm_ncb != ncb || m->sm_cap != cap) {
     std::vector<SmallItem> flat;
     std::vector<int> cnt;
     int max_items = 0, nworkers = 0;
-    build_small_schedule(m, ncb, flat, cnt, max_items, nworkers);
+    build_small_schedule(m, ncb, flat, cnt, max_items, nworkers, worker_cap);
     if (max_items > ST_MAX_ITEMS) return GPEMU_ERR_UNSUPPORTED;
     GP_HIP(hipStreamSynchronize(st));
     (void)hipFree(m->sm_items);
@@ -264,6 +297,14 @@ int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st) {
     GP_HIP(hipMemcpy(m->sm_cnt, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice));
     m->sm_ncb = ncb; m->sm_cap = cap; m->sm_max_items = max_items; m->sm_workers = nworkers;
   }
+  return GPEMU_OK;
+}
+
+int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st) {
+  Workspace &w = m->ws;
+  const int nrb = (int)(m->Npad / ST_M);
+  const int rc = small_schedule_ready(m, B, st);
+  if (rc != GPEMU_OK) return rc;
   w.cur_nrb = nrb;
   const int pe0 = prof_mark(m, st);
   if (m->sm_workers > 2 * m->num_cu)
@@ -274,6 +315,50 @@ int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st) {
                        (const SmallItem *)m->sm_items, m->sm_cnt, m->sm_max_items, m->Npad, w.Bcap, (int)m->k, nrb);
   GP_HIP(hipGetLastError());
   prof_pair(m, 0, pe0, prof_mark(m, st));
+  return GPEMU_OK;
+}
+
+// the small-batch GEMMs of ng groups (B <= 128 columns each) in one launch; GPEMU_ERR_UNSUPPORTED (no error set, nothing
+// launched) when a group's shape does not fit the kernel: the caller launches group by group
+// All groups' workers resident together: two 512-thread workgroups per CU in all, dealt to the groups by their share
+// of the k-tiles (left to themselves three groups of the shipped size bring 888 workers for 512 slots: 17.6 us against
+// 7.4 - 10.4 us for each group alone).  Multiples of 8, so that worker w of a group still sits on XCD w % 8.
+int prepare_trmm_vsq_small_groups(gpemu_model *const *ms, int ng, int64_t B, hipStream_t st) {
+  if (ng > SMALL_GROUPS_MAX) return GPEMU_ERR_UNSUPPORTED;
+  const int ncb = (int)(round_up(B, ST_N) / ST_N);
+  double cost[SMALL_GROUPS_MAX], total = 0.0;
+  for (int g = 0; g < ng; ++g) {
+    const double nrb = (double)(ms[g]->Npad / ST_M);
+    cost[g] = (double)ms[g]->k * ncb * (0.5 * nrb * (nrb + 1.0) + 1.5 * nrb);
+    total += cost[g];
+  }
+  const int slots = 2 * ms[0]->num_cu;
+  for (int g = 0; g < ng; ++g) {
+    int cap = (int)(slots * cost[g] / total) / 8 * 8;
+    if (cap < 8) cap = 8;
+    const int rc = small_schedule_ready(ms[g], B, st, cap);
+    if (rc != GPEMU_OK) return rc;
+  }
+  return GPEMU_OK;
+}
+
+int launch_trmm_vsq_small_groups(gpemu_model *const *ms, int ng, int64_t B, hipStream_t st) {
+  const int rc0 = prepare_trmm_vsq_small_groups(ms, ng, B, st);
+  if (rc0 != GPEMU_OK) return rc0;
+  SmallGroups sg;
+  sg.ng = ng;
+  sg.start[0] = 0;
+  for (int g = 0; g < ng; ++g) {
+    gpemu_model *m = ms[g];
+    Workspace &w = m->ws;
+    const int nrb = (int)(m->Npad / ST_M);
+    w.cur_nrb = nrb;
+    sg.g[g] = SmallGroup{m->Wt, w.KS, w.vsq_part, (const SmallItem *)m->sm_items, m->sm_cnt, m->Npad, w.Bcap,
+                         m->sm_max_items, (int)m->k, nrb};
+    sg.start[g + 1] = sg.start[g] + m->sm_workers;
+  }
+  hipLaunchKernelGGL(trmm_vsq_small_groups_kernel, dim3((unsigned)sg.start[ng]), dim3(512), 0, st, sg);
+  GP_HIP(hipGetLastError());
   return GPEMU_OK;
 }
 

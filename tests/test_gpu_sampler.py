@@ -268,6 +268,72 @@ def test_phase_api_slices_of_eight_ranks_equal_single(world):
     a.close(); ref.close(); dm.close()
 
 
+def test_groups_in_one_launch_per_stage_equal_the_per_group_launches(monkeypatch):
+    """A sampler over several emulation groups at the shipped size (~150 design points, 200 walkers, 5 / 11 / 25 PCs)
+    runs ONE cross-kernel, ONE triangular-GEMM and ONE likelihood launch per half-step for all groups
+    (gpemu_api.hip: logpost_groups); with GPEMU_NO_GROUP_MERGE the nine per-group launches: the same chain, bit for bit
+    -- also for two groups (two walkers per likelihood workgroup), through the per-phase API, and against the oracle."""
+    import ctypes as C
+    import torch
+    from gpemu import _lib, synthetic
+    from gpemu.sampler import DeviceSampler, shard_bounds
+    L = _lib.lib()
+    models, dms, probs = [], [], []
+    for gi, (F, k) in enumerate([(40, 5), (60, 11), (90, 25)]):
+        model, prob, _ = GU.fixed_theta_model(150, F, k, seed=gi)
+        dm = GU.device_model(model)
+        dm.likelihood_setup(prob["y_exp"], prob["y_err"], prob["lo"], prob["hi"], 1.0)
+        models.append(model); dms.append(dm); probs.append(prob)
+    lo, hi = probs[0]["lo"], probs[0]["hi"]
+    for ng, W in ((3, 200), (2, 37)):
+        X0 = synthetic.make_walkers(W, seed=21, lo=lo, hi=hi)
+        out = {}
+        for merged in (True, False):
+            if merged:
+                monkeypatch.delenv("GPEMU_NO_GROUP_MERGE", raising=False)
+            else:
+                monkeypatch.setenv("GPEMU_NO_GROUP_MERGE", "1")
+            ds = DeviceSampler(dms[:ng], W, seed=8)
+            ds.set_state(X0)
+            ds.run(6)
+            out[merged] = ds.get_chain() + (ds.counts()[0],)
+            ds.close()
+        monkeypatch.delenv("GPEMU_NO_GROUP_MERGE", raising=False)
+        for a, b in zip(out[True], out[False]):
+            np.testing.assert_array_equal(a, b)
+        # the oracle's log-posterior of the stored positions (sum over the groups)
+        chain, lps = out[True][0], out[True][1]
+        for w in (0, W // 2, W - 1):
+            ref = sum(O.log_posterior(chain[-1, w], {"g": models[g]}, lo, hi, probs[g]["y_exp"], probs[g]["y_err"])[0]
+                      for g in range(ng))
+            np.testing.assert_allclose(lps[-1, w], ref, rtol=1e-9)
+        # per-phase API, the half cut into three slices (each a merged launch chain of its own)
+        a = DeviceSampler(dms[:ng], W, seed=8)
+        a.set_state(X0)
+        dev = torch.device("cuda", a.device)
+        _lib.check(L.gpemu_sampler_reserve_chain(a._h, 6))
+        for _ in range(6):
+            _lib.check(L.gpemu_sampler_begin_step(a._h))
+            for h in (0, 1):
+                n = a.ns[h]
+                per = shard_bounds(n, 3, 0)[2]
+                full = torch.zeros(per * 3, dtype=torch.float64, device=dev)
+                for r in range(3):
+                    l0, h0, _ = shard_bounds(n, 3, r)
+                    mine = torch.zeros(per, dtype=torch.float64, device=dev)
+                    _lib.check(L.gpemu_sampler_half_propose_eval(a._h, h, l0, h0, C.c_void_p(mine.data_ptr())))
+                    torch.cuda.synchronize()
+                    full[r * per:(r + 1) * per] = mine
+                _lib.check(L.gpemu_sampler_half_accept(a._h, h, C.c_void_p(full.data_ptr()), 1))
+            _lib.check(L.gpemu_sampler_end_step(a._h, 1))
+        ca, la = a.get_chain()
+        np.testing.assert_array_equal(ca, chain)
+        np.testing.assert_array_equal(la, lps)
+        a.close()
+    for dm in dms:
+        dm.close()
+
+
 # ---- BASELINE configs[3] ("C4") at its full size: the C3 model, 1024 walkers, shares of 128 / 64 proposals ----------
 def _c4_reference(dm, prob, steps):
     from gpemu import synthetic
