@@ -45,13 +45,14 @@ if os.environ.get("GPEMU_BENCH_REHEARSAL_WALKERS"):
 FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix rate (the local guide lists none)
 
 
-def build_workload(device=0):
-    """Synthetic C3 model, built with the product's own device fit path (setup, not timed):
+def build_workload(device=0, n_design=None, n_obs=None, n_pc=None, seed=0):
+    """Synthetic C3 model (or one of another size), built with the product's own device fit path (setup, not timed):
     standardise + PCA (gpemu_pca_fit), then kernel matrix / Cholesky / alpha at the fixed
     hyper-parameters of SURVEY.md 8d (gpemu_fit_factor).  Same generator as the goldens."""
     from gpemu import estimators, synthetic
     from gpemu.fit import DeviceFit
-    prob = synthetic.make_problem(N_DESIGN, N_OBS, seed=0)
+    N_DESIGN, N_OBS, N_PC = (n_design or globals()["N_DESIGN"], n_obs or globals()["N_OBS"], n_pc or globals()["N_PC"])
+    prob = synthetic.make_problem(N_DESIGN, N_OBS, seed=seed)
     scaler, pca, Y_pca = estimators.scale_and_pca(prob["Y"], device=device)
     ls = (prob["hi"] - prob["lo"]) * 0.5
     noise = 0.05
@@ -67,6 +68,37 @@ def build_workload(device=0):
     return dict(prob=prob, ls=np.tile(ls, (N_PC, 1)), noise=np.full(N_PC, noise), alpha=np.stack(alphas),
                 L=np.stack(Ls), components=pca.components_[:N_PC], mean=scaler.mean_, scale=scaler.scale_,
                 cun=cun)
+
+
+def measure_shipped_shape(device=0, n_walkers=200, steps=3000):
+    """One chain at the size the reference ships (ref: config/jet_substructure.yaml: ~150 design points, d = 6, 200
+    walkers, three emulation groups of 5 / 11 / 25 PCs, block-diagonal likelihood over the groups): the regime where a
+    stretch-move step is a handful of ~10 us launches, nothing like C3.  Models built by the product's own device fit."""
+    from gpemu import synthetic
+    from gpemu.model import DeviceModel
+    from gpemu.sampler import DeviceSampler
+    dms = []
+    for gi, (n_obs, n_pc) in enumerate([(60, 5), (120, 11), (215, 25)]):
+        wl = build_workload(device, 150, n_obs, n_pc, seed=gi)
+        prob = wl["prob"]
+        dmg = DeviceModel(X_train=prob["design"], ls=wl["ls"], alpha=wl["alpha"], L=wl["L"], components=wl["components"],
+                          scaler_mean=wl["mean"], scaler_scale=wl["scale"], kernel_kind=0, noise=wl["noise"],
+                          cov_unexplained=wl["cun"], device=device)
+        dmg.likelihood_setup(prob["y_exp"], prob["y_err"], prob["lo"], prob["hi"], 1.0)
+        dms.append(dmg)
+    ds = DeviceSampler(dms, n_walkers, seed=11)
+    ds.set_state(synthetic.make_walkers(n_walkers, seed=3))
+    ds.run(300, store=False)
+    dms[0].sync()
+    t0 = time.perf_counter()
+    ds.run(steps, store=False)
+    dms[0].sync()
+    dt = time.perf_counter() - t0
+    ds.close()
+    for dmg in dms:
+        dmg.close()
+    return {"workload": f"shipped shape: N_design=150, groups of 5 + 11 + 25 PCs (60 + 120 + 215 observables), {n_walkers} walkers",
+            "us_per_step": dt / steps * 1e6, "evals_per_s": n_walkers * steps / dt, "steps": steps}
 
 
 def measure_predict(dm, n_samples=1024, reps=20, prewarm_s=0.3):
@@ -529,7 +561,7 @@ def main():
         except Exception as e:
             predict = {"value": None, "error": repr(e)}
 
-    fit_c5 = fit_c3 = None
+    fit_c5 = fit_c3 = shipped = None
     if rank == 0 and world == 1 and not args.no_fit and not args.emulate_world:
         try:
             fit_c5 = measure_fit_c5(dev_index)
@@ -537,6 +569,10 @@ def main():
         except Exception as e:
             fit_c5 = fit_c5 or {"error": repr(e)}
             fit_c3 = fit_c3 or {"error": repr(e)}
+        try:
+            shipped = measure_shipped_shape(dev_index)
+        except Exception as e:
+            shipped = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -571,7 +607,7 @@ def main():
                                  "rccl_to_torch": tinfo.get("rccl_fallback_reason")},
                "acceptance_fraction_mean": float((nacc / max(iters, 1)).mean()),
                "roofline": roofline, "cpu_baseline": cpu, "gp_predict": predict, "fit_c5": fit_c5, "fit_c3": fit_c3,
-               "weak_scaling": weak}
+               "shipped_shape": shipped, "weak_scaling": weak}
         if rehearsal:
             out["rehearsal"] = True
         print(json.dumps(out), flush=True)
