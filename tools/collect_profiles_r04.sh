@@ -35,4 +35,6 @@ python3 $R/tools/time_lml_batch.py 5000 8 >> $OUT/fit_batch.txt 2>&1
 ( cd $R/bayesian-inference_amd/csrc/tools && ./kstar_probe 1000 512 && ./kstar_probe 1000 64 && ./kstar_probe 1000 1024 10 7 2 ) > $OUT/kstar_probe.txt 2>&1
 python3 $R/tools/time_exact.py > $OUT/time_exact.txt 2>&1
 python3 $R/tools/run_dropin_c3.py 50 1000 10000 > $OUT/dropin_c3_end_to_end.txt 2>&1
+( python3 $R/tools/time_shipped_chain.py groups 150 0 0 200 3000; python3 $R/tools/time_shipped_chain.py groups 150 0 0 100 3000; GPEMU_NO_GROUP_MERGE=1 python3 $R/tools/time_shipped_chain.py groups 150 0 0 200 3000; python3 $R/tools/time_shipped_chain.py 150 215 25 200 3000; python3 $R/tools/time_shipped_chain.py 150 215 11 200 3000 ) > $OUT/shipped_shape.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_shipped -- python3 $R/tools/time_shipped_chain.py groups 150 0 0 200 2000 > $OUT/stats_shipped.log 2>&1
 echo collected
