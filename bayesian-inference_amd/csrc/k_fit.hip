@@ -91,71 +91,278 @@ __global__ __launch_bounds__(256) void kmat_kernel(const double *__restrict__ X,
 //   inverse  the four 16 x 16 diagonal blocks by forward substitution (one wave each, lane = column),
 //            then two levels of  X21 = -X22 (L21 X11)  as small LDS matrix products on all threads.
 // do_factor = 0: the block already holds the factor.
+#ifdef GPEMU_POTRF_STAMPS      // tools/potrf_probe.hip: cycle stamps of the phases of one launch
+__device__ long long g_potrf_stamps[16];
+__device__ double g_potrf_flags[64];
+#define POTRF_STAMP(i) do { if (threadIdx.x == 0) g_potrf_stamps[i] = clock64(); } while (0)
+#define POTRF_WAVE_STAMP(i) do { if ((threadIdx.x & 63) == 0) g_potrf_stamps[i] = clock64(); } while (0)
+__device__ long long g_panel_stamps[128][16];     // [row of the panel][event]: wall_clock64 (100 MHz, one clock for all XCDs)
+#define PANEL_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 128) g_panel_stamps[blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define POTRF_STAMP(i) do { } while (0)
+#define POTRF_WAVE_STAMP(i) do { } while (0)
+#define PANEL_STAMP(k) do { } while (0)
+#endif
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
 
-// One 16-column panel of the 64 x 64 block (columns J0 .. J0+15): wave 0 factors the diagonal 16 x 16 block and
-// solves the rows below it with the rows held in registers (lane = row), then all threads apply the rank-16
-// update to the trailing lower triangle.
-template <int J0>
-__device__ __forceinline__ void panel_step(double (*D)[NB + 1], int tid, int blk, int *info) {
+// ---- the 16-column sweep of a panel as a pipeline of three waves -----------------------------------------------
+// Until round 4 ONE wave swept a panel: lane = row (the 16 rows of the diagonal block and the rows below it), pivot by
+// pivot, every L[c][j] fetched with two v_readlane into an SGPR pair -- 750 instructions per sweep, 5 480 ticks, four
+// sweeps = half of a 64 x 64 block's time on the serial path of the factorisation.  A wave issues an fp64 instruction
+// every ~9 ticks, whatever it is (measured: replacing the three instructions of an update by two DPP ones changed
+// nothing), so the instructions are dealt to three waves (three SIMDs) instead:
+//   wave 0  factors the 16 x 16 diagonal block alone.  Lane & 15 = row, the block replicated in every row of 16 lanes,
+//           so that L[c][j] is lane c of the own row: ONE v_fmac_f64_dpp (row_newbcast is legal for 64-bit operations
+//           on gfx90a+) per update and no SGPR.  The nine dependent steps of the next pivot (broadcast, 1 / sqrt as
+//           hardware estimate + two Newton steps, scaling) are written between the updates of the current one -- a wave
+//           issues in order.  Each finished column goes to LDS at once, then its 1 / sqrt as the column's flag.
+//   wave 1  owns the rows below (lane = row) and follows column by column: r[j] *= rinv_j, r[c] -= r[j] L[c][j] with
+//           L[c][j] a broadcast LDS read.
+//   wave 2  inverts the diagonal block as the columns arrive (lane = column of the inverse, forward substitution), with
+//           rinv_j as the reciprocal of the diagonal -- the separate pass over the four diagonal blocks is gone.
+// A flag slot holds a NaN with a payload no arithmetic produces until its value is there (LDS executes a wave's
+// instructions in order: column first, flag second; volatile accesses keep the compiler to that order).  Wave 0 waits
+// for nobody, so the followers' waits end; they are bounded all the same.
+// The arithmetic of the factor -- fma(-L[c][j], L[i][j], .) for j ascending, the scaled column -- is that of the
+// one-wave form: same bits.  The inverse of a diagonal 16 x 16 block differs in its last bits (rinv_j instead of the
+// IEEE 1 / L[j][j]).
+constexpr unsigned long long SWEEP_PENDING = 0x7ff8dead0000beefULL;
+// the volatile accesses name the LDS address space themselves (address-space inference leaves volatile ones generic:
+// a flat store with system scope and a wait behind it)
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+
+template <int L>
+__device__ __forceinline__ double row16_bcast(double v) {        // v of lane L of the own row of 16, after an s_nop 1
+  double r;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(L));
+  return r;
+}
+// The hazard recogniser does not look into inline assembly (a DPP read of a VGPR needs two wait states after the VALU
+// write of it): the statements are volatile -- kept in program order -- and carry an s_nop where the order does not
+// give the distance.
+template <int L>
+__device__ __forceinline__ void fmac_neg_bcast(double &acc, double src, double mul) {   // acc -= src[lane L of the row] * mul
+  asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(L));
+}
+
+// updates number U0 .. U1-1 of pivot column J: d[c] -= L[c][J] d[J] for the columns c = J + 2 + U
+template <int J, int U0, int U1>
+__device__ __forceinline__ void sweep_updates(double (&d)[16]) {
+  if constexpr (U0 < U1) {
+    fmac_neg_bcast<J + 2 + U0>(d[J + 2 + U0], d[J], d[J]);
+    sweep_updates<J, U0 + 1, U1>(d);
+  }
+}
+
+// column J of the diagonal block is final (d[J], lanes >= J of a row; zeros before): to LDS, then its flag.  Every lane
+// stores, at a constant offset from a per-lane base: lanes 0 .. 15 their element of the column (the zeros above the
+// diagonal on zeros), lane 0 the flag, everybody else into dump slots -- no address arithmetic between the pivots.
+struct SweepOut {
+  lds_f64 *col;            // &D[J0 + lane][J0] (lanes < 16) / 16 dump slots
+  lds_f64 *flag;           // the panel's 16 flags (lane 0) / 16 dump slots
+};
+template <int J>
+__device__ __forceinline__ void sweep_publish(const SweepOut &o, double v, double rinv) {
+  *(volatile lds_f64 *)(o.col + J) = v;
+  *(volatile lds_f64 *)(o.flag + J) = rinv;
+}
+
+// Pivot J + 1 of the sweep while the updates of pivot column J (scaled already) are issued: column J + 1 is updated
+// first, then the steps of its pivot go out one by one with some of pivot J's remaining updates behind each.  The wave
+// issues one instruction per ~6 ticks whatever it is, an s_nop included, so the wait states the hazards ask for (two
+// between the write of a VGPR and a DPP read of it, one behind the transcendental) are made of updates while there are
+// any.
+template <int J>
+__device__ __forceinline__ void sweep_pivot(double (&d)[16], const SweepOut &o) {
+  constexpr int NU = (J + 2 <= 15) ? 14 - J : 0;      // updates of pivot J to the columns J + 2 .. 15
+  constexpr int NA = NU < 2 ? NU : 2;                 // between the update of column J + 1 and its broadcast
+  constexpr int NB1 = NU > NA ? 1 : 0;                // between the estimate and its first use
+  constexpr int NR = NU - NA - NB1;                   // the rest: seven gaps
+#define GAP(g) sweep_updates<J, NA + NB1 + (g) * NR / 7, NA + NB1 + ((g) + 1) * NR / 7>(d)
+  if constexpr (J + 1 < 16) {
+    double piv, y, a, h;
+    fmac_neg_bcast<J + 1>(d[J + 1], d[J], d[J]);
+    sweep_updates<J, 0, NA>(d);
+    if constexpr (NA == 0) asm volatile("s_nop 1");
+    if constexpr (NA == 1) asm volatile("s_nop 0");
+    // (v_rsq_f64_dpp assembles, and the compiler's DPP combiner emits it, but on this part it returns NaN: the
+    // transcendental unit does not take the DPP operand -- measured; broadcast and estimate stay two instructions)
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(piv) : "v"(d[J + 1]), "n"(J + 1));
+    asm volatile("v_rsq_f64 %0, %1" : "=v"(y) : "v"(piv));
+    sweep_updates<J, NA, NA + NB1>(d);
+    if constexpr (NB1 == 0) asm volatile("s_nop 0");
+    asm volatile("v_mul_f64 %0, %1, -%2" : "=v"(a) : "v"(y), "v"(piv));
+    asm volatile("v_mul_f64 %0, %1, 0.5" : "=v"(h) : "v"(y));
+    GAP(0);
+    asm volatile("v_fma_f64 %0, %0, %1, 1.0" : "+v"(a) : "v"(y));
+    GAP(1);
+    asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(y) : "v"(h), "v"(a));
+    GAP(2);
+    asm volatile("v_mul_f64 %0, %1, -%2" : "=v"(a) : "v"(y), "v"(piv));
+    asm volatile("v_mul_f64 %0, %1, 0.5" : "=v"(h) : "v"(y));
+    GAP(3);
+    asm volatile("v_fma_f64 %0, %0, %1, 1.0" : "+v"(a) : "v"(y));
+    GAP(4);
+    asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(y) : "v"(h), "v"(a));
+    GAP(5);
+    asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[J + 1]) : "v"(y));       // lanes >= J + 1 of a row: column J + 1 of L
+    sweep_publish<J + 1>(o, d[J + 1], y);     // (two LDS stores: the wait states before the DPP reads of the scaled column)
+    GAP(6);
+    sweep_pivot<J + 1>(d, o);
+  }
+#undef GAP
+}
+
+// a[N0 .. N1) are computed -- in registers -- here: the compiler may not sink their producers behind a later wait (it
+// left all the arithmetic of a follower to the end)
+template <int N0, int N1>
+__device__ __forceinline__ void pin_values(double (&a)[16]) {
+  if constexpr (N1 - N0 >= 4) {
+    asm volatile("" : "+v"(a[N0]), "+v"(a[N0 + 1]), "+v"(a[N0 + 2]), "+v"(a[N0 + 3]));
+    pin_values<N0 + 4, N1>(a);
+  } else if constexpr (N1 - N0 >= 1) {
+    asm volatile("" : "+v"(a[N0]));
+    pin_values<N0 + 1, N1>(a);
+  }
+}
+
+// A follower's request for column J: the flag first, then the broadcast reads of L[J+1 .. 15][J] right behind it, all in
+// flight together.  LDS serves a wave's reads in order: if the flag read finds the value, the column read behind it finds
+// the column.  Issued one column AHEAD (the reads of column J + 1 travel while column J is applied), so a follower that
+// keeps up never sees the latency of LDS; one that finds the flag pending asks again.
+template <int J>
+__device__ __forceinline__ void follow_fetch(double (*D)[NB + 1], const double *flags, unsigned long long &fl, double (&l)[16]) {
+  if constexpr (J < 16) {
+    fl = *(volatile lds_u64 *)(lds_u64 *)(flags + J);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int c = J + 1; c < 16; ++c) l[c] = D[c][J];      // (D: the panel's corner) uniform address: broadcast
+    asm volatile("" ::: "memory");
+  }
+}
+
+// column J of a follower: x[J] = (INV: the forward substitution's value, zero above the diagonal of the inverse)
+// x[J] rinv_J, then x[c] -= x[J] L[c][J] for the later c
+template <int J, bool INV>
+__device__ __forceinline__ void follow_step(double (*D)[NB + 1], const double *flags, double (&x)[16], int c,
+                                            unsigned long long fl, double (&l)[16]) {
+  if constexpr (J < 16) {
+    int polls = 0;
+    while (fl == SWEEP_PENDING && ++polls < (1 << 22)) follow_fetch<J>(D, flags, fl, l);     // bounded: wave 0 waits for nobody
+    const double rinv = __longlong_as_double((long long)fl);
+    unsigned long long fl2 = 0;
+    double l2[16];
+    follow_fetch<J + 1>(D, flags, fl2, l2);
+    const double xj = (!INV || J >= c) ? x[J] * rinv : 0.0;
+    x[J] = xj;
+#pragma unroll
+    for (int k = J + 1; k < 16; ++k) x[k] = fma(-xj, l[k], x[k]);
+    pin_values<J + 1, 16>(x);
+    follow_step<J + 1, INV>(D, flags, x, c, fl2, l2);
+  }
+}
+
+// tile (ti, tj) of the trailing block [T0, 64)^2 takes the rank-16 update of the panel at column J0: four k-steps; a
+// diagonal tile writes its lower part only (the column sweep relies on zeros above)
+__device__ __forceinline__ void trailing_tile(double (*D)[NB + 1], int J0, int T0, int ti, int tj, int lane) {
+  const int lr = lane & 15, lk = lane >> 4;
+  d4t acc = d4t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[T0 + 16 * ti + lr][J0 + 4 * ks + lk], D[T0 + 16 * tj + lr][J0 + 4 * ks + lk], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = lk + 4 * r, col = lr;
+    if (ti != tj || col <= row) D[T0 + 16 * ti + row][T0 + 16 * tj + col] -= acc[r];
+  }
+}
+
+// One 16-column panel of the 64 x 64 block (columns J0 .. J0+15): the sweep (above; the diagonal block's inverse goes
+// to X, flags = 16 slots holding SWEEP_PENDING), then all threads apply the rank-16 update to the trailing lower
+// triangle.  J0 is a run-time value and the four panels of a block run through ONE copy of this code (tile_factor's
+// loop is not unrolled): fully unrolled per panel the block's factorisation was ~75 KB of straight-line code, every
+// instruction of it executed once -- more than the 64 KB instruction cache, i.e. fetched from L2 by every block.
+__device__ __forceinline__ void panel_step(double (*D)[NB + 1], double (*X)[NB + 1], double *flags, double *dump, int J0, int tid,
+                                           int blk, int *info) {
   constexpr int PB = 16;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int MB = NB - J0 - PB;             // rows below the diagonal block
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double (*Dp)[NB + 1] = (double (*)[NB + 1])&D[J0][J0];       // the panel's corner
   if (wave == 0) {
-    const int r = J0 + lane;
-    const bool act = r < NB;
-    double row[PB];
+    double dg[PB];
 #pragma unroll
-    for (int c = 0; c < PB; ++c) row[c] = act ? D[act ? r : 0][J0 + c] : 0.0;
-    int bad = 0;
-#pragma unroll
-    for (int j = 0; j < PB; ++j) {
-      const double piv2 = readlane_f64(row[j], j);
-      if (!(piv2 > 0.0) && bad == 0) bad = J0 + j + 1;
-      // 1 / sqrt(pivot): hardware estimate + two Newton steps instead of the IEEE sqrt-and-divide sequence, which sits
-      // on the serial path of all 64 pivots (relative error ~1e-16; a non-positive pivot gives NaN / inf as before)
-      double rinv = __builtin_amdgcn_rsq(piv2);
-      rinv = fma(0.5 * rinv, fma(-piv2 * rinv, rinv, 1.0), rinv);
-      rinv = fma(0.5 * rinv, fma(-piv2 * rinv, rinv, 1.0), rinv);
-      const double lj = row[j] * rinv;      // lanes >= j: column J0+j of L; lanes < j hold zeros
-      row[j] = lj;
-#pragma unroll
-      for (int c = j + 1; c < PB; ++c) row[c] = fma(-lj, readlane_f64(lj, c), row[c]);
+    for (int c = 0; c < PB; ++c) dg[c] = Dp[lane & 15][c];
+    SweepOut o;
+    o.col = (lds_f64 *)(lane < PB ? &Dp[lane][0] : dump + lane);          // (a dump slot per lane: no bank conflicts)
+    o.flag = (lds_f64 *)(lane == 0 ? flags : dump + 96 + lane);
+    {
+      const double piv = row16_bcast<0>(dg[0]);
+      double y = __builtin_amdgcn_rsq(piv);
+      y = fma(0.5 * y, fma(-piv * y, y, 1.0), y);
+      y = fma(0.5 * y, fma(-piv * y, y, 1.0), y);
+      asm volatile("v_mul_f64 %0, %0, %1" : "+v"(dg[0]) : "v"(y));
+      sweep_publish<0>(o, dg[0], y);
+      asm volatile("s_nop 1" : "+v"(dg[0]));
     }
-    if (bad && lane == 0 && info && *info == 0) *info = blk * NB + bad;
-    if (act) {
+    sweep_pivot<0>(dg, o);
+    // a pivot that is not positive leaves a 1 / sqrt that is not a positive number (NaN: the estimate of a negative
+    // number, or the Newton step on the infinite estimate of zero) -- looked for here, off the pivots' path
+    const double rj = flags[lane & 15];
+    const unsigned long long notpos = __ballot(!(rj > 0.0)) & 0xffffull;
+    if (notpos && lane == 0 && info && *info == 0) *info = blk * NB + J0 + __builtin_ctzll(notpos) + 1;
+    if (J0 == 0) POTRF_WAVE_STAMP(10);
+  } else if (wave == 1) {
+    if (MB > 0) {
+      const bool act = lane < MB;
+      double row[PB];
 #pragma unroll
-      for (int c = 0; c < PB; ++c)
-        if (lane >= PB || c <= lane) D[r][J0 + c] = row[c];   // nothing above the diagonal
+      for (int c = 0; c < PB; ++c) row[c] = act ? Dp[PB + (act ? lane : 0)][c] : 0.0;
+      unsigned long long fl;
+      double l[PB];
+      follow_fetch<0>(Dp, flags, fl, l);
+      follow_step<0, false>(Dp, flags, row, 0, fl, l);
+      if (act) {
+#pragma unroll
+        for (int c = 0; c < PB; ++c) Dp[PB + lane][c] = row[c];
+      }
+      if (J0 == 0) POTRF_WAVE_STAMP(11);
     }
+  } else if (wave == 2) {
+    // inverse of the diagonal block, lane = column: forward substitution, column by column of L (right-looking): once
+    // x[mm] is known every later row takes its term -- independent FMAs; the serial path is one multiply and one FMA
+    // per row
+    if (lane < PB) {
+      const int c = lane;
+      double acc[PB];
+#pragma unroll
+      for (int ii = 0; ii < PB; ++ii) acc[ii] = (ii == c) ? 1.0 : 0.0;
+      unsigned long long fl;
+      double l[PB];
+      follow_fetch<0>(Dp, flags, fl, l);
+      follow_step<0, true>(Dp, flags, acc, c, fl, l);
+#pragma unroll
+      for (int ii = 0; ii < PB; ++ii) X[J0 + ii][J0 + c] = acc[ii];
+    }
+    if (J0 == 0) POTRF_WAVE_STAMP(12);
+  } else if (J0 > 0) {
+    // the part of the previous panel's rank-16 update that this sweep does not read: the tiles right of its first column
+    const int Tp = J0, Mp = NB - Tp;
+    for (int ti = 1; ti < Mp / 16; ++ti)
+      for (int tj = 1; tj <= ti; ++tj) trailing_tile(D, J0 - PB, Tp, ti, tj, lane);
   }
   __syncthreads();
-  constexpr int T0 = J0 + PB, M = NB - T0;       // trailing block [T0, 64)^2, lower triangle
+  if (J0 == 0) POTRF_STAMP(8);
+  // Rank-16 update of the trailing lower triangle [T0, 64)^2 on the matrix cores, 16 x 16 tiles.  Here only its first
+  // tile column -- the next panel, one tile per wave; the rest is left to wave 3, which is idle during the next sweep
+  // (above).  A tile still takes the panels' updates in their order.
+  const int T0 = J0 + PB, M = NB - T0;
   if (M > 0) {
-    // rank-16 update of the trailing lower triangle on the matrix cores: 16 x 16 tiles (ti >= tj) dealt to the four
-    // waves, four k-steps each; a diagonal tile writes its lower part only (the column sweep relies on zeros above)
-    const int lr = lane & 15, lk = lane >> 4;
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    int t = 0;
-#pragma unroll
-    for (int ti = 0; ti < M / 16; ++ti)
-#pragma unroll
-      for (int tj = 0; tj <= ti; ++tj) {
-        if ((t++ & 3) != wv) continue;
-        d4t acc = d4t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < PB / 4; ++ks)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(D[T0 + 16 * ti + lr][J0 + 4 * ks + lk], D[T0 + 16 * tj + lr][J0 + 4 * ks + lk],
-                                                     acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = lk + 4 * r, col = lr;
-          if (ti != tj || col <= row) D[T0 + 16 * ti + row][T0 + 16 * tj + col] -= acc[r];
-        }
-      }
+    if (wave < M / 16) trailing_tile(D, J0, T0, wave, 0, lane);
     __syncthreads();
   }
 }
@@ -210,34 +417,29 @@ __device__ __forceinline__ void merge_level(double (*D)[NB + 1], double (*X)[NB 
   __syncthreads();
 }
 
-// blockIdx.x: diagonal block (64 apart), blockIdx.y: problem of a batch (strides batchA, batchD; info per problem)
-#ifdef GPEMU_POTRF_STAMPS      // tools/potrf_probe.hip: cycle stamps of the phases of one launch
-__device__ long long g_potrf_stamps[16];
-#define POTRF_STAMP(i) do { if (threadIdx.x == 0) g_potrf_stamps[i] = clock64(); } while (0)
-__device__ long long g_panel_stamps[128][16];     // [row of the panel][event]: wall_clock64 (100 MHz, one clock for all XCDs)
-#define PANEL_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 128) g_panel_stamps[blockIdx.x][k] = wall_clock64(); } while (0)
-#else
-#define POTRF_STAMP(i) do { } while (0)
-#define PANEL_STAMP(k) do { } while (0)
-#endif
 
-// Cholesky factor of the 64 x 64 block in D (lower triangle, zeros above), in place; 256 threads
-__device__ __forceinline__ void tile_factor(double (*D)[NB + 1], int tid, int blk, int *info) {
-  panel_step<0>(D, tid, blk, info);
-  POTRF_STAMP(2);
-  panel_step<16>(D, tid, blk, info);
-  panel_step<32>(D, tid, blk, info);
-  panel_step<48>(D, tid, blk, info);
+// Cholesky factor of the 64 x 64 block in D (lower triangle, zeros above), in place, and the inverses of its four
+// 16 x 16 diagonal blocks in X (which must hold zeros on entry); T: scratch (sweep flags); 256 threads
+__device__ __forceinline__ void tile_factor(double (*D)[NB + 1], double (*X)[NB + 1], double (*T)[32 + 1], int tid, int blk, int *info) {
+  double *flags = &T[0][0], *dump = &T[0][0] + NB;
+  if (tid < NB) ((unsigned long long *)flags)[tid] = SWEEP_PENDING;
+  __syncthreads();
+#pragma nounroll
+  for (int J0 = 0; J0 < NB; J0 += 16) {        // one copy of the code for the four panels (see panel_step)
+    panel_step(D, X, flags + J0, dump, J0, tid, blk, info);
+    if (J0 == 0) POTRF_STAMP(2);
+  }
+#ifdef GPEMU_POTRF_STAMPS
+  if (tid < 64) g_potrf_flags[tid] = flags[tid];
+#endif
 }
 
-// X = D^-1 for the lower-triangular 64 x 64 factor D; X must hold zeros on entry; T is the scratch of the merges
-__device__ __forceinline__ void tile_inverse(double (*D)[NB + 1], double (*X)[NB + 1], double (*T)[32 + 1], int tid) {
+// the inverses of the four 16 x 16 diagonal blocks of a given factor D (the factor path gets them from the sweep)
+__device__ __forceinline__ void tile_inverse_diag16(double (*D)[NB + 1], double (*X)[NB + 1], double (*T)[32 + 1], int tid) {
   constexpr int PB = 16;
   const int lane = tid & 63, wave = tid >> 6;
-  // inverse of the four 16 x 16 diagonal blocks: wave w, lane = column
-  // Forward substitution, column by column of L (right-looking): once x[mm] is known every later row takes its term
-  // -- independent FMAs; the serial path is one multiply and one FMA per row instead of a dot product and a division.
-  // The reciprocals of the diagonal: one division per lane, handed round through the scratch T (same wave: in order).
+  // wave w, lane = column.  Forward substitution as in the sweep's wave 2.  The reciprocals of the diagonal: one
+  // division per lane, handed round through the scratch T (same wave: in order).
   if (lane < PB) {
     const int b0 = wave * PB, c = lane;
     double *rdiag = &T[0][0] + b0;
@@ -255,11 +457,17 @@ __device__ __forceinline__ void tile_inverse(double (*D)[NB + 1], double (*X)[NB
     for (int ii = 0; ii < PB; ++ii) X[b0 + ii][b0 + c] = x[ii];
   }
   __syncthreads();
+}
+
+// X = D^-1 for the lower-triangular 64 x 64 factor D, given the inverses of the four 16 x 16 diagonal blocks in X (zeros
+// elsewhere); T is the scratch of the merges
+__device__ __forceinline__ void tile_inverse(double (*D)[NB + 1], double (*X)[NB + 1], double (*T)[32 + 1], int tid) {
   POTRF_STAMP(5);
   // merge pairs of inverted diagonal blocks of size b into blocks of size 2b (b = 16, then 32); the loops run
   // over the full b (X holds zeros above the diagonal, so the triangular structure needs no bounds) and are
   // unrolled, which lets the LDS reads of one output pipeline instead of waiting on a data-dependent trip count
   merge_level<16>(D, X, T, tid);
+  POTRF_STAMP(9);
   merge_level<32>(D, X, T, tid);
 }
 
@@ -295,7 +503,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda,
   __syncthreads();
   POTRF_STAMP(1);
   if (do_factor) {
-    tile_factor(D, tid, block_index + (int)blockIdx.x, info);
+    tile_factor(D, X, T, tid, block_index + (int)blockIdx.x, info);
     POTRF_STAMP(3);
     for (int idx = tid; idx < NB * NB; idx += 256) {
       const int r = idx >> 6, c = idx & 63;
@@ -303,6 +511,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda,
     }
   }
   POTRF_STAMP(4);
+  if (!do_factor) tile_inverse_diag16(D, X, T, tid);
   tile_inverse(D, X, T, tid);
   POTRF_STAMP(6);
   for (int idx = tid; idx < NB * NB; idx += 256) {
@@ -499,7 +708,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, 
           }
       }
     __syncthreads();
-    tile_factor(U, tid, rb, info);
+    tile_factor(U, V, T, tid, rb, info);
     tile_inverse(U, V, T, tid);
     double *Db = Dinv + (int64_t)rb * NB * NB;
     for (int idx = tid; idx < NB * NB; idx += 256) publish_store(Db + idx, V[idx >> 6][idx & 63]);
