@@ -122,14 +122,13 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 //           issues in order.  Each finished column goes to LDS at once, then its 1 / sqrt as the column's flag.
 //   wave 1  owns the rows below (lane = row) and follows column by column: r[j] *= rinv_j, r[c] -= r[j] L[c][j] with
 //           L[c][j] a broadcast LDS read.
-//   wave 2  inverts the diagonal block as the columns arrive (lane = column of the inverse, forward substitution), with
-//           rinv_j as the reciprocal of the diagonal -- the separate pass over the four diagonal blocks is gone.
+//   wave 2  inverts the diagonal block as the columns arrive (lane = column of the inverse, forward substitution) -- the
+//           separate pass over the four diagonal blocks is gone.
 // A flag slot holds a NaN with a payload no arithmetic produces until its value is there (LDS executes a wave's
 // instructions in order: column first, flag second; volatile accesses keep the compiler to that order).  Wave 0 waits
 // for nobody, so the followers' waits end; they are bounded all the same.
-// The arithmetic of the factor -- fma(-L[c][j], L[i][j], .) for j ascending, the scaled column -- is that of the
-// one-wave form: same bits.  The inverse of a diagonal 16 x 16 block differs in its last bits (rinv_j instead of the
-// IEEE 1 / L[j][j]).
+// The arithmetic of the factor -- fma(-L[c][j], L[i][j], .) for j ascending, the scaled column -- and of the inverse
+// (IEEE 1 / L[j][j], the forward substitution's FMAs in row order) is that of the one-wave form: same bits.
 constexpr unsigned long long SWEEP_PENDING = 0x7ff8dead0000beefULL;
 // the volatile accesses name the LDS address space themselves (address-space inference leaves volatile ones generic:
 // a flat store with system scope and a wait behind it)
@@ -235,13 +234,13 @@ __device__ __forceinline__ void pin_values(double (&a)[16]) {
 // flight together.  LDS serves a wave's reads in order: if the flag read finds the value, the column read behind it finds
 // the column.  Issued one column AHEAD (the reads of column J + 1 travel while column J is applied), so a follower that
 // keeps up never sees the latency of LDS; one that finds the flag pending asks again.
-template <int J>
+template <int J, bool DIAG>
 __device__ __forceinline__ void follow_fetch(double (*D)[NB + 1], const double *flags, unsigned long long &fl, double (&l)[16]) {
   if constexpr (J < 16) {
     fl = *(volatile lds_u64 *)(lds_u64 *)(flags + J);
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int c = J + 1; c < 16; ++c) l[c] = D[c][J];      // (D: the panel's corner) uniform address: broadcast
+    for (int c = J + (DIAG ? 0 : 1); c < 16; ++c) l[c] = D[c][J];      // (D: the panel's corner) uniform address: broadcast
     asm volatile("" ::: "memory");
   }
 }
@@ -253,11 +252,19 @@ __device__ __forceinline__ void follow_step(double (*D)[NB + 1], const double *f
                                             unsigned long long fl, double (&l)[16]) {
   if constexpr (J < 16) {
     int polls = 0;
-    while (fl == SWEEP_PENDING && ++polls < (1 << 22)) follow_fetch<J>(D, flags, fl, l);     // bounded: wave 0 waits for nobody
-    const double rinv = __longlong_as_double((long long)fl);
+    while (fl == SWEEP_PENDING && ++polls < (1 << 22)) follow_fetch<J, INV>(D, flags, fl, l);     // bounded: wave 0 waits for nobody
+    // rows below: scaled by the sweep's own 1 / sqrt(pivot) (the flag's value r0).  Inverse: by the reciprocal of the
+    // diagonal element L_jj = RN(pivot r0), which the stand-alone pass (tile_inverse_diag16) and the one-wave form take
+    // from an IEEE division -- ~25 instructions on this wave's path per column (measured: the wave ends 900 ticks
+    // behind wave 0).  r0 is within a few ulp of 1 / L_jj, so ONE Newton step with fused residual,
+    // RN(r0 + r0 RN(1 - L_jj r0)), has a relative error of ~2^-100 before its final rounding: the correctly rounded
+    // reciprocal unless 1 / L_jj lies within 2^-100 of a rounding boundary (a ~2^-47 chance per element; tools/chol_bits.py:
+    // the digests of factors, LML and gradients equal those of the division form).
+    const double r0 = __longlong_as_double((long long)fl);
+    const double rinv = INV ? fma(fma(-l[J], r0, 1.0), r0, r0) : r0;
     unsigned long long fl2 = 0;
     double l2[16];
-    follow_fetch<J + 1>(D, flags, fl2, l2);
+    follow_fetch<J + 1, INV>(D, flags, fl2, l2);
     const double xj = (!INV || J >= c) ? x[J] * rinv : 0.0;
     x[J] = xj;
 #pragma unroll
@@ -324,7 +331,7 @@ __device__ __forceinline__ void panel_step(double (*D)[NB + 1], double (*X)[NB +
       for (int c = 0; c < PB; ++c) row[c] = act ? Dp[PB + (act ? lane : 0)][c] : 0.0;
       unsigned long long fl;
       double l[PB];
-      follow_fetch<0>(Dp, flags, fl, l);
+      follow_fetch<0, false>(Dp, flags, fl, l);
       follow_step<0, false>(Dp, flags, row, 0, fl, l);
       if (act) {
 #pragma unroll
@@ -343,7 +350,7 @@ __device__ __forceinline__ void panel_step(double (*D)[NB + 1], double (*X)[NB +
       for (int ii = 0; ii < PB; ++ii) acc[ii] = (ii == c) ? 1.0 : 0.0;
       unsigned long long fl;
       double l[PB];
-      follow_fetch<0>(Dp, flags, fl, l);
+      follow_fetch<0, true>(Dp, flags, fl, l);
       follow_step<0, true>(Dp, flags, acc, c, fl, l);
 #pragma unroll
       for (int ii = 0; ii < PB; ++ii) X[J0 + ii][J0 + c] = acc[ii];
