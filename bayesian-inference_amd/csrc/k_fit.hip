@@ -11,7 +11,7 @@
 // gpemu_fit_lml once per evaluation.
 //
 // Blocked Cholesky, panel width 64 (matrix padded to a multiple of 64 with an identity tail):
-//   potrf_diag_kernel   factor the 64 x 64 diagonal block in LDS and invert it      (one wave)
+//   potrf_diag_kernel   factor the 64 x 64 diagonal block in LDS and invert it      (one workgroup)
 //   GEMM                panel = A21 . inv(L11)^T                                     (MFMA f64)
 //   GEMM (SYRK)         A22 -= panel . panel^T, lower tiles only                     (MFMA f64)
 // Triangular inverse W = L^-1 by block rows with two MFMA GEMMs per block row; the inverted
@@ -84,13 +84,12 @@ __global__ __launch_bounds__(256) void kmat_kernel(const double *__restrict__ X,
 
 // ---- 64 x 64 diagonal block: Cholesky + inverse ------------------------------------------------
 // 256 threads, block in LDS, both phases blocked by 16 so that only 4 x 16 pivots are serial:
-//   factor   per 16-column panel: wave 0 holds the panel rows in registers (lane = row) and runs the
-//            right-looking column sweep with v_readlane broadcasts -- this factors the 16 x 16 diagonal
-//            block and solves the rows below it in one go; then all 256 threads apply the rank-16 update
-//            to the trailing lower triangle in LDS.
-//   inverse  the four 16 x 16 diagonal blocks by forward substitution (one wave each, lane = column),
-//            then two levels of  X21 = -X22 (L21 X11)  as small LDS matrix products on all threads.
-// do_factor = 0: the block already holds the factor.
+//   factor   per 16-column panel a right-looking column sweep by three waves (below: the 16 x 16 diagonal block, the
+//            rows under it, the diagonal block's inverse), then the rank-16 update of the trailing lower triangle in
+//            LDS on the matrix cores;
+//   inverse  the four 16 x 16 diagonal blocks come out of the sweeps (of a GIVEN factor, do_factor = 0: by forward
+//            substitution, one wave each, lane = column), then two levels of  X21 = -X22 (L21 X11)  as small LDS
+//            matrix products on all threads.
 #ifdef GPEMU_POTRF_STAMPS      // tools/potrf_probe.hip: cycle stamps of the phases of one launch
 __device__ long long g_potrf_stamps[16];
 __device__ double g_potrf_flags[64];
