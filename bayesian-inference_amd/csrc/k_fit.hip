@@ -96,7 +96,7 @@ __device__ double g_potrf_flags[64];
 #define POTRF_STAMP(i) do { if (threadIdx.x == 0) g_potrf_stamps[i] = clock64(); } while (0)
 #define POTRF_WAVE_STAMP(i) do { if ((threadIdx.x & 63) == 0) g_potrf_stamps[i] = clock64(); } while (0)
 __device__ long long g_panel_stamps[128][16];     // [row of the panel][event]: wall_clock64 (100 MHz, one clock for all XCDs)
-#define PANEL_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 128) g_panel_stamps[blockIdx.x][k] = wall_clock64(); } while (0)
+#define PANEL_STAMP(k) do { if (threadIdx.x == 0 && q < 128) g_panel_stamps[q][k] = wall_clock64(); } while (0)
 #else
 #define POTRF_STAMP(i) do { } while (0)
 #define POTRF_WAVE_STAMP(i) do { } while (0)
@@ -543,6 +543,10 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda,
 // The arithmetic (operand order of every MFMA chain, C - acc for the updates) is that of the three-launch path: the
 // factor has the same bits.
 constexpr int CHOL_Q = 4;                       // blocks per panel
+#ifndef GPEMU_CHOL_HEADS_ONE_XCD
+#define GPEMU_CHOL_HEADS_ONE_XCD 1
+#endif
+constexpr bool chol_heads_one_xcd = GPEMU_CHOL_HEADS_ONE_XCD != 0;
 constexpr int CHOL_FLAGS = 4 + 4 * 4;           // per problem: D ready [4], L_cs ready [c][s]
 constexpr int CHOL_WAIT_POLLS = 1 << 20;       // ~1 s
 
@@ -611,13 +615,18 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, 
   Dinv += (int64_t)blockIdx.y * batchD;
   info += blockIdx.y;
   flags += (int64_t)blockIdx.y * CHOL_FLAGS;
-  PANEL_STAMP(0);
   __shared__ double U[NB][NB + 1];     // this strip's current column block (rows wave-private) / the factor of a head
   __shared__ double V[NB][NB + 1];     // Dinv_s or L_cs / the inverse of a head
   __shared__ double T[32][32 + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
-  const int q = blockIdx.x, rb = jb0 + q;
+  // Row of this workgroup.  Workgroups go to the XCDs round-robin in launch order; with at least 32 rows the first 32 are
+  // dealt so that the four heads (rows 0 .. 3) are workgroups 0, 8, 16, 24 -- all on one XCD: a head takes Dinv and L of the
+  // head before it from that XCD's L2 instead of across the fabric.  (Still: whoever is waited for is among the first
+  // 32 workgroups, which start together.)
+  const int bx = blockIdx.x;
+  const int q = (gridDim.x >= 32 && bx < 32 && chol_heads_one_xcd) ? (bx & 7) * 4 + (bx >> 3) : bx, rb = jb0 + q;
+  PANEL_STAMP(0);
   const bool head = q < npb;
   const int ncol = head ? q + 1 : npb;           // column blocks of the panel on or under the diagonal in this row
   double *Arow = A + ((int64_t)rb * NB) * Np + (int64_t)jb0 * NB;
@@ -658,8 +667,10 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) U[16 * wave + lk + 4 * r][16 * nt + lr] = acc[s][nt][r];
     __syncthreads();
+    if (head && s == q - 1) PANEL_STAMP(11);     // Dinv_s in LDS
     d4t l[4];
     strip_product<true>(U, V, wave, lane, l);
+    if (head && s == q - 1) PANEL_STAMP(12);     // L_qs formed
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -688,6 +699,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, 
         load_V(A + ((int64_t)(jb0 + c) * NB) * Np + (int64_t)(jb0 + s) * NB, Np);
       }
       __syncthreads();
+      if (head && c == q && s == q - 1) PANEL_STAMP(13);         // L_qs stored, the own update's operands in LDS
       d4t t[4];
       strip_product<false>(U, V, wave, lane, t);
 #pragma unroll
@@ -695,6 +707,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[c][nt][r] -= t[nt][r];
       __syncthreads();                                           // before V is refilled
+      if (head && c == q && s == q - 1) PANEL_STAMP(14);         // own diagonal block updated
     }
     if (post_late) chol_post(flags + 4 + 4 * q + s, tag);
     PANEL_STAMP(3 + 2 * s);                      // step s done

@@ -89,6 +89,9 @@ int main() {
         if (r >= 6 && r < rows - 3 && r % 16) continue;
         printf("%4d", r);
         for (int k = 0; k <= 10; ++k) printf(" %7.2f", ps[r][k] ? (ps[r][k] - t0) / 100.0 : 0.0);
+        if (r >= 1 && r <= 3)       // a head's last step: Dinv seen -> in LDS -> L formed -> stored -> own block updated -> posted
+          printf("   | last step: +%.2f +%.2f +%.2f +%.2f +%.2f", (ps[r][11] - ps[r][2 * r]) / 100.0, (ps[r][12] - ps[r][11]) / 100.0,
+                 (ps[r][13] - ps[r][12]) / 100.0, (ps[r][14] - ps[r][13]) / 100.0, (ps[r][2 * r + 1] - ps[r][14]) / 100.0);
         printf("\n");
       }
       static long long zero[128][16];
