@@ -71,6 +71,26 @@ def test_not_positive_definite_raises():
         cholesky(A)
 
 
+@pytest.mark.parametrize("bad", [-1.0, 0.0])
+def test_first_non_positive_pivot_is_reported_like_lapack(bad):
+    """dpotrf's info = order of the first leading minor that is not positive definite.  The device finds it from the
+    1 / sqrt(pivot) values a sweep leaves behind (a NaN from the first bad pivot on): first, last and inner pivots of the
+    16-column panels, of the first and of later 64 x 64 blocks; later bad pivots do not overwrite the first."""
+    from gpemu import _lib
+    from gpemu.fit import LinAlgError, cholesky
+    n = 200
+    for p in (0, 1, 15, 16, 31, 47, 48, 63, 64, 79, 127, 128, 199):
+        A = np.eye(n) * 4.0 + 0.01
+        A[p, p] = bad
+        if p + 3 < n:
+            A[p + 3, p + 3] = -5.0
+        with pytest.raises(LinAlgError):
+            cholesky(A)
+        assert f"(pivot {p + 1})" in _lib.lib().gpemu_last_error().decode(), (p, _lib.lib().gpemu_last_error().decode())
+    L = cholesky(np.eye(n) * 4.0 + 0.01)        # and the handle still factors a good matrix
+    assert relerr(np.tril(L), np.linalg.cholesky(np.eye(n) * 4.0 + 0.01)) < 1e-13
+
+
 def test_c3_size_fit_matches_oracle():
     """N = 1000 (BASELINE config 3): device lml/grad/factor vs the oracle at the fixed theta."""
     from gpemu.fit import DeviceFit
