@@ -161,12 +161,12 @@ __device__ __forceinline__ void sweep_updates(double (&d)[16]) {
 // stores, at a constant offset from a per-lane base: lanes 0 .. 15 their element of the column (the zeros above the
 // diagonal on zeros), lane 0 the flag, everybody else into dump slots -- no address arithmetic between the pivots.
 struct SweepOut {
-  lds_f64 *col;            // &D[J0 + lane][J0] (lanes < 16) / 16 dump slots
+  lds_f64 *col;            // lt + lane (lanes < 16): element `lane` of column J goes to lt[16 J + lane] / dump slots
   lds_f64 *flag;           // the panel's 16 flags (lane 0) / 16 dump slots
 };
 template <int J>
 __device__ __forceinline__ void sweep_publish(const SweepOut &o, double v, double rinv) {
-  *(volatile lds_f64 *)(o.col + J) = v;
+  *(volatile lds_f64 *)(o.col + 16 * J) = v;
   *(volatile lds_f64 *)(o.flag + J) = rinv;
 }
 
@@ -234,12 +234,12 @@ __device__ __forceinline__ void pin_values(double (&a)[16]) {
 // the column.  Issued one column AHEAD (the reads of column J + 1 travel while column J is applied), so a follower that
 // keeps up never sees the latency of LDS; one that finds the flag pending asks again.
 template <int J, bool DIAG>
-__device__ __forceinline__ void follow_fetch(double (*D)[NB + 1], const double *flags, unsigned long long &fl, double (&l)[16]) {
+__device__ __forceinline__ void follow_fetch(const double *lt, const double *flags, unsigned long long &fl, double (&l)[16]) {
   if constexpr (J < 16) {
     fl = *(volatile lds_u64 *)(lds_u64 *)(flags + J);
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int c = J + (DIAG ? 0 : 1); c < 16; ++c) l[c] = D[c][J];      // (D: the panel's corner) uniform address: broadcast
+    for (int c = J + (DIAG ? 0 : 1); c < 16; ++c) l[c] = lt[16 * J + c];      // uniform addresses, consecutive: broadcast reads
     asm volatile("" ::: "memory");
   }
 }
@@ -247,7 +247,7 @@ __device__ __forceinline__ void follow_fetch(double (*D)[NB + 1], const double *
 // column J of a follower: x[J] = (INV: the forward substitution's value, zero above the diagonal of the inverse)
 // x[J] rinv_J, then x[c] -= x[J] L[c][J] for the later c
 template <int J, bool INV>
-__device__ __forceinline__ void follow_step(double (*D)[NB + 1], const double *flags, double (&x)[16], int c,
+__device__ __forceinline__ void follow_step(const double *D, const double *flags, double (&x)[16], int c,
                                             unsigned long long fl, double (&l)[16]) {
   if constexpr (J < 16) {
     int polls = 0;
@@ -293,8 +293,8 @@ __device__ __forceinline__ void trailing_tile(double (*D)[NB + 1], int J0, int T
 // triangle.  J0 is a run-time value and the four panels of a block run through ONE copy of this code (tile_factor's
 // loop is not unrolled): fully unrolled per panel the block's factorisation was ~75 KB of straight-line code, every
 // instruction of it executed once -- more than the 64 KB instruction cache, i.e. fetched from L2 by every block.
-__device__ __forceinline__ void panel_step(double (*D)[NB + 1], double (*X)[NB + 1], double *flags, double *dump, int J0, int tid,
-                                           int blk, int *info) {
+__device__ __forceinline__ void panel_step(double (*D)[NB + 1], double (*X)[NB + 1], double *flags, double *dump, double *lt,
+                                           const double *lt_prev, int J0, int tid, int blk, int *info) {
   constexpr int PB = 16;
   const int MB = NB - J0 - PB;             // rows below the diagonal block
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -304,8 +304,8 @@ __device__ __forceinline__ void panel_step(double (*D)[NB + 1], double (*X)[NB +
 #pragma unroll
     for (int c = 0; c < PB; ++c) dg[c] = Dp[lane & 15][c];
     SweepOut o;
-    o.col = (lds_f64 *)(lane < PB ? &Dp[lane][0] : dump + lane);          // (a dump slot per lane: no bank conflicts)
-    o.flag = (lds_f64 *)(lane == 0 ? flags : dump + 96 + lane);
+    o.col = (lds_f64 *)(lane < PB ? lt + lane : dump + lane);             // (a dump slot per lane: no bank conflicts)
+    o.flag = (lds_f64 *)(lane == 0 ? flags : dump + 320 + lane);
     {
       const double piv = row16_bcast<0>(dg[0]);
       double y = __builtin_amdgcn_rsq(piv);
@@ -330,8 +330,8 @@ __device__ __forceinline__ void panel_step(double (*D)[NB + 1], double (*X)[NB +
       for (int c = 0; c < PB; ++c) row[c] = act ? Dp[PB + (act ? lane : 0)][c] : 0.0;
       unsigned long long fl;
       double l[PB];
-      follow_fetch<0, false>(Dp, flags, fl, l);
-      follow_step<0, false>(Dp, flags, row, 0, fl, l);
+      follow_fetch<0, false>(lt, flags, fl, l);
+      follow_step<0, false>(lt, flags, row, 0, fl, l);
       if (act) {
 #pragma unroll
         for (int c = 0; c < PB; ++c) Dp[PB + lane][c] = row[c];
@@ -349,13 +349,16 @@ __device__ __forceinline__ void panel_step(double (*D)[NB + 1], double (*X)[NB +
       for (int ii = 0; ii < PB; ++ii) acc[ii] = (ii == c) ? 1.0 : 0.0;
       unsigned long long fl;
       double l[PB];
-      follow_fetch<0, true>(Dp, flags, fl, l);
-      follow_step<0, true>(Dp, flags, acc, c, fl, l);
+      follow_fetch<0, true>(lt, flags, fl, l);
+      follow_step<0, true>(lt, flags, acc, c, fl, l);
 #pragma unroll
       for (int ii = 0; ii < PB; ++ii) X[J0 + ii][J0 + c] = acc[ii];
     }
     if (J0 == 0) POTRF_WAVE_STAMP(12);
   } else if (J0 > 0) {
+    // the previous panel's diagonal block from its column buffer into D (nobody reads it there before the merges)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) D[J0 - PB + (lane & 15)][J0 - PB + 4 * u + (lane >> 4)] = lt_prev[16 * (4 * u + (lane >> 4)) + (lane & 15)];
     // the part of the previous panel's rank-16 update that this sweep does not read: the tiles right of its first column
     const int Tp = J0, Mp = NB - Tp;
     for (int ti = 1; ti < Mp / 16; ++ti)
@@ -427,14 +430,19 @@ __device__ __forceinline__ void merge_level(double (*D)[NB + 1], double (*X)[NB 
 // Cholesky factor of the 64 x 64 block in D (lower triangle, zeros above), in place, and the inverses of its four
 // 16 x 16 diagonal blocks in X (which must hold zeros on entry); T: scratch (sweep flags); 256 threads
 __device__ __forceinline__ void tile_factor(double (*D)[NB + 1], double (*X)[NB + 1], double (*T)[32 + 1], int tid, int blk, int *info) {
-  double *flags = &T[0][0], *dump = &T[0][0] + NB;
+  // T: the sweeps' flags [0, 64), two column buffers of 16 x 16 (a finished column of the diagonal block is stored
+  // CONTIGUOUSLY for the followers -- one base address and constant offsets instead of a row stride per element: waves
+  // 1 / 2 done at 4123 / 4417 -> 4130 / 4113 ticks of a sweep; the block reaches D one sweep later), dump slots from 576
+  double *flags = &T[0][0], *ltb = &T[0][0] + NB, *dump = &T[0][0] + 576;
   if (tid < NB) ((unsigned long long *)flags)[tid] = SWEEP_PENDING;
   __syncthreads();
 #pragma nounroll
   for (int J0 = 0; J0 < NB; J0 += 16) {        // one copy of the code for the four panels (see panel_step)
-    panel_step(D, X, flags + J0, dump, J0, tid, blk, info);
+    panel_step(D, X, flags + J0, dump, ltb + 256 * ((J0 >> 4) & 1), ltb + 256 * (((J0 >> 4) & 1) ^ 1), J0, tid, blk, info);
     if (J0 == 0) POTRF_STAMP(2);
   }
+  D[NB - 16 + (tid & 15)][NB - 16 + (tid >> 4)] = ltb[256 + 16 * (tid >> 4) + (tid & 15)];      // the last diagonal block
+  __syncthreads();
 #ifdef GPEMU_POTRF_STAMPS
   if (tid < 64) g_potrf_flags[tid] = flags[tid];
 #endif
