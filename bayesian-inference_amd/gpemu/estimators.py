@@ -442,7 +442,7 @@ def fit_batch_size(n_design, requested=None, device=None):
     return max(1, min(int(requested), int(budget // (6 * 8 * n_pad * n_pad))))
 
 
-def _lockstep_minimise(dfit, problems, bounds, max_batch, groups=None):
+def _lockstep_minimise(dfit, problems, bounds, max_batch, groups=None, second=None):
     """``problems``: list of (target y, start theta).  All minimisations advance together: every round takes the next
     requested point of each run of a group (at most ``max_batch``), evaluates them in ONE launch chain
     (``gpemu_fit_lml_batch``) and hands the values back.  Returns [(theta, minimum)] in the order given.
@@ -452,16 +452,31 @@ def _lockstep_minimise(dfit, problems, bounds, max_batch, groups=None):
     thread hands the other group's values back and advances its optimisers to their next requests.  At C3 the host side
     of a round (64 ``setulb`` steps) is a quarter of the evaluation time, which was added to it before.  The runs are
     independent and a batched evaluation has the bits of a single one, so every run visits the points it visits alone,
-    whatever group it is in."""
+    whatever group it is in.
+
+    ``second``: a second device handle (own stream, own work matrices).  The evaluations of group 1 go through it, on a
+    second worker thread, so the two groups' launch chains can be on the device TOGETHER: a chain of batched evaluations
+    leaves most CUs idle during its serial stretches (16 diagonal-block launches on one CU per problem, launches at the
+    launch floor), which the other group's chain fills."""
     import concurrent.futures
     if groups is None:
         groups = int(os.environ.get("GPEMU_FIT_GROUPS", "2"))
     groups = max(1, min(int(groups), 2)) if len(problems) > max_batch else 1
+    handles = [dfit, second if (second is not None and groups == 2) else dfit]
+    n_workers = 2 if handles[1] is not dfit else 1
     runs = [None] * len(problems)
     results = [None] * len(problems)
     nxt = 0
     active = [[] for _ in range(groups)]
     pending = [None] * groups            # (future of the evaluation in flight, the points it was asked for)
+
+    busy = []                            # (start, end) of every evaluation: the device's busy time is their union
+
+    def evaluate(h, ys, xs):
+        t0 = time.perf_counter()
+        out = h.lml_batch(ys, xs)
+        busy.append((t0, time.perf_counter()))
+        return out
 
     def hand_back(g):
         fut, ask = pending[g]
@@ -505,7 +520,7 @@ def _lockstep_minimise(dfit, problems, bounds, max_batch, groups=None):
     if groups > 1:
         sys.setswitchinterval(2e-5)
     try:
-        with concurrent.futures.ThreadPoolExecutor(max_workers=1) as device:     # one evaluation on the device at a time
+        with concurrent.futures.ThreadPoolExecutor(max_workers=n_workers) as device:     # one evaluation per handle at a time
             g = 0
             while True:
                 if pending[g] is not None:
@@ -514,12 +529,19 @@ def _lockstep_minimise(dfit, problems, bounds, max_batch, groups=None):
                 if ask:
                     ys = np.stack([problems[i][0] for i, _ in ask])
                     xs = np.stack([x for _, x in ask])
-                    pending[g] = (device.submit(dfit.lml_batch, ys, xs), ask)
+                    pending[g] = (device.submit(evaluate, handles[g], ys, xs), ask)
                 if all(p is None for p in pending) and not any(active) and nxt >= len(problems):
                     break
                 g = (g + 1) % groups
     finally:
         sys.setswitchinterval(switch_interval)
+    # wall time with at least one evaluation inside the library (with two handles the calls overlap)
+    union, end = 0.0, -1.0
+    for t0, t1 in sorted(busy):
+        if t1 > end:
+            union += t1 - max(t0, end)
+            end = t1
+    _lockstep_minimise.last_busy_seconds = union
     return results
 
 
@@ -568,6 +590,15 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
     n_threads = max(1, min(int(n_streams), max(len(tasks), 1)))
     shared = _fit.DeviceFit(X, kk.kind, kk.nu, kk.has_const, kk.has_noise, alpha, device)
     handles = [shared]
+    # a second handle for the second group of the lock-step driver (GPEMU_FIT_HANDLES=1: both groups through one)
+    two_handles = (int(os.environ.get("GPEMU_FIT_HANDLES", "2")) >= 2 and int(os.environ.get("GPEMU_FIT_GROUPS", "2")) >= 2
+                   and len(tasks) > n_threads and n_threads > 1)
+    if two_handles:      # both handles' work matrices must fit beside each other
+        n_pad = -(-X.shape[0] // 64) * 64
+        free = _lib.device_free_bytes(device)
+        two_handles = free is None or 2.0 * 6 * 8 * n_pad * n_pad * n_threads < 0.8 * free
+    if two_handles:
+        handles.append(_fit.DeviceFit(X, kk.kind, kk.nu, kk.has_const, kk.has_noise, alpha, device))
     evaluator = _LockStepEvaluator(shared, n_threads)
     columns = [np.ascontiguousarray(Yc[:, i]) for i in range(k_gp)]
 
@@ -592,8 +623,11 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
     try:
         if n_threads > 1 and optimise and _setulb_driver_ok():
             # one host thread drives all L-BFGS-B runs through the routine's reverse-communication interface
-            driver = "lockstep (scipy.optimize._lbfgsb.setulb, one host thread, two groups alternating on the device)"
-            optima = _lockstep_minimise(shared, [(columns[i], starts[i][j]) for i, j in tasks], kk.bounds, n_threads)
+            driver = ("lockstep (scipy.optimize._lbfgsb.setulb, one host thread, two groups of runs"
+                      + (", each with its own device handle: their evaluations overlap on the device)" if two_handles
+                         else " alternating on the device)"))
+            optima = _lockstep_minimise(shared, [(columns[i], starts[i][j]) for i, j in tasks], kk.bounds, n_threads,
+                                        second=handles[1] if two_handles else None)
         else:
             driver = ("sequential (scipy.optimize.minimize)" if n_threads == 1 else
                       f"threads ({n_threads} x scipy.optimize.minimize meeting in a lock-step evaluator)")
@@ -607,6 +641,8 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
     finally:
         n_eval = sum(h.n_evaluations for h in handles)
         t_lib = sum(h.seconds_in_library for h in handles)
+        if len(handles) > 1:             # overlapping calls: the union of their intervals plus what ran outside the driver
+            t_lib = getattr(_lockstep_minimise, "last_busy_seconds", t_lib)
         for h in handles:
             h.close()
     t_fit = time.perf_counter() - t_fit

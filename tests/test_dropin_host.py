@@ -292,7 +292,17 @@ def test_lockstep_groups_alternating_on_the_device_give_the_sequential_results()
         for t in range(n):
             np.testing.assert_array_equal(got[t][0], ref[t].x)
             assert got[t][1] == ref[t].fun
-    # fewer problems than one batch: one group, nothing to alternate with
-    dev = Device()
-    got = E._lockstep_minimise(dev, problems[:3], bounds, max_batch=4)
-    assert all(np.array_equal(got[t][0], ref[t].x) for t in range(3))
+    # two handles: group 1's evaluations go through the second one, on a second worker thread; same results, and the
+    # driver reports the time with at least one evaluation in flight
+    dev, dev2 = Device(), Device()
+    got = E._lockstep_minimise(dev, problems, bounds, max_batch=4, groups=2, second=dev2)
+    assert dev.sizes and dev2.sizes and max(dev.sizes + dev2.sizes) <= 4
+    assert threading.get_ident() not in (dev.threads | dev2.threads)
+    for t in range(n):
+        np.testing.assert_array_equal(got[t][0], ref[t].x)
+        assert got[t][1] == ref[t].fun
+    assert E._lockstep_minimise.last_busy_seconds > 0.0
+    # fewer problems than one batch: one group, nothing to alternate with (the second handle stays unused)
+    dev, dev2 = Device(), Device()
+    got = E._lockstep_minimise(dev, problems[:3], bounds, max_batch=4, second=dev2)
+    assert all(np.array_equal(got[t][0], ref[t].x) for t in range(3)) and not dev2.sizes

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """bench.py's fit_c3 leg, cold (as the driver's bench run has it) and warm, with the lock-step driver's one- and
-two-group forms (GPEMU_FIT_GROUPS): one child process per setting.
+two-group forms (GPEMU_FIT_GROUPS) and one or two device handles (GPEMU_FIT_HANDLES): one child process per setting.
    python tools/fit_c3_groups.py"""
 import json
 import os
@@ -15,7 +15,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         print(label, json.dumps({k: out[k] for k in ("seconds", "seconds_in_library", "seconds_host_optimiser",
                                                          "lml_evaluations", "mean_lml")}), flush=True)
     sys.exit(0)
-for groups in ("1", "2", "1", "2"):
-    env = dict(os.environ, GPEMU_FIT_GROUPS=groups)
-    print("GPEMU_FIT_GROUPS =", groups, flush=True)
+for groups, handles in (("2", "1"), ("2", "2"), ("2", "1"), ("2", "2")):
+    env = dict(os.environ, GPEMU_FIT_GROUPS=groups, GPEMU_FIT_HANDLES=handles)
+    print("GPEMU_FIT_GROUPS =", groups, "GPEMU_FIT_HANDLES =", handles, flush=True)
     subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, check=True)
