@@ -454,16 +454,21 @@ def _lockstep_minimise(dfit, problems, bounds, max_batch, groups=None, second=No
     independent and a batched evaluation has the bits of a single one, so every run visits the points it visits alone,
     whatever group it is in.
 
-    ``second``: a second device handle (own stream, own work matrices).  The evaluations of group 1 go through it, on a
-    second worker thread, so the two groups' launch chains can be on the device TOGETHER: a chain of batched evaluations
-    leaves most CUs idle during its serial stretches (16 diagonal-block launches on one CU per problem, launches at the
-    launch floor), which the other group's chain fills."""
+    ``second``: further device handles (own stream, own work matrices), one per further group.  The evaluations of group
+    g go through handle g on a worker thread of its own, so the groups' launch chains are on the device TOGETHER: a chain
+    of batched evaluations leaves most CUs idle during its serial stretches (16 diagonal-block launches on one CU per
+    problem, launches at the launch floor), which the other groups' chains fill."""
     import concurrent.futures
     if groups is None:
         groups = int(os.environ.get("GPEMU_FIT_GROUPS", "2"))
-    groups = max(1, min(int(groups), 2)) if len(problems) > max_batch else 1
-    handles = [dfit, second if (second is not None and groups == 2) else dfit]
-    n_workers = 2 if handles[1] is not dfit else 1
+    extra = [] if second is None else (list(second) if isinstance(second, (list, tuple)) else [second])
+    # (more groups than two only where every group has a handle of its own: groups that take turns on ONE handle gain
+    # nothing beyond the second)
+    groups = max(1, min(int(groups), max(2, 1 + len(extra)))) if len(problems) > max_batch else 1
+    # no more groups than batches of problems
+    groups = max(1, min(groups, -(-len(problems) // max_batch)))
+    handles = [dfit] + [extra[g - 1] if g - 1 < len(extra) else dfit for g in range(1, groups)]
+    n_workers = len({id(h) for h in handles})
     runs = [None] * len(problems)
     results = [None] * len(problems)
     nxt = 0
@@ -590,14 +595,17 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
     n_threads = max(1, min(int(n_streams), max(len(tasks), 1)))
     shared = _fit.DeviceFit(X, kk.kind, kk.nu, kk.has_const, kk.has_noise, alpha, device)
     handles = [shared]
-    # a second handle for the second group of the lock-step driver (GPEMU_FIT_HANDLES=1: both groups through one)
-    two_handles = (int(os.environ.get("GPEMU_FIT_HANDLES", "2")) >= 2 and int(os.environ.get("GPEMU_FIT_GROUPS", "2")) >= 2
-                   and len(tasks) > n_threads and n_threads > 1)
-    if two_handles:      # both handles' work matrices must fit beside each other
+    # a handle of its own for every group of the lock-step driver (GPEMU_FIT_HANDLES=1: two groups taking turns on one)
+    n_handles = int(os.environ.get("GPEMU_FIT_HANDLES", "3"))      # measured at C3: 1.09 / 0.97 / 0.89 / 0.89-0.95 s with 1 / 2 / 3 / 4
+    n_groups = int(os.environ.get("GPEMU_FIT_GROUPS", str(max(2, n_handles))))
+    n_handles = max(1, min(n_handles, n_groups, -(-len(tasks) // max(n_threads, 1)))) if n_threads > 1 else 1
+    if n_handles > 1:    # all handles' work matrices must fit beside each other
         n_pad = -(-X.shape[0] // 64) * 64
         free = _lib.device_free_bytes(device)
-        two_handles = free is None or 2.0 * 6 * 8 * n_pad * n_pad * n_threads < 0.8 * free
-    if two_handles:
+        while n_handles > 1 and free is not None and n_handles * 6.0 * 8 * n_pad * n_pad * n_threads >= 0.8 * free:
+            n_handles -= 1
+    two_handles = n_handles > 1
+    for _ in range(n_handles - 1):
         handles.append(_fit.DeviceFit(X, kk.kind, kk.nu, kk.has_const, kk.has_noise, alpha, device))
     evaluator = _LockStepEvaluator(shared, n_threads)
     columns = [np.ascontiguousarray(Yc[:, i]) for i in range(k_gp)]
@@ -623,11 +631,11 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
     try:
         if n_threads > 1 and optimise and _setulb_driver_ok():
             # one host thread drives all L-BFGS-B runs through the routine's reverse-communication interface
-            driver = ("lockstep (scipy.optimize._lbfgsb.setulb, one host thread, two groups of runs"
-                      + (", each with its own device handle: their evaluations overlap on the device)" if two_handles
-                         else " alternating on the device)"))
+            driver = ("lockstep (scipy.optimize._lbfgsb.setulb, one host thread, "
+                      + (f"{n_handles} groups of runs, each with its own device handle: their evaluations overlap on the device)"
+                         if two_handles else "two groups of runs alternating on the device)"))
             optima = _lockstep_minimise(shared, [(columns[i], starts[i][j]) for i, j in tasks], kk.bounds, n_threads,
-                                        second=handles[1] if two_handles else None)
+                                        groups=n_groups if two_handles else None, second=handles[1:] if two_handles else None)
         else:
             driver = ("sequential (scipy.optimize.minimize)" if n_threads == 1 else
                       f"threads ({n_threads} x scipy.optimize.minimize meeting in a lock-step evaluator)")

@@ -302,6 +302,13 @@ def test_lockstep_groups_alternating_on_the_device_give_the_sequential_results()
         np.testing.assert_array_equal(got[t][0], ref[t].x)
         assert got[t][1] == ref[t].fun
     assert E._lockstep_minimise.last_busy_seconds > 0.0
+    # three groups, three handles
+    devs = [Device(), Device(), Device()]
+    got = E._lockstep_minimise(devs[0], problems, bounds, max_batch=4, groups=3, second=devs[1:])
+    assert all(d.sizes for d in devs) and max(sum((d.sizes for d in devs), [])) <= 4
+    for t in range(n):
+        np.testing.assert_array_equal(got[t][0], ref[t].x)
+        assert got[t][1] == ref[t].fun
     # fewer problems than one batch: one group, nothing to alternate with (the second handle stays unused)
     dev, dev2 = Device(), Device()
     got = E._lockstep_minimise(dev, problems[:3], bounds, max_batch=4, second=dev2)
