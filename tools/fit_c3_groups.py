@@ -15,7 +15,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         print(label, json.dumps({k: out[k] for k in ("seconds", "seconds_in_library", "seconds_host_optimiser",
                                                          "lml_evaluations", "mean_lml")}), flush=True)
     sys.exit(0)
-for groups, handles in (("2", "2"), ("3", "3"), ("4", "4"), ("2", "2"), ("3", "3"), ("4", "4")):
+for groups, handles in (("2", "1"), ("2", "2"), ("3", "3"), ("2", "1"), ("2", "2"), ("3", "3")):
     env = dict(os.environ, GPEMU_FIT_GROUPS=groups, GPEMU_FIT_HANDLES=handles)
     print("GPEMU_FIT_GROUPS =", groups, "GPEMU_FIT_HANDLES =", handles, flush=True)
     subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, check=True)
