@@ -596,7 +596,10 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
     shared = _fit.DeviceFit(X, kk.kind, kk.nu, kk.has_const, kk.has_noise, alpha, device)
     handles = [shared]
     # a handle of its own for every group of the lock-step driver (GPEMU_FIT_HANDLES=1: two groups taking turns on one)
-    n_handles = int(os.environ.get("GPEMU_FIT_HANDLES", "3"))      # measured at C3: 1.09 / 0.97 / 0.89 / 0.89-0.95 s with 1 / 2 / 3 / 4
+    # measured (tools/fit_c3_groups.py, tools/time_lml_batch_handles.py): the C3 fit 1.09 / 0.97 / 0.89 / 0.89-0.95 s with
+    # 1 / 2 / 3 / 4 handles, 64 x N = 1000 evaluations 45 / 37 / 34 / 40 us per problem; 58 x N = 5000 2.74 / 2.70 / 2.73 ms
+    # per problem -- large problems fill the chip by themselves and keep to one handle (and a third of the memory)
+    n_handles = int(os.environ.get("GPEMU_FIT_HANDLES", "3" if X.shape[0] <= 2048 else "1"))
     n_groups = int(os.environ.get("GPEMU_FIT_GROUPS", str(max(2, n_handles))))
     n_handles = max(1, min(n_handles, n_groups, -(-len(tasks) // max(n_threads, 1)))) if n_threads > 1 else 1
     if n_handles > 1:    # all handles' work matrices must fit beside each other
