@@ -14,6 +14,11 @@ import numpy as np
 
 
 def _dist():
+    """torch.distributed, or None where there cannot be a process group: torch absent -- or not imported by anybody yet in
+    a process that no launcher started (importing it costs ~1 s, a third of a C3 `fit_emulators`)."""
+    import sys
+    if "torch" not in sys.modules and (int(os.environ.get("WORLD_SIZE", "1")) <= 1 or "RANK" not in os.environ):
+        return None
     try:
         import torch.distributed as dist
         return dist if dist.is_available() else None

@@ -645,12 +645,10 @@ class EnsembleSampler:
     def world_size(self):
         if self._sharded is False:       # an independent chain on this rank (replica parallelism)
             return 1
-        try:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                return dist.get_world_size()
-        except ImportError:
-            pass
+        from . import dist as gdist
+        dist = gdist._dist()             # None in a single process that never imported torch (no ~1 s import)
+        if dist is not None and dist.is_initialized():
+            return dist.get_world_size()
         return 1
 
     def _call_rows(self, q):
