@@ -313,3 +313,21 @@ def test_lockstep_groups_alternating_on_the_device_give_the_sequential_results()
     dev, dev2 = Device(), Device()
     got = E._lockstep_minimise(dev, problems[:3], bounds, max_batch=4, second=dev2)
     assert all(np.array_equal(got[t][0], ref[t].x) for t in range(3)) and not dev2.sizes
+
+
+def test_rank_query_of_a_single_process_does_not_import_torch():
+    """`gpemu.dist.rank_world()` in a process that no launcher started and that has not imported torch: (0, 1), and
+    torch stays unimported (it costs ~1 s, a third of a C3 `fit_emulators`); under a launcher's environment the group is
+    looked for as before."""
+    import subprocess
+    import sys
+    code = ("import sys, os; sys.path.insert(0, %r); "
+            "[os.environ.pop(k, None) for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')]; "
+            "from gpemu import dist as gd; print(gd.rank_world(), 'torch' in sys.modules); "
+            "os.environ.update(RANK='0', WORLD_SIZE='2'); print(gd._dist() is not None)") % os.path.join(
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bayesian-inference_amd")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "(0, 1) False"
+    assert lines[1] == "True"          # a launcher's environment: torch.distributed is consulted
