@@ -202,6 +202,10 @@ def measure_fit_c3(device=0, n_restarts=50):
     ls0 = prob["hi"] - prob["lo"]
     kern = estimators.ARDKernel(estimators.RBF_KIND, length_scale=ls0, length_scale_bounds=np.outer(ls0, (0.01, 100.0)),
                                 noise_level=0.1, noise_level_bounds=(1e-3, 10.0))
+    # untimed: a two-GP fit of the first 128 design points -- the first launch of every kernel of the fit loads its code
+    # object (0.2-0.3 s in all), which is not the fit's time (the PCA and metric 2 are warmed the same way)
+    np.random.seed(2025)
+    estimators.fit_gps(prob["design"][:128], Y_pca[:128, :2], kern, alpha=1e-10, n_restarts_optimizer=1, device=device)
     np.random.seed(2026)
     t0 = time.perf_counter()
     gps = estimators.fit_gps(prob["design"], Y_pca[:, :N_PC], kern, alpha=1e-10, n_restarts_optimizer=n_restarts,
