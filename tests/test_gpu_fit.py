@@ -91,6 +91,23 @@ def test_first_non_positive_pivot_is_reported_like_lapack(bad):
     assert relerr(np.tril(L), np.linalg.cholesky(np.eye(n) * 4.0 + 0.01)) < 1e-13
 
 
+def test_cholesky_random_sizes_same_bits_twice_and_lapack():
+    """The column sweep of a diagonal block hands its columns from wave to wave through LDS flags: random SPD matrices of
+    many sizes (one block, several blocks, several panels) and conditionings, each factored twice -- same bits -- and
+    compared with LAPACK (tools/soak_cholesky.py is the long form)."""
+    from gpemu.fit import cholesky
+    rng = np.random.default_rng(2024)
+    for n in list(rng.integers(1, 700, size=60)) + [64, 65, 256, 257, 1100]:
+        n = int(n)
+        M = rng.normal(size=(n, n))
+        cond = 10.0 ** rng.uniform(0, 7)
+        A = M @ M.T / n + np.eye(n) / cond
+        L1, L2 = np.tril(cholesky(A)), np.tril(cholesky(A))
+        assert L1.tobytes() == L2.tobytes(), n
+        ref = np.linalg.cholesky(A)
+        assert np.max(np.abs(L1 - ref)) / np.max(np.abs(ref)) < 1e-9 * max(1.0, cond * 1e-4), (n, cond)
+
+
 def test_c3_size_fit_matches_oracle():
     """N = 1000 (BASELINE config 3): device lml/grad/factor vs the oracle at the fixed theta."""
     from gpemu.fit import DeviceFit
