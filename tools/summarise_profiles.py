@@ -46,7 +46,16 @@ for name, out in (("bench_default.json", f"{prefix}_bench_default.json"), ("emul
         if name == "dropin_c3_end_to_end.txt":
             lines = ["The whole C3 analysis THROUGH THE DROP-IN MODULES (tools/run_dropin_c3.py 50 1000 10000), one MI355X:\n"] + \
                     [ln for ln in lines if "Warning" not in ln and "warn" not in ln]
-        open(os.path.join(dst, out), "w").writelines(lines)
+        # hand-written notes appended to a committed summary (from the first line that starts one) survive a refresh
+        keep = []
+        if os.path.exists(os.path.join(dst, out)):
+            old = open(os.path.join(dst, out)).readlines()
+            marks = [i for i, ln in enumerate(old) if ln.startswith(("---- third session", "Third session of round"))]
+            if marks:
+                keep = ["\n"] + old[marks[0]:]
+        while lines and not lines[-1].strip():
+            lines.pop()
+        open(os.path.join(dst, out), "w").writelines(lines + keep)
 
 
 def pmc(dirname, counter):
