@@ -248,10 +248,13 @@ __device__ __forceinline__ void follow_fetch(const double *lt, const double *fla
 // x[J] rinv_J, then x[c] -= x[J] L[c][J] for the later c
 template <int J, bool INV>
 __device__ __forceinline__ void follow_step(const double *D, const double *flags, double (&x)[16], int c,
-                                            unsigned long long fl, double (&l)[16]) {
+                                            unsigned long long fl, double (&l)[16], int &expired) {
   if constexpr (J < 16) {
     int polls = 0;
     while (fl == SWEEP_PENDING && ++polls < (1 << 22)) follow_fetch<J, INV>(D, flags, fl, l);     // bounded: wave 0 waits for nobody
+    // (an expired wait cannot happen while wave 0 runs; were it to, the last column's would expire too: reported as
+    // info = -1, never silently)
+    if constexpr (J == 15) { if (fl == SWEEP_PENDING) expired = 1; }
     // rows below: scaled by the sweep's own 1 / sqrt(pivot) (the flag's value r0).  Inverse: by the reciprocal of the
     // diagonal element L_jj = RN(pivot r0), which the stand-alone pass (tile_inverse_diag16) and the one-wave form take
     // from an IEEE division -- ~25 instructions on this wave's path per column (measured: the wave ends 900 ticks
@@ -269,7 +272,7 @@ __device__ __forceinline__ void follow_step(const double *D, const double *flags
 #pragma unroll
     for (int k = J + 1; k < 16; ++k) x[k] = fma(-xj, l[k], x[k]);
     pin_values<J + 1, 16>(x);
-    follow_step<J + 1, INV>(D, flags, x, c, fl2, l2);
+    follow_step<J + 1, INV>(D, flags, x, c, fl2, l2, expired);
   }
 }
 
@@ -331,7 +334,9 @@ __device__ __forceinline__ void panel_step(double (*D)[NB + 1], double (*X)[NB +
       unsigned long long fl;
       double l[PB];
       follow_fetch<0, false>(lt, flags, fl, l);
-      follow_step<0, false>(lt, flags, row, 0, fl, l);
+      int expired = 0;
+      follow_step<0, false>(lt, flags, row, 0, fl, l, expired);
+      if (expired && info) __hip_atomic_store(info, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (act) {
 #pragma unroll
         for (int c = 0; c < PB; ++c) Dp[PB + lane][c] = row[c];
@@ -350,7 +355,9 @@ __device__ __forceinline__ void panel_step(double (*D)[NB + 1], double (*X)[NB +
       unsigned long long fl;
       double l[PB];
       follow_fetch<0, true>(lt, flags, fl, l);
-      follow_step<0, true>(lt, flags, acc, c, fl, l);
+      int expired = 0;
+      follow_step<0, true>(lt, flags, acc, c, fl, l, expired);
+      if (expired && info) __hip_atomic_store(info, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
       for (int ii = 0; ii < PB; ++ii) X[J0 + ii][J0 + c] = acc[ii];
     }
@@ -1466,6 +1473,7 @@ int gpemu_cholesky(int device, int64_t N, double *A_inout) {
   (void)hipFree(A); (void)hipFree(Dinv); (void)hipFree(dinfo);
   if (e != hipSuccess) { set_error("cholesky: %s", hipGetErrorString(e)); return GPEMU_ERR_HIP; }
   if (rc != GPEMU_OK) return rc;
+  if (info < 0) { set_error("cholesky: a wait inside the factorisation kernels expired"); return GPEMU_ERR_STATE; }
   if (info != 0) { set_error("matrix is not positive definite (pivot %d)", info); return info; }
   for (int64_t i = 0; i < N; ++i)
     for (int64_t j = 0; j < N; ++j) A_inout[i * N + j] = (j <= i) ? h[i * Np + j] : 0.0;
