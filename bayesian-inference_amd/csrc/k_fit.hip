@@ -111,23 +111,27 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // ---- the 16-column sweep of a panel as a pipeline of three waves -----------------------------------------------
 // Until round 4 ONE wave swept a panel: lane = row (the 16 rows of the diagonal block and the rows below it), pivot by
 // pivot, every L[c][j] fetched with two v_readlane into an SGPR pair -- 750 instructions per sweep, 5 480 ticks, four
-// sweeps = half of a 64 x 64 block's time on the serial path of the factorisation.  A wave issues an fp64 instruction
-// every ~9 ticks, whatever it is (measured: replacing the three instructions of an update by two DPP ones changed
-// nothing), so the instructions are dealt to three waves (three SIMDs) instead:
+// sweeps = half of a 64 x 64 block's time on the serial path of the factorisation.  ONE wave issues an instruction every
+// ~6 ticks, whatever it is, an s_nop included (tools/dp_latency_probe; in the sweep: replacing the three instructions of
+// an update by two DPP ones changed nothing), so the instructions are dealt to three waves (three SIMDs) instead:
 //   wave 0  factors the 16 x 16 diagonal block alone.  Lane & 15 = row, the block replicated in every row of 16 lanes,
 //           so that L[c][j] is lane c of the own row: ONE v_fmac_f64_dpp (row_newbcast is legal for 64-bit operations
 //           on gfx90a+) per update and no SGPR.  The nine dependent steps of the next pivot (broadcast, 1 / sqrt as
 //           hardware estimate + two Newton steps, scaling) are written between the updates of the current one -- a wave
-//           issues in order.  Each finished column goes to LDS at once, then its 1 / sqrt as the column's flag.
+//           issues in order.  Each finished column goes to LDS at once (a contiguous 16 x 16 column buffer), then its
+//           1 / sqrt as the column's flag.
 //   wave 1  owns the rows below (lane = row) and follows column by column: r[j] *= rinv_j, r[c] -= r[j] L[c][j] with
 //           L[c][j] a broadcast LDS read.
 //   wave 2  inverts the diagonal block as the columns arrive (lane = column of the inverse, forward substitution) -- the
 //           separate pass over the four diagonal blocks is gone.
+//   wave 3  copies the PREVIOUS panel's diagonal block from its column buffer into the block and applies the part of the
+//           previous panel's rank-16 update that this sweep does not read.
 // A flag slot holds a NaN with a payload no arithmetic produces until its value is there (LDS executes a wave's
 // instructions in order: column first, flag second; volatile accesses keep the compiler to that order).  Wave 0 waits
 // for nobody, so the followers' waits end; they are bounded all the same.
 // The arithmetic of the factor -- fma(-L[c][j], L[i][j], .) for j ascending, the scaled column -- and of the inverse
-// (IEEE 1 / L[j][j], the forward substitution's FMAs in row order) is that of the one-wave form: same bits.
+// (the correctly rounded 1 / L[j][j], the forward substitution's FMAs in row order) is that of the one-wave form: same
+// bits (tools/chol_bits.py).
 constexpr unsigned long long SWEEP_PENDING = 0x7ff8dead0000beefULL;
 // the volatile accesses name the LDS address space themselves (address-space inference leaves volatile ones generic:
 // a flat store with system scope and a wait behind it)
