@@ -181,6 +181,31 @@ def test_concurrent_gp_fits_equal_the_sequential_loop():
         assert a.log_marginal_likelihood_value_ == b.log_marginal_likelihood_value_
 
 
+@pytest.mark.parametrize("handles", ["1", "2", "3"])
+def test_group_fit_is_the_same_through_one_two_or_three_device_handles(handles, monkeypatch):
+    """GPEMU_FIT_HANDLES: the groups of the lock-step driver evaluate through a device handle each, their launch chains on
+    the device together (three by default up to N = 2048) -- or take turns on one.  Same optima bit for bit as the
+    sequential loop, whatever the number."""
+    from gpemu import estimators as E
+    g = GU.load("g1_matern15_noise")
+    spec = GU.spec_of(g)
+    X, Yc = g["design"], g["Y_pca_truncated"]
+    ls0 = g["hi"] - g["lo"]
+    kern = E.ARDKernel(kind=spec.kind, nu=spec.nu, length_scale=ls0,
+                       length_scale_bounds=np.outer(ls0, (0.01, 100.0)), noise_level=0.1,
+                       noise_level_bounds=(1e-3, 1e1))
+    np.random.seed(99)
+    one = E.fit_gps(X, Yc, kern, alpha=1e-10, n_restarts_optimizer=4, n_streams=1)
+    monkeypatch.setenv("GPEMU_FIT_HANDLES", handles)
+    np.random.seed(99)
+    par = E.fit_gps(X, Yc, kern, alpha=1e-10, n_restarts_optimizer=4, n_streams=3)       # several batches per group
+    assert (f"{handles} groups of runs, each with its own device handle" in par[0].fit_driver_) == (handles != "1")
+    for a, b in zip(one, par):
+        np.testing.assert_array_equal(a.kernel_.theta, b.kernel_.theta)
+        np.testing.assert_array_equal(a.L_, b.L_)
+        assert a.log_marginal_likelihood_value_ == b.log_marginal_likelihood_value_
+
+
 def test_batched_lml_equals_single_evaluations():
     """gpemu_fit_lml_batch: several (target, theta) pairs through ONE launch chain give, bit for bit, what the
     stand-alone evaluations give (every kernel carries the problem index, the GEMMs run batched), including a
