@@ -363,6 +363,8 @@ class _LbfgsbRun:
     sequence of points, values and the result are those of ``minimize`` (scipy/optimize/_lbfgsb_py.py: the
     objective is first evaluated at the clipped start point, which is also the first point the routine asks for)."""
 
+    _setulb = None                    # scipy.optimize._lbfgsb.setulb, looked up once
+
     def __init__(self, x0, bounds):
         n = len(x0)
         self.m, self.maxls, self.maxiter, self.maxfun = 10, 20, 15000, 15000
@@ -394,20 +396,27 @@ class _LbfgsbRun:
 
     def advance(self):
         """Run the routine up to its next request.  Returns the point to evaluate, or None when finished."""
-        from scipy.optimize import _lbfgsb
+        setulb = _LbfgsbRun._setulb
+        if setulb is None:
+            from scipy.optimize import _lbfgsb
+            setulb = _LbfgsbRun._setulb = _lbfgsb.setulb
+        task = self.task
         while True:
-            _lbfgsb.setulb(self.m, self.x, self.low, self.up, self.nbd, self.f, self.g, self.factr, self.pgtol, self.wa,
-                           self.iwa, self.task, self.lsave, self.isave, self.dsave, self.maxls, self.ln_task)
-            if self.task[0] == 3:
-                if self.last_x is not None and np.array_equal(self.x, self.last_x):
+            setulb(self.m, self.x, self.low, self.up, self.nbd, self.f, self.g, self.factr, self.pgtol, self.wa,
+                   self.iwa, task, self.lsave, self.isave, self.dsave, self.maxls, self.ln_task)
+            if task[0] == 3:
+                # (np.array_equal's answer for two finite float arrays of one shape, at a third of its cost: with ~150
+                # design points the group fit is bound by this host loop, ~13 us per evaluation of which the routine
+                # itself is two calls of ~6 us)
+                if self.last_x is not None and (self.x == self.last_x).all():
                     continue            # value already known (scipy's memo): hand it straight back
                 return self.x.copy()
-            if self.task[0] == 1:
+            if task[0] == 1:
                 self.nit += 1
                 if self.nit >= self.maxiter:
-                    self.task[0], self.task[1] = 5, 504
+                    task[0], task[1] = 5, 504
                 elif self.nfev > self.maxfun:
-                    self.task[0], self.task[1] = 5, 502
+                    task[0], task[1] = 5, 502
                 continue
             self.done = True
             return None
