@@ -422,7 +422,9 @@ class _LbfgsbRun:
             return None
 
     def supply(self, x, f, g):
-        self.f, self.g = float(f), np.asarray(g, dtype=np.float64)
+        self.f = float(f)
+        self.g = g if (type(g) is np.ndarray and g.dtype == np.float64 and g.flags.c_contiguous) else \
+            np.ascontiguousarray(g, dtype=np.float64)
         self.last_x = x
         self.nfev += 1
 
@@ -496,11 +498,15 @@ def _lockstep_minimise(dfit, problems, bounds, max_batch, groups=None, second=No
         fut, ask = pending[g]
         pending[g] = None
         lml, grad, info = fut.result()
+        # (whole-array negation and plain Python scalars: this loop runs once per evaluation of the fit, and with ~150
+        # design points the fit is bound by the host side of an evaluation, not by the device)
+        neg_lml, neg_grad, bad = (-np.asarray(lml, dtype=np.float64)).tolist(), -np.asarray(grad, dtype=np.float64), \
+            np.asarray(info).tolist()
         for j, (idx, x) in enumerate(ask):
-            if int(info[j]) != 0:       # skl _gpr.py:586-590: not positive definite -> +inf, zero gradient
+            if bad[j] != 0:             # skl _gpr.py:586-590: not positive definite -> +inf, zero gradient
                 runs[idx].supply(x, np.inf, np.zeros_like(x))
             else:
-                runs[idx].supply(x, -lml[j], -grad[j])
+                runs[idx].supply(x, neg_lml[j], neg_grad[j])
 
     def advance(g):
         """refill the group, run its optimisers to their next requests; the points asked for (may be empty)"""
