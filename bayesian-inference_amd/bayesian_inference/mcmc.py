@@ -362,7 +362,9 @@ class LoggingEnsembleSampler(EnsembleSampler):
         # advance in blocks that end on the logging steps, so that the device runs ahead of the host
         while done < n_sampling_steps:
             block = min(n_logging_steps - done % n_logging_steps, n_sampling_steps - done)
-            state = self.advance(X0 if done == 0 else None, block, **kwargs)
+            # (the ensemble itself is only wanted at the end: the shipped settings log every 10 steps, and two blocking
+            # downloads per block were a tenth of a 50 000-step run)
+            state = self.advance(X0 if done == 0 else None, block, want_state=done + block >= n_sampling_steps, **kwargs)
             done += block
             if done % n_logging_steps == 0 or done == n_sampling_steps:
                 frac = self.acceptance_fraction

@@ -677,8 +677,9 @@ class EnsembleSampler:
             self._device = False
 
     # -- running ----------------------------------------------------------------------------------
-    def advance(self, initial_state, nsteps, store=True):
-        """Run ``nsteps`` steps (from ``initial_state`` if given, else from the current state)."""
+    def advance(self, initial_state, nsteps, store=True, want_state=True):
+        """Run ``nsteps`` steps (from ``initial_state`` if given, else from the current state).  ``want_state`` = False:
+        the ensemble is not downloaded and None is returned (the blocks between two log lines of a long run)."""
         self._ensure()
         self._cache = None
         if initial_state is not None:
@@ -699,6 +700,8 @@ class EnsembleSampler:
             self._impl.run_sharded(nsteps, store)
         else:
             self._impl.run(nsteps, store)
+        if not want_state:
+            return None
         if self._device:
             X, lp = self._impl.get_state()
         else:
