@@ -76,6 +76,28 @@ def test_host_ensemble_equals_oracle_with_emcee_stream():
     np.testing.assert_array_equal(he.naccepted, nacc)
 
 
+def test_logging_blocks_neither_fetch_the_chain_nor_the_ensemble():
+    """LoggingEnsembleSampler at the shipped interval (a log line every 10 steps, ref: mcmc.py:187-204): the blocks between
+    two log lines return no state, the acceptance fraction comes from the counters (the result cache -- a copy of the
+    whole chain so far -- stays empty until somebody asks for the chain), and the chain is the one of an unbroken run."""
+    from bayesian_inference.mcmc import LoggingEnsembleSampler
+    from gpemu.sampler import EnsembleSampler
+    d, W = 3, 16
+    f = _gauss_logp(np.zeros(d), np.eye(d))
+    X0 = np.random.default_rng(5).normal(size=(W, d))
+    a = LoggingEnsembleSampler(W, d, f, seed=9, vectorize=True, sharded=False)
+    state = a.run_mcmc(X0, 47, n_logging_steps=10)
+    assert a._cache is None                                 # five log lines later: nothing was copied
+    assert a.advance(None, 3, want_state=False) is None
+    af = a.acceptance_fraction
+    assert a._cache is None and af.shape == (W,) and a.iteration == 50
+    b = EnsembleSampler(W, d, f, seed=9, vectorize=True, sharded=False)
+    b.advance(X0, 50)
+    np.testing.assert_array_equal(a.get_chain(), b.get_chain())
+    np.testing.assert_array_equal(state.coords, b.get_chain()[46])
+    np.testing.assert_array_equal(af, b.acceptance_fraction)
+
+
 def test_host_ensemble_requires_enough_walkers():
     from gpemu.sampler import HostEnsemble
     with pytest.raises(RuntimeError):
