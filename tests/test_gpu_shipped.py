@@ -70,12 +70,17 @@ def test_shipped_fit_side_at_identical_theta():
 def test_shipped_whole_fit_of_the_41_gps():
     """The three groups' GPs FITTED on the device (device scaler + PCA, Matern-1.5 + White, 2 restarts from numpy's
     global state seeded as make_g7_shipped.py seeds the reference's fit_emulators, groups in the reference's order)
-    against the reference's fitted hyper-parameters: per GP the same theta, or a no-worse optimum; at least 90 % the
-    same (ref: emulation.py:109-172 -> skl _gpr.py:299-364)."""
+    against the reference's fit (ref: emulation.py:109-172 -> skl _gpr.py:299-364).  Per GP: the reference's theta to
+    1e-6, or a CERTIFIED equivalent optimum (dropin_util.certify_fit_against_reference: no worse LML and a point
+    L-BFGS-B stops at, both in the oracle's arithmetic).  Every group's predictions: the oracle AT THE DEVICE'S THETA,
+    1e-6.  No agreement quota (round 4 asked for 37 of 41 coincidences and got 38 -- or 36, with another rounding
+    order of the Cholesky whose LMLs were all equal or better: gpurun_out/s4/gputest.log)."""
+    from bayesian_inference import emulation
     from gpemu import estimators as E
     g = GU.load("g7_shipped_config")
     names = [str(n) for n in g["group_names"]]
     lo, hi = g["lo"], g["hi"]
+    jitter = float(g["gpr_alpha"])
     np.random.seed(20260307)
     agree_all, n_all = 0, 0
     for n in names:
@@ -86,13 +91,21 @@ def test_shipped_whole_fit_of_the_41_gps():
         ls = hi - lo
         kern = E.ARDKernel(E.MATERN_KIND, length_scale=ls, length_scale_bounds=np.outer(ls, (0.01, 100)), nu=1.5,
                            noise_level=0.25, noise_level_bounds=(0.0001, 1))
-        emus = E.fit_gps(g["design"], scores[:, :k], kern, alpha=float(g["gpr_alpha"]), n_restarts_optimizer=2)
-        agree, _ = DU.check_fit_against_reference(emus, g[n + "_theta"], g[n + "_lml_value"], f"G7 {n}", min_agree=0.0)
+        emus = E.fit_gps(g["design"], scores[:, :k], kern, alpha=jitter, n_restarts_optimizer=2)
+        agree, _ = DU.certify_fit_against_reference(emus, g[n + "_theta"], g[n + "_lml_value"], f"G7 {n}", g["design"],
+                                                    g[n + "_Y_pca_truncated"], jitter)
         agree_all += int(agree.sum()); n_all += k
         for i in np.flatnonzero(agree):      # same optimum: the factorisation the reference ended with
             assert relerr(emus[i].alpha_, g[n + "_alpha"][i]) < 1e-5
-    print(f"[G7] {agree_all} of {n_all} GPs at the reference's theta")
-    assert agree_all >= 0.9 * n_all, f"only {agree_all} of {n_all} GPs reach the reference's hyper-parameters"
+        # the group's predictions from the fitted GPs against the reference's arithmetic at the SAME theta
+        res = {"PCA": {"pca": pca, "scaler": scaler, "Y_pca_truncated": scores[:, :k]}, "emulators": emus}
+        p = emulation.predict_emulation_group(g["Xq"], res, _GroupCfg(k))
+        om = DU.oracle_group_at(emus, g["design"], g[n + "_Y_pca_truncated"], g[n + "_pca_components"],
+                                g[n + "_pca_explained_variance"], g[n + "_scaler_mean"], g[n + "_scaler_scale"], jitter)
+        po = O.predict_group(g["Xq"], om)
+        assert relerr(p["central_value"], po["central_value"]) < 1e-6
+        assert relerr(p["cov"], po["cov"]) < 1e-6
+    print(f"[G7] {agree_all} of {n_all} GPs at the reference's theta, the others certified")
 
 
 def test_shipped_merged_predict_and_log_posterior():
