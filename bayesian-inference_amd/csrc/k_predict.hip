@@ -288,7 +288,11 @@ typedef __attribute__((address_space(3))) void *las_ptr;
 __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
     const double *__restrict__ Wt, const double *__restrict__ KS, double *__restrict__ out,
     const TrmmItem *__restrict__ sched, const int *__restrict__ sched_cnt, int max_items,
-    int64_t Npad, int64_t Bcap, int k, int nrb, unsigned long long *__restrict__ stamps) {
+    int64_t Npad, int64_t Bcap, int k, int nrb
+#ifdef GPEMU_TRMM_STAMPS        // diagnostic build (tools/trmm_balance.py): per-worker time stamps of a launch
+    , unsigned long long *__restrict__ stamps
+#endif
+    ) {
   constexpr int BUFD = KT * TM + KT * TILE;            // one k-tile: [W tile | K_*^T tile], 48 KiB
   __shared__ __attribute__((aligned(16))) double L0[BUFD];
   __shared__ __attribute__((aligned(16))) double L1[BUFD];
@@ -302,7 +306,9 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
   const int wm = wave >> 2, wn = wave & 3;
   const int lr = lane & 15, lk = lane >> 4;
 
+#ifdef GPEMU_TRMM_STAMPS
   if (stamps && tid == 0) stamps[blockIdx.x * 16] = __builtin_amdgcn_s_memrealtime();
+#endif
   const int nitems = sched_cnt[blockIdx.x];
   if (tid < nitems) s_items[tid] = sched[(int64_t)blockIdx.x * max_items + tid];
   __syncthreads();
@@ -372,7 +378,9 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
   dma(L0);
   dma(L1);
   tile_barrier();
+#ifdef GPEMU_TRMM_STAMPS
   if (stamps && tid == 0) stamps[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 
   d4 acc[2][2];
 #pragma unroll
@@ -459,7 +467,9 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+#ifdef GPEMU_TRMM_STAMPS
       if (stamps && tid == 0 && c_item < 13) stamps[blockIdx.x * 16 + 2 + c_item] = __builtin_amdgcn_s_memrealtime();
+#endif
       if (++c_item == nitems) return true;
       cur = my[c_item];
       c_nt = (int)(((int64_t)cur.rb * TM + TM + KT - 1) / KT);
@@ -598,7 +608,9 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
     m->sched_ncb = ncb; m->sched_cap = cap; m->sched_max_items = hit->max_items; m->sched_workers = hit->workers;
   }
   const int pe0 = prof_mark(m, st);
-  // diagnostic: per-worker time stamps of launch 600 (tools/trmm_balance.py; tests/test_gpu_shapes.py turns it on)
+#ifdef GPEMU_TRMM_STAMPS
+  // diagnostic build only (make STAMPS=1; tools/trmm_balance.py): per-worker time stamps of launch 600, dumped to the
+  // file GPEMU_TRMM_STAMP_FILE names.  The product build has neither the state nor the getenv in its launch path.
   static const char *stamp_path = getenv("GPEMU_TRMM_STAMP_FILE");
   static unsigned long long *dstamps = nullptr;
   static int stamp_calls = 0;
@@ -628,6 +640,13 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
       fclose(f);
     }
   }
+#else
+  hipLaunchKernelGGL(trmm_vsq_dma_kernel, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
+                     w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
+                     m->Npad, w.Bcap, (int)m->k, nrb);
+  GP_HIP(hipGetLastError());
+  prof_pair(m, 0, pe0, prof_mark(m, st));
+#endif
   return GPEMU_OK;
 }
 

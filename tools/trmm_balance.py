@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-worker finish times of the dominant kernel (in-kernel stamps of launch 600, GPEMU_TRMM_STAMP_FILE) and the step
-time of the same bench run."""
+time of the same bench run.  Needs the diagnostic library: `make -C bayesian-inference_amd/csrc clean all STAMPS=1`
+(the product build carries no stamp code; rebuild without STAMPS afterwards)."""
 import json, os, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
