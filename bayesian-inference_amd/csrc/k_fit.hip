@@ -17,6 +17,7 @@
 // Triangular inverse W = L^-1 by block rows with two MFMA GEMMs per block row; the inverted
 // diagonal blocks come from the Cholesky step.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 
 #include "gemm.h"
@@ -556,16 +557,21 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, int64_t lda,
 //     A_rc -= L_rs L_cs^T          for the later columns c of the panel, L_cs published by head c
 // and a head, when it arrives at its own diagonal block, factors and inverts it in LDS and publishes the inverse.
 // Publication is a release store of the panel's tag to a flag, consumption an acquire load (agent scope: the strips
-// live on different XCDs).  No deadlock: a workgroup only ever waits for heads, heads only for heads of smaller row
-// index, and workgroups start in launch order (blockIdx.x = row within the panel, heads first) -- whoever is waited
-// for has been started.  Every wait is bounded all the same (info = -1 on expiry) so that a fault cannot hang the GPU.
+// live on different XCDs).  Progress: a workgroup only ever waits for heads, heads only for heads of smaller row index.
+// With the heads at workgroups 0 .. 3 of their problem whoever is waited for was DISPATCHED before the waiter (a 1-D
+// grid is dispatched in index order: observed behaviour of this part, not a HIP guarantee).  With the one-XCD placement
+// (heads_one_xcd: heads at workgroups 0, 8, 16, 24, see the kernel) that is no longer so: workgroups 1 .. 23 of a problem
+// may sit on a CU polling for a head that has not been dispatched yet.  The invariant is then a CAPACITY one: at any
+// time at most 24 workgroups per concurrent panel launch can be blocked on an undispatched head (those of the problem
+// at the launch's dispatch frontier; every earlier problem has all its heads on the chip and drains by itself), so the
+// frontier always finds a slot as long as the device holds more than 24 x (concurrent panel launches) workgroups of
+// this kernel at once.  The host enables the placement only with a margin on that: resident workgroups (runtime
+// occupancy x CUs) >= 64 x (fit handles alive in this process), chol_heads_placement(); otherwise heads stay first.
+// Every wait is bounded all the same (info = -1 on expiry, ~1 s) so that a fault -- or a device shared with something
+// this rule does not see -- cannot hang the GPU: the evaluation fails with GPEMU_ERR_STATE and the handle stays usable.
 // The arithmetic (operand order of every MFMA chain, C - acc for the updates) is that of the three-launch path: the
-// factor has the same bits.
+// factor has the same bits, whichever placement.
 constexpr int CHOL_Q = 4;                       // blocks per panel
-#ifndef GPEMU_CHOL_HEADS_ONE_XCD
-#define GPEMU_CHOL_HEADS_ONE_XCD 1
-#endif
-constexpr bool chol_heads_one_xcd = GPEMU_CHOL_HEADS_ONE_XCD != 0;
 constexpr int CHOL_FLAGS = 4 + 4 * 4;           // per problem: D ready [4], L_cs ready [c][s]
 constexpr int CHOL_WAIT_POLLS = 1 << 20;       // ~1 s
 
@@ -629,7 +635,8 @@ __device__ __forceinline__ void strip_product(const double (*U)[NB + 1], const d
 // fault != 0 (tests only, GPEMU_CHOL_FAULT): the second head of the first panel never publishes its inverse -- the waits
 // for it must expire and the evaluation end with GPEMU_ERR_STATE.
 __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, double *Dinv, int jb0, int npb, int *info,
-                                                         int *flags, int tag, int64_t batchA, int64_t batchD, int fault) {
+                                                         int *flags, int tag, int64_t batchA, int64_t batchD, int fault,
+                                                         int heads_one_xcd) {
   A += (int64_t)blockIdx.y * batchA;
   Dinv += (int64_t)blockIdx.y * batchD;
   info += blockIdx.y;
@@ -639,12 +646,12 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int64_t Np, 
   __shared__ double T[32][32 + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lk = lane >> 4;
-  // Row of this workgroup.  Workgroups go to the XCDs round-robin in launch order; with at least 32 rows the first 32 are
-  // dealt so that the four heads (rows 0 .. 3) are workgroups 0, 8, 16, 24 -- all on one XCD: a head takes Dinv and L of the
-  // head before it from that XCD's L2 instead of across the fabric.  (Still: whoever is waited for is among the first
-  // 32 workgroups, which start together.)
+  // Row of this workgroup.  Workgroups go to the XCDs round-robin in launch order; with heads_one_xcd (host: at least 32
+  // rows and room on the device, see the progress argument above) the first 32 are dealt so that the four heads (rows
+  // 0 .. 3) are workgroups 0, 8, 16, 24 -- all on one XCD: a head takes Dinv and L of the head before it from that XCD's L2
+  // instead of across the fabric.
   const int bx = blockIdx.x;
-  const int q = (gridDim.x >= 32 && bx < 32 && chol_heads_one_xcd) ? (bx & 7) * 4 + (bx >> 3) : bx, rb = jb0 + q;
+  const int q = (heads_one_xcd && gridDim.x >= 32 && bx < 32) ? (bx & 7) * 4 + (bx >> 3) : bx, rb = jb0 + q;
   PANEL_STAMP(0);
   const bool head = q < npb;
   const int ncol = head ? q + 1 : npb;           // column blocks of the panel on or under the diagonal in this row
@@ -774,6 +781,30 @@ __global__ __launch_bounds__(256) void scatter_diag_blocks_kernel(const double *
 // Two levels: the 64-wide steps (diagonal factor, panel solve) only update the rest of their own PANEL of CHOL_Q blocks;
 // the trailing matrix beyond the panel gets ONE rank-(64 CHOL_Q) update per panel -- a quarter of the passes over it of a
 // rank-64 update per step (the update is HBM bound at K = 64: 8 FLOP per byte moved).
+// fit handles alive in this process: each may have a panel launch in flight (estimators.fit_gps runs up to three at once)
+static std::atomic<int> g_live_fit_handles{0};
+
+// May the heads of a panel sit at workgroups 0, 8, 16, 24 (one XCD) instead of 0 .. 3?  Only where the device holds,
+// with a margin, more workgroups of chol_panel_kernel than can be blocked on undispatched heads (24 per concurrent
+// panel launch): resident = runtime occupancy x CUs >= 64 x live handles.  GPEMU_CHOL_HEADS_ONE_XCD=0 / 1 forces it
+// (tests), GPEMU_CHOL_CAPACITY overrides the resident figure (tests: a small partition).  Read per call.
+static int chol_heads_placement(hipStream_t st) {
+  (void)st;
+  if (const char *e = getenv("GPEMU_CHOL_HEADS_ONE_XCD")) return atoi(e) != 0;
+  static int resident = -1;                       // per process: one device kind per process in every supported setup
+  if (resident < 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_panel_kernel, 256, 0) == hipSuccess &&
+        hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      resident = per_cu * prop.multiProcessorCount;
+    else { (void)hipGetLastError(); resident = 0; }
+  }
+  int cap = resident;
+  if (const char *e = getenv("GPEMU_CHOL_CAPACITY")) cap = atoi(e);
+  return cap >= 64 * std::max(1, g_live_fit_handles.load()) ? 1 : 0;
+}
+
 int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hipStream_t st, int nb, const CholOverlap *ov) {
   const int nblk = (int)(Np / NB);
   constexpr int chol_q = 4;
@@ -803,11 +834,12 @@ int device_cholesky_blocked(double *A, int64_t Np, double *Dinv, int *dinfo, hip
   const bool fused = panel_on && chol_q == CHOL_Q && ov && ov->flags && (int64_t)nblk * nb <= panel_max_wg;
   const int fault = getenv("GPEMU_CHOL_FAULT") ? atoi(getenv("GPEMU_CHOL_FAULT")) : 0;     // tests: a head that never publishes
   if (fused) GP_HIP(hipMemsetAsync(ov->flags, 0, sizeof(int) * (size_t)CHOL_FLAGS * nb, st));
+  const int heads_one_xcd = fused ? chol_heads_placement(st) : 0;
   for (int jb0 = 0; jb0 < nblk; jb0 += chol_q) {
     const int jb1 = std::min(nblk, jb0 + chol_q);             // the panel: blocks [jb0, jb1)
     if (fused) {
       hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)(nblk - jb0), (unsigned)nb), dim3(256), 0, st, A, Np, Dinv, jb0,
-                         jb1 - jb0, dinfo, ov->flags, jb0 / chol_q + 1, Np * Np, Np * NB, fault);
+                         jb1 - jb0, dinfo, ov->flags, jb0 / chol_q + 1, Np * Np, Np * NB, fault, heads_one_xcd);
       GP_HIP(hipGetLastError());
     }
     for (int jb = jb0; jb < jb1 && !fused; ++jb) {
@@ -1178,6 +1210,7 @@ struct gpemu_fit {
   int *info = nullptr;
   int n_gparts = 0;
   int cap = 0;              // problems the workspace holds (fit_reserve)
+  bool counted = false;     // in g_live_fit_handles (the panel kernel's head placement rule)
 };
 
 using namespace gpemu;
@@ -1372,12 +1405,15 @@ int gpemu_fit_create(gpemu_fit **out, int device, int64_t N, int64_t d, const do
     gpemu_fit_destroy(f);
     return GPEMU_ERR_HIP;
   }
+  f->counted = true;
+  g_live_fit_handles.fetch_add(1);
   *out = f;
   return GPEMU_OK;
 }
 
 int gpemu_fit_destroy(gpemu_fit *f) {
   if (!f) return GPEMU_OK;
+  if (f->counted) g_live_fit_handles.fetch_sub(1);
   (void)hipSetDevice(f->device);
   if (f->stream) (void)hipStreamSynchronize(f->stream);
   if (f->overlap.side) { (void)hipStreamSynchronize(f->overlap.side); (void)hipStreamDestroy(f->overlap.side); }

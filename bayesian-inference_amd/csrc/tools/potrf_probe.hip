@@ -75,7 +75,7 @@ int main() {
       hipMemcpy(A, h.data(), sizeof(double) * Np * Np, hipMemcpyHostToDevice);
       hipMemset(flags, 0, sizeof(int) * gpemu::CHOL_FLAGS);
       hipEventRecord(e0, nullptr);
-      hipLaunchKernelGGL(gpemu::chol_panel_kernel, dim3(rows, 1), dim3(256), 0, nullptr, A, Np, Dinv, 0, 4, info, flags, 1, Np * Np, Np * 64, 0);
+      hipLaunchKernelGGL(gpemu::chol_panel_kernel, dim3(rows, 1), dim3(256), 0, nullptr, A, Np, Dinv, 0, 4, info, flags, 1, Np * Np, Np * 64, 0, 1);
       hipEventRecord(e1, nullptr);
       hipEventSynchronize(e1);
       float ms = 0;

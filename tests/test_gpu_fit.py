@@ -368,6 +368,37 @@ def test_panel_factorisation_in_a_batch(monkeypatch):
     assert np.all(np.isfinite(np.delete(lml, 3)))
 
 
+def test_panel_head_placement_rule_and_bits(monkeypatch):
+    """The heads of a panel sit on ONE XCD (workgroups 0, 8, 16, 24) only where the device holds many more workgroups of
+    the panel kernel than can be blocked on undispatched heads (k_fit.hip: chol_heads_placement); otherwise --
+    forced off, or a pretended small partition (GPEMU_CHOL_CAPACITY) with three handles alive, each with a panel launch
+    in flight from its own host thread -- they stay at workgroups 0 .. 3.  Same bits either way, single and batched, and
+    every evaluation completes (no expired wait)."""
+    import concurrent.futures
+    from gpemu import synthetic
+    from gpemu.fit import DeviceFit
+    N = 2300                                            # 36 tile rows: the placement applies to the first panels
+    prob = synthetic.make_problem(N, 6, seed=3)
+    X = prob["design"]
+    y = prob["Y"][:, 0] - prob["Y"][:, 0].mean()
+    theta = np.log(np.r_[(prob["hi"] - prob["lo"]) * 0.4, 0.02])
+    ref = None
+    for env in ({}, {"GPEMU_CHOL_HEADS_ONE_XCD": "1"}, {"GPEMU_CHOL_HEADS_ONE_XCD": "0"}, {"GPEMU_CHOL_CAPACITY": "64"}):
+        for key in ("GPEMU_CHOL_HEADS_ONE_XCD", "GPEMU_CHOL_CAPACITY"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        fits = [DeviceFit(X, kernel_kind=0, has_noise=True, jitter=1e-10) for _ in range(3)]
+        with concurrent.futures.ThreadPoolExecutor(3) as pool:        # three launch chains on the device together
+            outs = list(pool.map(lambda f: [f.lml(y, theta, eval_gradient=True) for _ in range(3)][-1], fits))
+        for f in fits:
+            f.close()
+        ref = ref or outs[0]
+        for lml, grad in outs:
+            assert lml == ref[0], env
+            np.testing.assert_array_equal(grad, ref[1], err_msg=str(env))
+
+
 def test_panel_wait_is_bounded(monkeypatch):
     """Every wait inside the one-launch-per-panel kernel is bounded: with a head that never publishes its inverse
     (fault injection, GPEMU_CHOL_FAULT) the strips' waits expire, every later wait gives up at once, and the evaluation
