@@ -374,7 +374,7 @@ int gpemu_model_destroy(gpemu_model *m) {
   hipFree(m->exact_scratch);
   hipFree(m->blk_start); hipFree(m->blk_of);
   for (const gpemu_model::SchedEntry &en : m->sched_cache) { hipFree(en.items); hipFree(en.cnt); }
-  hipFree(m->sm_items); hipFree(m->sm_cnt);
+  for (const gpemu_model::SchedEntry &en : m->sm_cache) { hipFree(en.items); hipFree(en.cnt); }
   free_workspace(m->ws);
   for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
   if (m->stream) hipStreamDestroy(m->stream);

@@ -74,6 +74,11 @@ struct gpemu_model {
   void *sm_items = nullptr;
   int *sm_cnt = nullptr;
   int sm_ncb = -1, sm_max_items = 0, sm_workers = 0, sm_cap = 0;
+  // every small-batch schedule built so far, keyed by (ncb, cap): the stand-alone launch (cap = num_cu) and the launch
+  // shared with other groups (cap = -worker cap) alternate in a drop-in run (log_posterior(X) of a few rows between
+  // sampler blocks), and a launch in flight keeps reading the one it was given -- so none is freed before the model is
+  // (a few KB each; bounded: the oldest goes, after a stream sync, beyond 16)
+  std::vector<SchedEntry> sm_cache;
   int kernel_kind = 0;
   double nu = 0;
   int has_const = 0, has_noise = 0;

@@ -282,20 +282,32 @@ static int small_schedule_ready(gpemu_model *m, int64_t B, hipStream_t st, int w
   const int ncb = (int)(round_up(B, ST_N) / ST_N);
   const int cap = worker_cap > 0 ? -worker_cap : m->num_cu;      // (key of the one cached schedule)
   if (m->sm_ncb != ncb || m->sm_cap != cap) {
-    std::vector<SmallItem> flat;
-    std::vector<int> cnt;
-    int max_items = 0, nworkers = 0;
-    build_small_schedule(m, ncb, flat, cnt, max_items, nworkers, worker_cap);
-    if (max_items > ST_MAX_ITEMS) return GPEMU_ERR_UNSUPPORTED;
-    GP_HIP(hipStreamSynchronize(st));
-    (void)hipFree(m->sm_items);
-    (void)hipFree(m->sm_cnt);
-    m->sm_items = nullptr; m->sm_cnt = nullptr; m->sm_ncb = -1;
-    GP_HIP(hipMalloc(&m->sm_items, sizeof(SmallItem) * flat.size()));
-    GP_HIP(hipMalloc((void **)&m->sm_cnt, sizeof(int) * cnt.size()));
-    GP_HIP(hipMemcpy(m->sm_items, flat.data(), sizeof(SmallItem) * flat.size(), hipMemcpyHostToDevice));
-    GP_HIP(hipMemcpy(m->sm_cnt, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice));
-    m->sm_ncb = ncb; m->sm_cap = cap; m->sm_max_items = max_items; m->sm_workers = nworkers;
+    const gpemu_model::SchedEntry *hit = nullptr;
+    for (const auto &e : m->sm_cache)
+      if (e.ncb == ncb && e.cap == cap) hit = &e;
+    if (!hit) {
+      std::vector<SmallItem> flat;
+      std::vector<int> cnt;
+      int max_items = 0, nworkers = 0;
+      build_small_schedule(m, ncb, flat, cnt, max_items, nworkers, worker_cap);
+      if (max_items > ST_MAX_ITEMS) return GPEMU_ERR_UNSUPPORTED;     // (nothing cached or replaced: the current one stays)
+      if (m->sm_cache.size() >= 16) {                                  // bounded: drop the oldest once nothing reads it
+        GP_HIP(hipStreamSynchronize(st));
+        GP_HIP(hipStreamSynchronize(m->stream));
+        (void)hipFree(m->sm_cache.front().items);
+        (void)hipFree(m->sm_cache.front().cnt);
+        m->sm_cache.erase(m->sm_cache.begin());
+      }
+      gpemu_model::SchedEntry e{ncb, cap, nullptr, nullptr, max_items, nworkers};
+      GP_HIP(hipMalloc(&e.items, sizeof(SmallItem) * flat.size()));
+      GP_HIP(hipMalloc((void **)&e.cnt, sizeof(int) * cnt.size()));
+      GP_HIP(hipMemcpy(e.items, flat.data(), sizeof(SmallItem) * flat.size(), hipMemcpyHostToDevice));
+      GP_HIP(hipMemcpy(e.cnt, cnt.data(), sizeof(int) * cnt.size(), hipMemcpyHostToDevice));
+      m->sm_cache.push_back(e);
+      hit = &m->sm_cache.back();
+    }
+    m->sm_items = hit->items; m->sm_cnt = hit->cnt;
+    m->sm_ncb = ncb; m->sm_cap = cap; m->sm_max_items = hit->max_items; m->sm_workers = hit->workers;
   }
   return GPEMU_OK;
 }

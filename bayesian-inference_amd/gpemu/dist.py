@@ -13,11 +13,22 @@ import os
 import numpy as np
 
 
+def _env_world():
+    """WORLD_SIZE of a launcher's environment; 1 when absent, empty or not a number (some schedulers export it so:
+    a malformed value must not break a plain single-process run)."""
+    try:
+        return max(1, int(os.environ.get("WORLD_SIZE", "1")))
+    except ValueError:
+        return 1
+
+
 def _dist():
     """torch.distributed, or None where there cannot be a process group: torch absent -- or not imported by anybody yet in
-    a process that no launcher started (importing it costs ~1 s, a third of a C3 `fit_emulators`)."""
+    a process that no launcher started (importing it costs ~1 s, a third of a C3 `fit_emulators`).  So several ranks
+    are seen only if torch is imported, or RANK and WORLD_SIZE are set, BEFORE the first sampler / fit call asks for its
+    rank (INTEGRATION.md, "Multi-GPU")."""
     import sys
-    if "torch" not in sys.modules and (int(os.environ.get("WORLD_SIZE", "1")) <= 1 or "RANK" not in os.environ):
+    if "torch" not in sys.modules and (_env_world() <= 1 or "RANK" not in os.environ):
         return None
     try:
         import torch.distributed as dist
@@ -33,7 +44,7 @@ def ensure_process_group():
     dist = _dist()
     if dist is None or dist.is_initialized():
         return
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = _env_world()
     if world <= 1 or "RANK" not in os.environ:
         return
     import torch

@@ -456,7 +456,12 @@ def fit_batch_size(n_design, requested=None, device=None):
 def _lockstep_minimise(dfit, problems, bounds, max_batch, groups=None, second=None):
     """``problems``: list of (target y, start theta).  All minimisations advance together: every round takes the next
     requested point of each run of a group (at most ``max_batch``), evaluates them in ONE launch chain
-    (``gpemu_fit_lml_batch``) and hands the values back.  Returns [(theta, minimum)] in the order given.
+    (``gpemu_fit_lml_batch``) and hands the values back.  Returns ([(theta, minimum)] in the order given, seconds with at
+    least one evaluation inside the library -- the union of the handles' busy intervals).
+
+    Side effect, for the duration of the call only: with more than one group the interpreter's thread switch interval is
+    lowered to 20 us (``sys.setswitchinterval``, process wide -- other Python threads of the process switch more often
+    meanwhile) and restored in a ``finally``.
 
     ``groups`` = 2 (default when there is more than one batch of problems; GPEMU_FIT_GROUPS): two groups of runs
     alternate -- while the device evaluates the points of one (a worker thread inside the C call, the GIL released), this
@@ -561,8 +566,7 @@ def _lockstep_minimise(dfit, problems, bounds, max_batch, groups=None, second=No
         if t1 > end:
             union += t1 - max(t0, end)
             end = t1
-    _lockstep_minimise.last_busy_seconds = union
-    return results
+    return results, union
 
 
 def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy_X_train=False, device=None,
@@ -622,9 +626,10 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
         free = _lib.device_free_bytes(device)
         while n_handles > 1 and free is not None and n_handles * 6.0 * 8 * n_pad * n_pad * n_threads >= 0.8 * free:
             n_handles -= 1
+    lockstep = n_threads > 1 and optimise and _setulb_driver_ok()
+    if not lockstep:
+        n_handles = 1               # the other drivers evaluate through `shared` alone: no further work matrices
     two_handles = n_handles > 1
-    for _ in range(n_handles - 1):
-        handles.append(_fit.DeviceFit(X, kk.kind, kk.nu, kk.has_const, kk.has_noise, alpha, device))
     evaluator = _LockStepEvaluator(shared, n_threads)
     columns = [np.ascontiguousarray(Yc[:, i]) for i in range(k_gp)]
 
@@ -646,14 +651,18 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
             evaluator.leave()
 
     t_fit = time.perf_counter()
+    t_busy = None
     try:
-        if n_threads > 1 and optimise and _setulb_driver_ok():
+        for _ in range(n_handles - 1):      # inside the try: a failed allocation must not leak the handles made so far
+            handles.append(_fit.DeviceFit(X, kk.kind, kk.nu, kk.has_const, kk.has_noise, alpha, device))
+        if lockstep:
             # one host thread drives all L-BFGS-B runs through the routine's reverse-communication interface
             driver = ("lockstep (scipy.optimize._lbfgsb.setulb, one host thread, "
                       + (f"{n_handles} groups of runs, each with its own device handle: their evaluations overlap on the device)"
                          if two_handles else "two groups of runs alternating on the device)"))
-            optima = _lockstep_minimise(shared, [(columns[i], starts[i][j]) for i, j in tasks], kk.bounds, n_threads,
-                                        groups=n_groups if two_handles else None, second=handles[1:] if two_handles else None)
+            optima, t_busy = _lockstep_minimise(shared, [(columns[i], starts[i][j]) for i, j in tasks], kk.bounds, n_threads,
+                                                groups=n_groups if two_handles else None,
+                                                second=handles[1:] if two_handles else None)
         else:
             driver = ("sequential (scipy.optimize.minimize)" if n_threads == 1 else
                       f"threads ({n_threads} x scipy.optimize.minimize meeting in a lock-step evaluator)")
@@ -667,8 +676,8 @@ def fit_gps(design, Y_columns, kernel, alpha=1e-10, n_restarts_optimizer=0, copy
     finally:
         n_eval = sum(h.n_evaluations for h in handles)
         t_lib = sum(h.seconds_in_library for h in handles)
-        if len(handles) > 1:             # overlapping calls: the union of their intervals plus what ran outside the driver
-            t_lib = getattr(_lockstep_minimise, "last_busy_seconds", t_lib)
+        if len(handles) > 1 and t_busy is not None:     # overlapping calls: the union of their busy intervals
+            t_lib = t_busy
         for h in handles:
             h.close()
     t_fit = time.perf_counter() - t_fit

@@ -286,7 +286,7 @@ def test_lockstep_groups_alternating_on_the_device_give_the_sequential_results()
            for t in range(n)]
     for groups in (1, 2):
         dev = Device()
-        got = E._lockstep_minimise(dev, problems, bounds, max_batch=4, groups=groups)
+        got, _busy = E._lockstep_minimise(dev, problems, bounds, max_batch=4, groups=groups)
         assert max(dev.sizes) <= 4 and len(got) == n
         assert threading.get_ident() not in dev.threads            # evaluated on the driver's device thread
         for t in range(n):
@@ -295,23 +295,23 @@ def test_lockstep_groups_alternating_on_the_device_give_the_sequential_results()
     # two handles: group 1's evaluations go through the second one, on a second worker thread; same results, and the
     # driver reports the time with at least one evaluation in flight
     dev, dev2 = Device(), Device()
-    got = E._lockstep_minimise(dev, problems, bounds, max_batch=4, groups=2, second=dev2)
+    got, busy = E._lockstep_minimise(dev, problems, bounds, max_batch=4, groups=2, second=dev2)
     assert dev.sizes and dev2.sizes and max(dev.sizes + dev2.sizes) <= 4
     assert threading.get_ident() not in (dev.threads | dev2.threads)
     for t in range(n):
         np.testing.assert_array_equal(got[t][0], ref[t].x)
         assert got[t][1] == ref[t].fun
-    assert E._lockstep_minimise.last_busy_seconds > 0.0
+    assert busy > 0.0                      # returned, not kept in a function attribute
     # three groups, three handles
     devs = [Device(), Device(), Device()]
-    got = E._lockstep_minimise(devs[0], problems, bounds, max_batch=4, groups=3, second=devs[1:])
+    got, _busy = E._lockstep_minimise(devs[0], problems, bounds, max_batch=4, groups=3, second=devs[1:])
     assert all(d.sizes for d in devs) and max(sum((d.sizes for d in devs), [])) <= 4
     for t in range(n):
         np.testing.assert_array_equal(got[t][0], ref[t].x)
         assert got[t][1] == ref[t].fun
     # fewer problems than one batch: one group, nothing to alternate with (the second handle stays unused)
     dev, dev2 = Device(), Device()
-    got = E._lockstep_minimise(dev, problems[:3], bounds, max_batch=4, second=dev2)
+    got, _busy = E._lockstep_minimise(dev, problems[:3], bounds, max_batch=4, second=dev2)
     assert all(np.array_equal(got[t][0], ref[t].x) for t in range(3)) and not dev2.sizes
 
 
@@ -331,3 +331,16 @@ def test_rank_query_of_a_single_process_does_not_import_torch():
     lines = out.stdout.strip().splitlines()
     assert lines[0] == "(0, 1) False"
     assert lines[1] == "True"          # a launcher's environment: torch.distributed is consulted
+
+
+def test_malformed_world_size_counts_as_one(monkeypatch):
+    """An empty or non-numeric WORLD_SIZE (some schedulers export it so) is a single process, not a ValueError from the
+    first sampler call (gpemu/dist.py)."""
+    from gpemu import dist
+    for bad in ("", "abc", "0", "-3"):
+        monkeypatch.setenv("WORLD_SIZE", bad)
+        assert dist._env_world() == 1
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert dist._env_world() == 4
+    monkeypatch.delenv("WORLD_SIZE")
+    assert dist._env_world() == 1

@@ -229,3 +229,45 @@ def test_predict_full_writer_forms_agree(name, B, monkeypatch):
         np.testing.assert_allclose(out[form][0], out["mfma"][0], rtol=1e-12, atol=1e-13 * np.max(np.abs(out["mfma"][0])))
         np.testing.assert_allclose(out[form][1], out["mfma"][1], rtol=1e-11, atol=1e-13 * np.max(np.abs(out["mfma"][1])))
     dm.close()
+
+
+@pytest.mark.parametrize("kind,nu", [(O.RBF, np.inf), (O.MATERN, 1.5), (O.MATERN, 2.5)])
+def test_noise_free_emulator_with_length_scales_at_their_bounds(kind, nu):
+    """ADVICE r4 (predict_dev.h): K_* is formed on the matrix cores from the EXPANDED distance x.q - |x|^2/2 - |q|^2/2,
+    whose absolute error in the exponent grows like d (range / 2 ls)^2 eps; a noise-free emulator (alpha = 1e-10, no
+    WhiteKernel) amplifies an error in k_* by |L^-1| in var = kdiag - |L^-1 k_*|^2.  Worst case by construction: one
+    length scale at the reference's LOWER bound (0.01 x range: scaled coordinates up to +-50), the others at the upper
+    one (100 x range: the design points nearly coincide there, K ill conditioned), queries ON training points, 1e-9 / 1e-6 /
+    1e-3 of the range beside them, inside the box and five box widths outside.  Mean and variance against the oracle's
+    cdist form (skl kernels.py:1553-1582, 1708-1781; _gpr.py:441-494) at the north star's 1e-6."""
+    rng = np.random.default_rng(17)
+    N, d, k = 200, 6, 3
+    lo = np.array([0.1, 1.0, 0.0067, 0.0067, 0.0, 0.05])
+    hi = np.array([0.5, 10.0, 10.0, 10.0, 1.5, 100.0])
+    design = rng.uniform(lo, hi, (N, d))
+    spec = O.KernelSpec(kind=kind, nu=nu, has_const=False, has_noise=False)
+    gps = []
+    for p in range(k):
+        fac = np.full(d, 100.0)
+        fac[p] = 0.01                                  # PC p: dimension p at the lower bound (cond(K) ~1e7 for RBF)
+        y = np.sin(3.0 * (design[:, p] - lo[p]) / (hi[p] - lo[p])) + 0.1 * rng.normal(size=N)
+        gps.append(O.gp_fit_at_theta(design, y, np.log((hi - lo) * fac), spec, 1e-10))
+    F = 4
+    model = O.GroupModel(X_train=design, spec=spec, gps=gps, components=np.eye(k, F), explained_variance=np.ones(k),
+                         scaler_mean=np.zeros(F), scaler_scale=np.ones(F), n_pc=k)
+    rows = [design[:40]]
+    for eps_rel in (1e-9, 1e-6, 1e-3):
+        rows.append(design[40:80] + eps_rel * (hi - lo) * rng.choice([-1.0, 1.0], (40, d)))
+    rows.append(rng.uniform(lo, hi, (60, d)))
+    rows.append(hi + 5.0 * (hi - lo) * rng.uniform(0.0, 1.0, (20, d)))
+    Xq = np.concatenate(rows)
+    dm = GU.device_model(model, with_cov_unexplained=False)
+    m, v = dm.gp_predict(Xq)
+    dm.close()
+    mo, vo = O.gp_predict_all(Xq, model)
+    em = np.max(np.abs(m - mo)) / max(np.max(np.abs(mo)), 1e-300)
+    ev = np.max(np.abs(v - vo)) / max(1.0, np.max(vo))
+    print(f"[noise-free, bounds, kind {kind} nu {nu}] mean rel err {em:.2e}, variance err {ev:.2e} "
+          f"(cond-amplified: max |alpha| {max(np.max(np.abs(g.alpha)) for g in gps):.1e})")
+    assert em < 1e-6 and ev < 1e-6
+    assert np.all(v >= 0.0)
