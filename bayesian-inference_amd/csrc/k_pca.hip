@@ -702,6 +702,8 @@ extern "C" int gpemu_pca_fit(int device, int64_t N, int64_t F, const double *Y, 
   double total_var = 0.0;
   for (int c = 0; c < n; ++c) total_var += sigma[order[(size_t)c]] * sigma[order[(size_t)c]] / (double)(N - 1);
   std::vector<double> comp((size_t)F);
+  const char *flip_env = getenv("GPEMU_SVD_FLIP");          // read per call
+  const bool flip_u = flip_env && (flip_env[0] == 'u' || flip_env[0] == 'U');
   for (int64_t c = 0; c < nc; ++c) {
     const int j = order[(size_t)c];
     const double sg = sigma[j];
@@ -709,11 +711,24 @@ extern "C" int gpemu_pca_fit(int device, int64_t N, int64_t F, const double *Y, 
     // component row (length F): right singular vector of Xc
     if (!tw) for (int64_t f = 0; f < F; ++f) comp[f] = v[f];
     else for (int64_t f = 0; f < F; ++f) comp[f] = sg > 0.0 ? g[f] / sg : 0.0;
+    // svd_flip.  Default: the v-based decision of scikit-learn >= 1.5 (skl utils/extmath.py:944-952: per row of V^T the
+    // sign of its max-|.| entry, first index on ties) -- the version the goldens were made with.  GPEMU_SVD_FLIP=u: the
+    // u-based decision of the scikit-learn the reference pins (ref: pdm.lock:1998-1999 -> 1.3.0, PCA._fit_full calls
+    // svd_flip(U, Vt) with u_based_decision=True): per COLUMN of U.  U S is the data part of the work column (its
+    // rotation part when the transpose was factored), S > 0, so the deciding row of U is that of U S.
     int64_t arg = 0;
-    double best = -1.0;
-    for (int64_t f = 0; f < F; ++f)
-      if (std::fabs(comp[f]) > best) { best = std::fabs(comp[f]); arg = f; }
-    const double sign = comp[arg] < 0.0 ? -1.0 : 1.0;     // svd_flip, u_based_decision=False
+    double best = -1.0, at_arg = 0.0;
+    if (flip_u) {
+      const double *us = tw ? v : g;
+      for (int64_t i = 0; i < N; ++i)
+        if (std::fabs(us[i]) > best) { best = std::fabs(us[i]); arg = i; }
+      at_arg = us[arg];
+    } else {
+      for (int64_t f = 0; f < F; ++f)
+        if (std::fabs(comp[f]) > best) { best = std::fabs(comp[f]); arg = f; }
+      at_arg = comp[arg];
+    }
+    const double sign = at_arg < 0.0 ? -1.0 : 1.0;
     for (int64_t f = 0; f < F; ++f) components[c * F + f] = sign * comp[f];
     if (flip_argmax) flip_argmax[c] = arg;
     explained_variance[c] = sg * sg / (double)(N - 1);

@@ -166,7 +166,10 @@ int gpemu_cholesky(int device, int64_t N, double *A_inout);
  * decomposition/_pca.py:544-702, svd_flip utils/extmath.py:944-952).  Y[N*F] row-major.
  * n_components <= 0 means min(N, F).  Outputs: scaler mean_/scale_/var_ [F], pca mean_ [F],
  * components_ [nc*F], explained_variance_ / _ratio_ [nc], Y_pca [N*nc] (= U S), flip_argmax [nc]
- * (index of the max-|.| entry of each component row: the svd_flip sign decision), n_sweeps. */
+ * (index of the max-|.| entry of each component row: the svd_flip sign decision), n_sweeps.
+ * Environment GPEMU_SVD_FLIP=u (read per call): the u-based decision of the scikit-learn the reference pins (ref:
+ * pdm.lock:1998-1999 -> 1.3.0: per column of U; flip_argmax then holds the deciding ROW of U); default v: the rule of
+ * scikit-learn >= 1.5 the goldens were made with.  Physical-space outputs do not depend on it. */
 int gpemu_pca_fit(int device, int64_t N, int64_t F, const double *Y, int64_t n_components,
                   double *scaler_mean, double *scaler_scale, double *scaler_var, double *pca_mean,
                   double *components, double *explained_variance, double *explained_variance_ratio,

@@ -200,8 +200,10 @@ def scaler_fit(Y):
     return mean, scale, var
 
 
-def pca_fit(Ys, n_components=None):
+def pca_fit(Ys, n_components=None, u_based=False):
     """skl decomposition/_pca.py:544-702 (_fit_full, LAPACK gesdd) + svd_flip v-based (extmath.py:944-952).
+    ``u_based``: the decision of the scikit-learn the reference pins (1.3.0, ref: pdm.lock:1998-1999:
+    ``svd_flip(U, Vt)`` with u_based_decision=True -- per column of U, skl utils/extmath.py:934-942).
 
     Returns dict(mean, components, explained_variance, explained_variance_ratio, Y_pca, flip_argmax).
     """
@@ -210,8 +212,12 @@ def pca_fit(Ys, n_components=None):
     Xc = Ys - mean
     U, S, Vt = svd(Xc, full_matrices=False)
     ev = S ** 2 / (n - 1)
-    idx = np.argmax(np.abs(Vt), axis=1)
-    signs = np.sign(Vt[np.arange(Vt.shape[0]), idx])
+    if u_based:
+        idx = np.argmax(np.abs(U), axis=0)
+        signs = np.sign(U[idx, np.arange(U.shape[1])])
+    else:
+        idx = np.argmax(np.abs(Vt), axis=1)
+        signs = np.sign(Vt[np.arange(Vt.shape[0]), idx])
     U = U * signs[None, :]
     Vt = Vt * signs[:, None]
     evr = ev / ev.sum()

@@ -318,8 +318,41 @@ def golden_realdata(tag):
     save(f"{tag}.npz", **out)
 
 
+def golden_svd_flip_u(tag="g_svd_flip_u"):
+    """The sign rule of the scikit-learn the reference PINS (ref: pdm.lock:1998-1999 -> 1.3.0): its PCA._fit_full calls
+    ``svd_flip(U, Vt)`` with the u-based decision (per COLUMN of U the sign of its max-|.| entry), where 1.5+ -- the
+    version the other goldens were made with -- decides on the rows of Vt.  The installed 1.7.2 still exports that
+    rule: ``sklearn.utils.extmath.svd_flip(u, v, u_based_decision=True)``.  Same steps as ``_fit_full`` otherwise
+    (ref: emulation.py:109-117): StandardScaler, centre, LAPACK gesdd thin SVD.  Inputs: those of G1, G2 and G3."""
+    import scipy.linalg
+    import sklearn.preprocessing as skp
+    from sklearn.utils.extmath import svd_flip
+    out = {}
+    inputs = {"g1": synthetic.make_problem(50, 30, seed=0)["Y"], "g2": synthetic.make_problem(200, 100, seed=0)["Y"]}
+    src = os.path.join(HERE, "observables_fixture.npz")
+    if os.path.exists(src):
+        inputs["g3"] = np.load(src)["Y"]
+    for name, Y in inputs.items():
+        Ys = skp.StandardScaler().fit_transform(Y)
+        Xc = Ys - Ys.mean(axis=0)
+        U, S, Vt = scipy.linalg.svd(Xc, full_matrices=False)
+        Uu, Vu = svd_flip(U.copy(), Vt.copy(), u_based_decision=True)
+        Uv, Vv = svd_flip(U.copy(), Vt.copy(), u_based_decision=False)
+        k = 10
+        out[f"{name}_Y"] = Y
+        out[f"{name}_flip_u_argmax"] = np.argmax(np.abs(U), axis=0).astype(np.int64)        # row of U that decides
+        out[f"{name}_flip_v_argmax"] = np.argmax(np.abs(Vt), axis=1).astype(np.int64)
+        out[f"{name}_u_over_v_sign"] = np.sign(np.sum(Vu * Vv, axis=1)).astype(np.int64)    # +1: both rules agree
+        out[f"{name}_components_u"] = Vu[:k]
+        out[f"{name}_Y_pca_u"] = (Uu * S)[:, :k]
+        out[f"{name}_explained_variance"] = (S ** 2 / (Y.shape[0] - 1))[:k]
+    save(f"{tag}.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "flipu"]
+    if "flipu" in which:
+        golden_svd_flip_u()
     if "g1" in which:
         golden_synthetic("g1_rbf_noise", 50, 30, 5, "rbf_noise", 2)
         golden_synthetic("g1_matern15_noise", 50, 30, 5, "matern15_noise", 2)

@@ -155,6 +155,36 @@ def test_scaler_pca_vs_reference(name):
     assert 2 <= out["n_sweeps"] <= 30
 
 
+@pytest.mark.parametrize("name", ["g1", "g2", "g3"])
+def test_scaler_pca_u_based_sign_rule_of_the_pinned_sklearn(name, monkeypatch):
+    """GPEMU_SVD_FLIP=u: the sign rule of the scikit-learn the reference PINS (ref: pdm.lock:1998-1999 -> 1.3.0, whose
+    PCA._fit_full decides per column of U; call site ref: emulation.py:115-117) against
+    ``sklearn.utils.extmath.svd_flip(u, v, u_based_decision=True)`` on the inputs of G1-G3
+    (tests/golden/make_goldens.py: golden_svd_flip_u).  The deciding ROW INDICES of U exact; components and scores (what
+    the pickles hold and plot_emulation.py:74,103 reads) to 1e-9; and component by component the sign against the
+    default (v-based) rule as the two sklearn rules relate."""
+    from gpemu.fit import pca_fit
+    g = GU.load("g_svd_flip_u")
+    Y = g[name + "_Y"]
+    k = g[name + "_components_u"].shape[0]
+    monkeypatch.delenv("GPEMU_SVD_FLIP", raising=False)
+    out_v = pca_fit(Y)
+    monkeypatch.setenv("GPEMU_SVD_FLIP", "u")
+    out_u = pca_fit(Y)
+    assert np.array_equal(out_u["flip_argmax"][:k], g[name + "_flip_u_argmax"][:k])       # integer decisions: exact
+    assert np.array_equal(out_v["flip_argmax"][:k], g[name + "_flip_v_argmax"][:k])
+    assert relerr(out_u["components"][:k], g[name + "_components_u"]) < 1e-9
+    assert relerr(out_u["Y_pca"][:, :k], g[name + "_Y_pca_u"]) < 1e-9
+    ratio = np.sign(np.sum(out_u["components"][:k] * out_v["components"][:k], axis=1)).astype(np.int64)
+    assert np.array_equal(ratio, g[name + "_u_over_v_sign"][:k])
+    assert (ratio == -1).any(), "the two rules were meant to differ on these inputs"
+    # physical space is invariant: the reconstruction from k components does not see the rule
+    rec_u = out_u["Y_pca"][:, :k] @ out_u["components"][:k]
+    rec_v = out_v["Y_pca"][:, :k] @ out_v["components"][:k]
+    assert relerr(rec_u, rec_v) < 1e-12
+    np.testing.assert_array_equal(out_u["explained_variance"], out_v["explained_variance"])
+
+
 def test_concurrent_gp_fits_equal_the_sequential_loop():
     """fit_gps (k GPs x (1 + restarts) optimisations advancing in lock step, their log-marginal-likelihood
     evaluations batched into one launch chain: gpemu_fit_lml_batch) gives exactly what the sequential per-PC loop

@@ -37,6 +37,24 @@ def test_scaler_and_pca_exact_decisions(name):
     assert relerr(pca["Y_pca"][:, :k], g["Y_pca_truncated"]) < 1e-10
 
 
+@pytest.mark.parametrize("name", ["g1", "g2", "g3"])
+def test_pca_u_based_sign_rule_of_the_pinned_sklearn(name):
+    """The oracle's u-based svd_flip (the rule of the scikit-learn 1.3.0 the reference pins, ref: pdm.lock:1998-1999)
+    against sklearn's own ``svd_flip(u, v, u_based_decision=True)`` on the inputs of G1-G3 (golden_svd_flip_u)."""
+    g = GU.load("g_svd_flip_u")
+    Y = g[name + "_Y"]
+    mean, scale, _ = O.scaler_fit(Y)
+    k = g[name + "_components_u"].shape[0]
+    pu = O.pca_fit((Y - mean) / scale, u_based=True)
+    pv = O.pca_fit((Y - mean) / scale)
+    assert np.array_equal(pu["flip_argmax"][:k], g[name + "_flip_u_argmax"][:k])
+    assert np.array_equal(pv["flip_argmax"][:k], g[name + "_flip_v_argmax"][:k])
+    np.testing.assert_allclose(pu["components"][:k], g[name + "_components_u"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(pu["Y_pca"][:, :k], g[name + "_Y_pca_u"], rtol=0, atol=1e-10)
+    ratio = np.sign(np.sum(pu["components"][:k] * pv["components"][:k], axis=1)).astype(np.int64)
+    assert np.array_equal(ratio, g[name + "_u_over_v_sign"][:k])
+
+
 @pytest.mark.parametrize("name", SYN)
 def test_fit_at_theta_L_alpha_lml_grad(name):
     g = GU.load(name)
