@@ -485,14 +485,15 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
 }
 
 // host side: LPT schedule of the items of one launch shape (cached per model and column-tile count)
+// keep (probes only, tools/share_probe.hip): restrict the launch to the (PC, 64-row block) pairs it accepts
 static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &flat, std::vector<int> &cnt,
-                                int &max_items, int &nworkers) {
+                                int &max_items, int &nworkers, bool (*keep)(int p, int rb) = nullptr, int split_all = 0) {
   const int nrb = (int)m->vsq_nrb, k = (int)m->k;
   struct It { double cost; TrmmItem it; };
   std::vector<It> items;
   // row blocks with short K are issued as two 64-column halves; with one or two column blocks (B <= 256) there
   // are too few items for 256 workers unless every row block is
-  const int split_below = (ncb <= 2) ? nrb : nrb / 4;
+  const int split_below = (ncb <= 2 || split_all) ? nrb : nrb / 4;
   // per-item cost of the epilogue, in k-tiles.  Measured (in-kernel stamps, profiles/r03_trmm_balance.txt): workers with
   // 2 / 3 / 5 items finish at 85.3 / 87.6 / 88.5 us, but raising it to 0.4-0.9 (3 / 4 items everywhere) leaves the slowest
   // worker at 91 us: the spread is the XCDs' (means 86.6-88.2 us), not the cost model's
@@ -501,6 +502,7 @@ static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &
     const double nt = (double)(((int64_t)rb * TM + TM + KT - 1) / KT);
     for (int p = 0; p < k; ++p)
       for (int cb = 0; cb < ncb; ++cb) {
+        if (keep && !keep(p, rb)) continue;
         if (rb < split_below) {
           items.push_back({0.5 * nt + ov, TrmmItem{p, rb, cb * TILE, 1}});
           items.push_back({0.5 * nt + ov, TrmmItem{p, rb, cb * TILE + 64, 1}});
@@ -521,7 +523,7 @@ static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &
   // column-block items of one (PC, row block), equally long, start together and stream the same W rows through
   // that L2 -- and LPT runs within each XCD's workers.  Otherwise: plain LPT over all workers.
   const int nxcd = 8, ngroups = k * ncb;
-  if (nworkers == ncu && nworkers % nxcd == 0 && ngroups % nxcd == 0) {
+  if (!keep && nworkers == ncu && nworkers % nxcd == 0 && ngroups % nxcd == 0) {
     const int gper = ngroups / nxcd;
     for (const It &x : items) {
       const int g = x.it.p * ncb + x.it.col0 / TILE;

@@ -482,6 +482,7 @@ int gpemu_sampler_destroy(gpemu_sampler *s) {
   (void)hipFree(s->zz); (void)hipFree(s->logu); (void)hipFree(s->rint); (void)hipFree(s->q);
   (void)hipFree(s->factors); (void)hipFree(s->newlp); (void)hipFree(s->naccept); (void)hipFree(s->flags);
   (void)hipFree(s->chain); (void)hipFree(s->lpchain);
+  (void)hipFree(s->snapX); (void)hipFree(s->snaplp); (void)hipFree(s->snapacc);
   (void)hipFree(s->acf_part); (void)hipFree(s->acf_acf); (void)hipFree(s->acf_mean); (void)hipFree(s->acf_acf0);
   for (int h = 0; h < 2; ++h) { (void)hipFree(s->gmine[h]); (void)hipFree(s->gfull[h]); }
   delete s;
@@ -564,6 +565,46 @@ int gpemu_sampler_reset(gpemu_sampler *s) {
   GP_HIP(hipStreamSynchronize(s->stream));
   s->chain_len = 0;
   s->iterations = 0;
+  return GPEMU_OK;
+}
+
+// The chain state as it stands (ensemble, log-probabilities, acceptance counters, step / chain counters), kept on the
+// device; gpemu_sampler_restore puts it back.  The random stream is counter based (Philox: counter = step), so a block
+// of steps rerun after a restore draws what the failed attempt drew: the chain is that of an unbroken run.
+int gpemu_sampler_snapshot(gpemu_sampler *s) {
+  GP_ARG(s, "sampler");
+  GP_HIP(hipSetDevice(s->device));
+  const int64_t W = s->W;
+  if (!s->snapX) {
+    GP_HIP(hipMalloc((void **)&s->snapX, sizeof(double) * W * DPAD));
+    GP_HIP(hipMalloc((void **)&s->snaplp, sizeof(double) * W));
+    GP_HIP(hipMalloc((void **)&s->snapacc, sizeof(long long) * W));
+  }
+  GP_HIP(hipMemcpyAsync(s->snapX, s->X, sizeof(double) * W * DPAD, hipMemcpyDeviceToDevice, s->stream));
+  GP_HIP(hipMemcpyAsync(s->snaplp, s->logp, sizeof(double) * W, hipMemcpyDeviceToDevice, s->stream));
+  GP_HIP(hipMemcpyAsync(s->snapacc, s->naccept, sizeof(long long) * W, hipMemcpyDeviceToDevice, s->stream));
+  s->snap_step_counter = s->step_counter;
+  s->snap_iterations = s->iterations;
+  s->snap_chain_len = s->chain_len;
+  s->snap_valid = true;
+  return GPEMU_OK;
+}
+
+int gpemu_sampler_restore(gpemu_sampler *s) {
+  GP_ARG(s, "sampler");
+  if (!s->snap_valid) { set_error("gpemu_sampler_restore without a snapshot"); return GPEMU_ERR_STATE; }
+  GP_HIP(hipSetDevice(s->device));
+  const int64_t W = s->W;
+  GP_HIP(hipStreamSynchronize(s->stream));
+  GP_HIP(hipMemcpyAsync(s->X, s->snapX, sizeof(double) * W * DPAD, hipMemcpyDeviceToDevice, s->stream));
+  GP_HIP(hipMemcpyAsync(s->logp, s->snaplp, sizeof(double) * W, hipMemcpyDeviceToDevice, s->stream));
+  GP_HIP(hipMemcpyAsync(s->naccept, s->snapacc, sizeof(long long) * W, hipMemcpyDeviceToDevice, s->stream));
+  GP_HIP(hipMemsetAsync(s->flags, 0, sizeof(int) * 2, s->stream));
+  GP_HIP(hipStreamSynchronize(s->stream));
+  s->step_counter = s->snap_step_counter;
+  s->rng_ready_until = 0;              // the ring may hold later steps' draws in these slots: generate again
+  s->iterations = s->snap_iterations;
+  s->chain_len = s->snap_chain_len;    // rows written by the failed attempt are overwritten
   return GPEMU_OK;
 }
 
@@ -832,13 +873,19 @@ __global__ void fill_kernel(double *p, int64_t n, double v) {
 // rank): evaluate only the share rank 0 of an `emulate_world`-rank job would; everything else is rejected.
 int gpemu_sampler_run_sharded(gpemu_sampler *s, gpemu_comm *c, int64_t steps, int store_chain,
                               int emulate_world) {
-  GP_ARG(s && c && steps >= 0, "sampler / comm / steps");
-  GP_ARG(c->device == s->device, "communicator and sampler are bound to different devices");
-  GP_ARG(emulate_world >= 0 && (emulate_world == 0 || c->world == 1), "emulate_world needs a one-rank communicator");
+  GP_ARG(s && steps >= 0 && emulate_world >= 0, "sampler / steps / emulate_world");
   GP_HIP(hipSetDevice(s->device));
+  // the timing aid needs no communicator where the fused two-launch half-step applies (bench.py's scaling_model leg)
+  if (emulate_world > 0 && front_eligible_for(s, emulate_world)) return front_run(s, steps, store_chain, emulate_world, 0, true);
+  if (emulate_world > 0 && !c) {
+    set_error("emulate_world without a communicator: this sampler is outside the fused run's limits");
+    return GPEMU_ERR_UNSUPPORTED;
+  }
+  GP_ARG(c, "comm");
+  GP_ARG(c->device == s->device, "communicator and sampler are bound to different devices");
+  GP_ARG(emulate_world == 0 || c->world == 1, "emulate_world needs a one-rank communicator");
   hipStream_t st = s->stream;
   const int world = c->world;
-  if (emulate_world > 0 && front_eligible_for(s, emulate_world)) return front_run(s, steps, store_chain, emulate_world, 0, true);
   const int split = emulate_world > 0 ? emulate_world : world;
   int64_t lo[2], hi[2];
   for (int h = 0; h < 2; ++h) {

@@ -219,8 +219,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // block) order -- adjacent column blocks of a PC land on the same XCD, equally long, and start together -- and
 // the groups left over when the count is not a multiple of 8 are spread over every XCD.
 // worker_cap > 0: that many workers at most (several groups sharing one launch: k_trmm_small.hip, ..._groups)
+// keep (probes only, tools/share_probe.hip): restrict the launch to the (PC, 32-row block) pairs it accepts
 static void build_small_schedule(const gpemu_model *m, int ncb, std::vector<SmallItem> &flat, std::vector<int> &cnt,
-                                 int &max_items, int &nworkers, int worker_cap = 0) {
+                                 int &max_items, int &nworkers, int worker_cap = 0, bool (*keep)(int p, int rb) = nullptr) {
   const int nrb = (int)(m->Npad / ST_M), k = (int)m->k;
   struct It { double cost; SmallItem it; int group; };
   std::vector<It> items;
@@ -228,7 +229,8 @@ static void build_small_schedule(const gpemu_model *m, int ncb, std::vector<Smal
   for (int rb = 0; rb < nrb; ++rb) {
     const double nt = (double)(rb + 1);
     for (int p = 0; p < k; ++p)
-      for (int cb = 0; cb < ncb; ++cb) items.push_back({nt + ov, SmallItem{p, rb, cb * ST_N, 0}, p * ncb + cb});
+      for (int cb = 0; cb < ncb; ++cb)
+        if (!keep || keep(p, rb)) items.push_back({nt + ov, SmallItem{p, rb, cb * ST_N, 0}, p * ncb + cb});
   }
   std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.cost > b.cost; });
   const int ncu = worker_cap > 0 ? worker_cap : m->num_cu * small_workers_per_cu((int64_t)items.size(), m->num_cu);
@@ -236,7 +238,7 @@ static void build_small_schedule(const gpemu_model *m, int ncb, std::vector<Smal
   std::vector<std::vector<SmallItem>> per(nworkers);
   std::vector<double> load(nworkers, 0.0);
   const int nxcd = 8, ngroups = k * ncb;
-  const bool use_xcd = nworkers == ncu && nworkers % nxcd == 0 && ngroups >= nxcd;
+  const bool use_xcd = !keep && nworkers == ncu && nworkers % nxcd == 0 && ngroups >= nxcd;
   const int whole = use_xcd ? (ngroups / nxcd) * nxcd : 0;     // groups [0, whole) live on one XCD each
   const int gper = use_xcd ? ngroups / nxcd : 1;
   for (const It &x : items) {

@@ -65,6 +65,13 @@ struct gpemu_sampler {
   // XCD-aware order of the front kernel's cross-kernel workgroups, per (share size, group): device tables (k_front.hip)
   struct FrontPerm { int64_t cnt; int group, wg0; int *dperm; };
   std::vector<FrontPerm> front_perms;
+  // snapshot of the chain state (gpemu_sampler_snapshot / _restore): a block of steps that failed -- a lost peer
+  // exchange -- is rerun from here over another transport and gives the chain of an unbroken run
+  double *snapX = nullptr, *snaplp = nullptr;        // [W][DPAD], [W]
+  long long *snapacc = nullptr;                      // [W]
+  bool snap_valid = false;
+  uint64_t snap_step_counter = 0;
+  int64_t snap_iterations = 0, snap_chain_len = 0;
   // autocorrelation estimate (k_acf.hip): scratch kept between the lag blocks of one estimate
   double *acf_part = nullptr, *acf_acf = nullptr, *acf_mean = nullptr, *acf_acf0 = nullptr;
   size_t acf_part_bytes = 0, acf_acf_bytes = 0, acf_mean_bytes = 0;   // capacity of acf_part / acf_acf / acf_mean + acf_acf0

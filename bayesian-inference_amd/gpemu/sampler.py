@@ -407,6 +407,33 @@ class DeviceSampler:
                                    peer_local_stage=stage, peer_vote=cache[key])
         return cache[key]
 
+    def _run_peer_block(self, steps, store, vote):
+        """One block of steps through the fused peer-store run with a way back: the chain state is snapshot on the
+        device first; if the run fails with a LOST EXCHANGE on any rank (``vote(ok)``: every rank's outcome, all-reduced
+        -- the ranks must take the same branch), every rank restores the snapshot and False is returned: the caller
+        reruns the block over another transport.  True: the block is done.  A NaN log-probability is the model's, not
+        the transport's: raised as emcee raises it."""
+        L = _lib.lib()
+        check(L.gpemu_sampler_snapshot(self._h))
+        rc = L.gpemu_sampler_run_peer(self._h, int(steps), int(bool(store)))
+        lost = rc == -4 and "timed out" in _lib.last_error()            # GPEMU_ERR_STATE from the bounded waits
+        if rc != 0 and rc != 1 and not lost:
+            vote(False)                                                  # (the peers must not wait for this rank's vote)
+            check(rc)
+        if vote(rc in (0, 1)):
+            if rc == 1:
+                raise ValueError("Probability function returned NaN")
+            return True
+        check(L.gpemu_sampler_restore(self._h))
+        return False
+
+    def run_emulated(self, steps, world, store=False):
+        """Timing aid (bench.py's ``scaling_model``): rank 0's share of a ``world``-rank sharded run on this GPU through
+        the fused two-launch half-step, without a process group or communicator (the entries of the other ranks' shares
+        are pre-filled, so the exchange costs its local part only).  NOT a valid chain."""
+        self.last_transport = "emulated"
+        check(_lib.lib().gpemu_sampler_run_sharded(self._h, None, int(steps), int(bool(store)), int(world)))
+
     def run_sharded(self, steps, store=True, group=None, force=False, emulate_world=None, transport=None):
         """Same chain as ``run`` (every rank draws identical randomness); rank r evaluates its
         block of each half's proposals and the log-probabilities are exchanged.
@@ -436,13 +463,25 @@ class DeviceSampler:
                 # hand-backs included) have completed everywhere before anyone stores into a peer's buffer again
                 dist.barrier(group=group)
                 self.last_transport = "peer"
-                rc = L.gpemu_sampler_run_peer(self._h, int(steps), int(bool(store)))
-                if rc == 1:
-                    raise ValueError("Probability function returned NaN")
-                check(rc)
-                return None
+
+                def vote(ok):
+                    where = dev if on_device else torch.device("cpu")
+                    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=where)
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+                    return int(t.item()) == 1
+                if self._run_peer_block(int(steps), bool(store), vote):
+                    return None
+                # a peer's values did not arrive in time on some rank: every rank is back at the state before the block
+                # (restored from the device snapshot) and the block is rerun over the collective transport; the peer
+                # stores are not trusted again for this sampler
+                self.__dict__.setdefault("_peer_ok", {})[id(group) if group is not None else 0] = False
+                self.transport_info["peer_blocks_recovered"] = self.transport_info.get("peer_blocks_recovered", 0) + 1
+                logging.getLogger(__name__).warning(
+                    "sharded run: a peer exchange was lost; the block of %d steps is rerun over the collective transport "
+                    "from the state before it (same random stream: the chain is that of an unbroken run)", int(steps))
+            else:
+                self.transport_info["fallback_from_peer"] = True
             transport = "rccl"
-            self.transport_info["fallback_from_peer"] = True
         elif transport == "peer":
             transport = "rccl"          # the emulation switch lives in gpemu_sampler_run_sharded
         if on_device and transport == "rccl":

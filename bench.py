@@ -45,7 +45,7 @@ if os.environ.get("GPEMU_BENCH_REHEARSAL_WALKERS"):
 FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X datasheet fp64 matrix rate (the local guide lists none)
 
 
-def build_workload(device=0, n_design=None, n_obs=None, n_pc=None, seed=0):
+def build_workload(device=0, n_design=None, n_obs=None, n_pc=None, seed=0, kernel_kind=0, nu=np.inf):
     """Synthetic C3 model (or one of another size), built with the product's own device fit path (setup, not timed):
     standardise + PCA (gpemu_pca_fit), then kernel matrix / Cholesky / alpha at the fixed
     hyper-parameters of SURVEY.md 8d (gpemu_fit_factor).  Same generator as the goldens."""
@@ -57,7 +57,7 @@ def build_workload(device=0, n_design=None, n_obs=None, n_pc=None, seed=0):
     ls = (prob["hi"] - prob["lo"]) * 0.5
     noise = 0.05
     theta = np.log(np.r_[ls, noise])
-    fit = DeviceFit(prob["design"], kernel_kind=0, has_noise=True, jitter=1e-10, device=device)
+    fit = DeviceFit(prob["design"], kernel_kind=kernel_kind, nu=nu, has_noise=True, jitter=1e-10, device=device)
     Ls, alphas = [], []
     for i in range(N_PC):
         L, alpha, _ = fit.factor(Y_pca[:, i], theta)
@@ -99,6 +99,104 @@ def measure_shipped_shape(device=0, n_walkers=200, steps=3000):
         dmg.close()
     return {"workload": f"shipped shape: N_design=150, groups of 5 + 11 + 25 PCs (60 + 120 + 215 observables), {n_walkers} walkers",
             "us_per_step": dt / steps * 1e6, "evals_per_s": n_walkers * steps / dt, "steps": steps}
+
+
+def measure_steady(ds, dm, n_walkers, min_seconds=0.5, block=500):
+    """The headline sampler again, for at least `min_seconds` of device time and whatever --steps says (VERDICT r4 item 4:
+    the driver's --steps 20 is a 4.6 ms timed region): blocks of `block` steps until the clock says so, one timed region,
+    chain stored as in the headline pass."""
+    n_blocks = 0
+    ds.run(50)
+    dm.sync()
+    t0 = time.perf_counter()
+    while True:
+        ds.run(block)
+        n_blocks += 1
+        if n_blocks >= 4:                    # (>= 2 000 steps before the clock is looked at: no sync inside the first ones)
+            dm.sync()
+            if time.perf_counter() - t0 >= min_seconds:
+                break
+    dm.sync()
+    dt = time.perf_counter() - t0
+    steps = n_blocks * block
+    return {"steps": steps, "seconds": dt, "ms_per_step": dt / steps * 1e3, "value": n_walkers * steps / dt}
+
+
+def measure_matern15(device=0, steps=1500):
+    """The C3 workload with the kernel the reference SHIPS (ref: config/jet_substructure.yaml:58-61, rehlers.yaml:63-66:
+    Matern nu = 1.5 + White) instead of the RBF the headline is defined on: same sizes, same fixed length scales and noise
+    level, same sampler; `ms_per_step` and the cross-kernel's launch time (its base kernel is the only thing that changes)."""
+    from gpemu import synthetic
+    from gpemu.model import DeviceModel
+    from gpemu.sampler import DeviceSampler
+    wl = build_workload(device, kernel_kind=1, nu=1.5)
+    prob = wl["prob"]
+    dmm = DeviceModel(X_train=prob["design"], ls=wl["ls"], alpha=wl["alpha"], L=wl["L"], components=wl["components"],
+                      scaler_mean=wl["mean"], scaler_scale=wl["scale"], kernel_kind=1, nu=1.5, noise=wl["noise"],
+                      cov_unexplained=wl["cun"], device=device)
+    dmm.likelihood_setup(prob["y_exp"], prob["y_err"], prob["lo"], prob["hi"], 1.0)
+    ds = DeviceSampler([dmm], N_WALKERS, a=2.0, seed=1)
+    ds.set_state(synthetic.make_walkers(N_WALKERS, seed=1))
+    ds.reserve(steps + 200)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.3:
+        ds.run(100, store=False)
+        dmm.sync()
+    t0 = time.perf_counter()
+    ds.run(steps)
+    dmm.sync()
+    dt = time.perf_counter() - t0
+    dmm.profile(True)
+    ds.run(200, store=False)
+    dmm.sync()
+    prof = dmm.profile_read()
+    dmm.profile(False)
+    nacc, iters, _ = ds.counts()
+    ds.close()
+    dmm.close()
+    return {"workload": "C3 sizes with the shipped kernel: Matern nu=1.5 + White, fixed theta, 1024 walkers",
+            "steps": steps, "ms_per_step": dt / steps * 1e3, "value": N_WALKERS * steps / dt,
+            "kstar_avg_launch_us": prof["kstar"][0] / max(prof["kstar"][1], 1) * 1e3,
+            "trmm_avg_launch_us": prof["trmm_vsq"][0] / max(prof["trmm_vsq"][1], 1) * 1e3,
+            "acceptance_fraction_mean": float((nacc / max(iters, 1)).mean())}
+
+
+def measure_scaling_model(ds, dm, single_ms_per_step, steps=300):
+    """What the strong-scaling curve can be at 1024 walkers, measured on THIS GPU (no hardware curve exists: DESIGN 6):
+    rank 0's share of a 2- / 4- / 8-rank run through the fused two-launch half-step (entries of the other ranks' shares
+    pre-filled: the exchange costs its local part only, the xGMI hop is NOT in it), split into its terms with HIP events:
+    the triangular GEMM of the share, the front kernel (likelihood of the share + exchange + accept + proposal +
+    cross-kernel: latency, not throughput), the rest (RNG batch, gaps).  `floor`: the same step with the GEMM at 100 % of
+    the fp64 matrix peak and the front kernel as measured -- the speed-up NO schedule of the GEMM can exceed."""
+    out = {"single_gpu_ms_per_step": single_ms_per_step, "note": "emulated on one GPU; no cross-GPU hop; not a throughput claim"}
+    for world in (2, 4, 8):
+        try:
+            t_pre = time.perf_counter()
+            while time.perf_counter() - t_pre < 0.2:
+                ds.run_emulated(100, world)
+                dm.sync()
+            t0 = time.perf_counter()
+            ds.run_emulated(steps, world)
+            dm.sync()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            dm.profile(True)
+            ds.run_emulated(100, world)
+            dm.sync()
+            prof = dm.profile_read()
+            dm.profile(False)
+            gemm_us = prof["trmm_vsq"][0] / max(prof["trmm_vsq"][1], 1) * 1e3
+            front_us = prof["kstar"][0] / max(prof["kstar"][1], 1) * 1e3
+            share = -(-(N_WALKERS // 2) // world)
+            gemm_floor_us = N_PC * N_DESIGN ** 2 * share / (FP64_MATRIX_PEAK_TFLOPS * 1e12) * 1e6
+            floor_ms = 2.0 * (gemm_floor_us + front_us) * 1e-3
+            out[str(world)] = {"ms_per_step": ms, "speedup": single_ms_per_step / ms, "proposals_per_rank_and_half": share,
+                               "gemm_us": gemm_us, "front_us": front_us, "other_us_per_half_step": ms * 1e3 / 2 - gemm_us - front_us,
+                               "gemm_frac_of_peak": gemm_floor_us / gemm_us,
+                               "floor": {"gemm_at_peak_us": gemm_floor_us, "ms_per_step": floor_ms,
+                                         "speedup_bound": single_ms_per_step / floor_ms}}
+        except Exception as e:
+            out[str(world)] = {"error": repr(e)}
+    return out
 
 
 def measure_predict(dm, n_samples=1024, reps=20, prewarm_s=0.3):
@@ -154,7 +252,7 @@ def measure_fit_c5(device=0):
     scaler, pca, Y_pca = estimators.scale_and_pca(prob["Y"], device=device)
     t_pca = time.perf_counter() - t0
     theta = np.log(np.r_[(prob["hi"] - prob["lo"]) * 0.5, 0.05])
-    fit = DeviceFit(prob["design"], kernel_kind=0, has_noise=True, jitter=1e-10, device=device)
+    fit = DeviceFit(prob["design"], kernel_kind=kernel_kind, nu=nu, has_noise=True, jitter=1e-10, device=device)
     y = Y_pca[:, 0]
     out = {"workload": "C5: N_design=5000 x N_obs=2000", "pca_5000x2000_ms": t_pca * 1e3}
     for grad in (False, True):
@@ -558,6 +656,23 @@ def main():
         except Exception as e:
             weak = {"error": repr(e)}
 
+    steady = matern = scaling_model = None
+    if world == 1 and not args.emulate_world:
+        try:
+            ds.reserve(8000)
+            steady = measure_steady(ds, dm, N_WALKERS)
+        except Exception as e:
+            steady = {"error": repr(e)}
+        try:
+            scaling_model = measure_scaling_model(ds, dm, headline["ms_per_step"])
+        except Exception as e:
+            scaling_model = {"error": repr(e)}
+        if not args.no_fit:
+            try:
+                matern = measure_matern15(dev_index)
+            except Exception as e:
+                matern = {"error": repr(e)}
+
     predict = None
     if rank == 0 and not args.no_predict:
         try:
@@ -611,7 +726,8 @@ def main():
                                  "rccl_to_torch": tinfo.get("rccl_fallback_reason")},
                "acceptance_fraction_mean": float((nacc / max(iters, 1)).mean()),
                "roofline": roofline, "cpu_baseline": cpu, "gp_predict": predict, "fit_c5": fit_c5, "fit_c3": fit_c3,
-               "shipped_shape": shipped, "weak_scaling": weak}
+               "shipped_shape": shipped, "weak_scaling": weak,
+               "steady": steady, "matern15": matern, "scaling_model": scaling_model}
         if rehearsal:
             out["rehearsal"] = True
         print(json.dumps(out), flush=True)

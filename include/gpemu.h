@@ -256,7 +256,8 @@ int gpemu_comm_all_gather(gpemu_comm *c, const double *dsend, double *drecv, int
 /* `steps` stretch-move steps with each half's proposals split over the communicator's ranks (contiguous
  * blocks of ceil(n/world)); one 8-byte-per-proposal all-gather per half-step, no host round trip inside
  * the loop.  Same chain as gpemu_sampler_run on every rank.  emulate_world > 0 (one-rank communicator
- * only): evaluate just the share of rank 0 of an emulate_world-rank job -- a timing aid, not a valid chain. */
+ * only): evaluate just the share of rank 0 of an emulate_world-rank job -- a timing aid, not a valid chain; `c` may
+ * be NULL then where the fused two-launch half-step applies (GPEMU_ERR_UNSUPPORTED otherwise). */
 int gpemu_sampler_run_sharded(gpemu_sampler *s, gpemu_comm *c, int64_t steps, int store_chain,
                               int emulate_world);
 
@@ -285,6 +286,14 @@ int gpemu_sampler_peer_export(gpemu_sampler *s, char *handle_out64);
 int gpemu_sampler_peer_share(gpemu_sampler *s, int ranks_on_device);
 int gpemu_sampler_peer_import(gpemu_sampler *s, int world, int rank, const char *handles);
 int gpemu_sampler_run_peer(gpemu_sampler *s, int64_t steps, int store_chain);
+
+/* Snapshot / restore of the chain state on the device (ensemble, log-probabilities, acceptance counters, step and
+ * chain counters).  A block of steps whose peer exchange was lost (GPEMU_ERR_STATE from gpemu_sampler_run_peer) is
+ * rerun from the snapshot over a collective transport: the random stream is counter based, so the rerun draws what the
+ * failed attempt drew and the chain is that of an unbroken run.  Replaces nothing in the reference (its pool has no
+ * recovery: ref: mcmc.py:77-107); part of the sharded run that replaces the pool. */
+int gpemu_sampler_snapshot(gpemu_sampler *s);
+int gpemu_sampler_restore(gpemu_sampler *s);
 
 /* Philox4x32-10 block function (host copy of the device generator; for tests) */
 int gpemu_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,

@@ -768,6 +768,63 @@ def test_lost_peer_exchange_ends_in_bounded_time(tmp_path, monkeypatch):
             child.kill()
 
 
+def test_lost_peer_exchange_block_is_rerun_from_the_snapshot(tmp_path, monkeypatch):
+    """a lost exchange no longer ends the run.  Rank 0 of a two-rank "world" whose rank 1 exported its
+    buffer and never runs: the fused block times out, the ranks' vote (here: this rank's own outcome) says so, the
+    chain state comes back from the device snapshot (gpemu_sampler_snapshot / _restore) and the block is rerun over
+    another transport (here: the single-GPU run).  The random stream is counter based, so the chain -- positions,
+    log-probabilities, acceptance counts -- is that of an unbroken run, also for the block after."""
+    import ctypes as C
+    import time
+    import torch.multiprocessing as mp
+    from gpemu import _lib, synthetic
+    from gpemu.sampler import DeviceSampler
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    monkeypatch.setenv("GPEMU_PEER_TIMEOUT_MS", "300")
+    ctx = mp.get_context("spawn")
+    child = ctx.Process(target=_absent_peer, args=(str(tmp_path),))
+    child.start()
+    try:
+        t0 = time.time()
+        while not (tmp_path / "handle.bin").exists():
+            assert time.time() - t0 < 110 and child.is_alive(), "the absent peer never exported its buffer"
+            time.sleep(0.05)
+        theirs = (tmp_path / "handle.bin").read_bytes()
+        g, model, dm, _ = _setup()
+        L = _lib.lib()
+        W = 24
+        X0 = synthetic.make_walkers(W, seed=3, lo=g["lo"], hi=g["hi"])
+        ds = DeviceSampler([dm], W, seed=7)
+        ds.set_state(X0)
+        ds.run(4)                                        # a block before: the snapshot is not the initial state
+        mine = (C.c_char * 64)()
+        _lib.check(L.gpemu_sampler_peer_export(ds._h, C.cast(mine, C.c_void_p)))
+        both = C.create_string_buffer(mine.raw + theirs, 128)
+        _lib.check(L.gpemu_sampler_peer_import(ds._h, 2, 0, C.cast(both, C.c_void_p)))
+        votes = []
+
+        def vote(ok):
+            votes.append(ok)
+            return ok
+        assert ds._run_peer_block(6, True, vote) is False          # lost, restored
+        assert votes == [False]
+        ds.run(6)                                                   # the rerun of the block, then the next block
+        ds.run(3)
+        ref = DeviceSampler([dm], W, seed=7)
+        ref.set_state(X0)
+        ref.run(13)
+        np.testing.assert_array_equal(ds.get_chain()[0], ref.get_chain()[0])
+        np.testing.assert_array_equal(ds.get_chain()[1], ref.get_chain()[1])
+        np.testing.assert_array_equal(ds.counts()[0], ref.counts()[0])
+        assert ds.counts()[1:] == ref.counts()[1:]
+        ds.close(); ref.close(); dm.close()
+    finally:
+        (tmp_path / "done").write_text("x")
+        child.join(60)
+        if child.is_alive():
+            child.kill()
+
+
 def _multigroup_models():
     g = GU.load("g5_multigroup")
     models = {grp: GU.group_model(g, prefix=grp + "_") for grp in ("g1", "g2")}
