@@ -221,8 +221,11 @@ __device__ __forceinline__ double front_kstar_block(const FrontGroup &gk, const 
 // JTW: j-tiles per wave of the cross-kernel workgroups: 1 = 32 training rows per workgroup, 2 = 64.  KBIG: a group has
 // 17 ... 32 PCs -- its likelihood in registers like the smaller ones (walker_loglik_lowrank<32>: 256 VGPRs; the
 // instantiation without it keeps the 168 of the C3-sized run)
+// (KBIG: two workgroups per CU instead of three -- at the three-per-CU budget of 168 VGPRs the 32-PC likelihood spilled
+// 9 registers to scratch; the launches that take this instantiation are those of the shipped shape, a few hundred
+// workgroups: all resident either way)
 template <int JTW, bool KBIG>
-__global__ __launch_bounds__(256, 3) void front_kernel(FrontArgs fa) {
+__global__ __launch_bounds__(256, KBIG ? 2 : 3) void front_kernel(FrontArgs fa) {
   __shared__ double s_tab[1 << KSTAR_TB];
   __shared__ __attribute__((aligned(16))) double s_q[64 * DPAD];
   __shared__ double s_eff[2][64][DPAD];

@@ -141,7 +141,7 @@ class DeviceSampler:
         self.W, self.d = int(n_walkers) * self.n_chains, self.models[0].d
         self.ns = ((self.W + 1) // 2, self.W // 2)
         self.device = self.models[0].device
-        self.last_transport = None       # what the last run_sharded call really took: "peer" / "rccl" / "torch" / "single"
+        self.last_transport = None       # what the last run_sharded call really took: "peer" / "rccl" / "torch" / "single" / "replicated"
         self.transport_info = {}         # self-test results, communicator sizes, fall-back reasons
 
     def close(self):
@@ -407,6 +407,16 @@ class DeviceSampler:
                                    peer_local_stage=stage, peer_vote=cache[key])
         return cache[key]
 
+    def worth_sharding(self):
+        """Is a half-step of this sampler large enough for walker sharding to pay?  Arithmetic of one half-step on one
+        GPU, sum over the groups of k Npad^2 x proposals (the triangular GEMM), against GPEMU_SHARD_MIN_GFLOP
+        (default 1.0).  Measured: C3 (5.4 GFLOP per half-step) 116 us on one GPU against 36 us for a rank's share of 8;
+        the shipped three-group shape (0.27 GFLOP) 42 us on one GPU against 59 us through the fused half-step at ANY world
+        size (profiles/r04_shipped_shape_step.txt) -- below about 1 GFLOP the step is launch latency, which sharding adds
+        to."""
+        gflop = sum(m.k * (-(-m.N // 128) * 128) ** 2 for m in self.models) * self.ns[0] / self.n_chains / 1e9
+        return gflop >= float(os.environ.get("GPEMU_SHARD_MIN_GFLOP", "1.0"))
+
     def _run_peer_block(self, steps, store, vote):
         """One block of steps through the fused peer-store run with a way back: the chain state is snapshot on the
         device first; if the run fails with a LOST EXCHANGE on any rank (``vote(ok)``: every rank's outcome, all-reduced
@@ -455,6 +465,14 @@ class DeviceSampler:
         L = _lib.lib()
         dev = torch.device("cuda", self.device)
         on_device = dist.get_backend(group) == "nccl"
+        if transport is None and "GPEMU_SHARDED_TRANSPORT" not in os.environ and not emulate_world and not self.worth_sharding():
+            # A small model: a half-step on ONE GPU is a handful of ~10 us launches (the reference's shipped shape:
+            # 84 us per step), and the two-launch fused half-step every transport of a sharded run pays is slower than
+            # that (119 us at the same shape, before any hop): sharding would be a regression.  Every rank holds the whole
+            # ensemble and draws the same randomness, so each simply runs the chain itself -- the same chain, no exchange.
+            self.last_transport = "replicated"
+            self.transport_info["requested"] = "replicated (small model: below GPEMU_SHARD_MIN_GFLOP per half-step)"
+            return self.run(steps, store)
         transport = transport or os.environ.get("GPEMU_SHARDED_TRANSPORT", "peer")
         self.transport_info["requested"] = transport
         if transport == "peer" and not emulate_world:

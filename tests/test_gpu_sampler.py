@@ -843,6 +843,9 @@ def _sharded_multigroup_worker(rank, world, port, out_dir, fused):
     os.environ["MASTER_PORT"] = str(port)
     if not fused:
         os.environ["GPEMU_NO_FUSED"] = "1"       # read once per process by the library: set before its first use
+    # (a model this small would be REPLICATED by default -- sampler.worth_sharding -- instead of sharded: the threshold
+    # is taken away so that the default transport choice is what runs)
+    os.environ["GPEMU_SHARD_MIN_GFLOP"] = "0"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gpemu.sampler import DeviceSampler
     g, dms = _multigroup_models()

@@ -235,7 +235,12 @@ def _sharded_shipped_worker(rank, world, port, out_dir):
     W = 26
     ds = DeviceSampler(dms, W, seed=77)
     ds.set_state(synthetic.make_walkers(W, seed=12, lo=g["design"].min(0), hi=g["design"].max(0)))
-    ds.run_sharded(3)
+    # by default a model of the shipped size is replicated, not sharded (sampler.worth_sharding: a step is ~10 us
+    # launches, which sharding adds to); first that, then the sharded run itself with the threshold taken away
+    ds.run_sharded(1)
+    assert ds.last_transport == "replicated"
+    os.environ["GPEMU_SHARD_MIN_GFLOP"] = "0"
+    ds.run_sharded(2)
     ds.run_sharded(4)
     chain, lps = ds.get_chain()
     np.save(os.path.join(out_dir, f"chain_{rank}.npy"), chain)

@@ -261,3 +261,19 @@ def test_unseeded_sharded_sampler_uses_rank0_seed_gloo_world2(tmp_path):
     es = EnsembleSampler(14, 3, f, vectorize=True, seed=s0, sharded=False)
     es.run_mcmc(np.random.default_rng(5).normal(size=(14, 3)), 12)
     np.testing.assert_array_equal(es.get_chain(), c0)     # the single-process chain for that seed
+
+
+def test_small_models_are_replicated_not_sharded(monkeypatch):
+    """DeviceSampler.worth_sharding: the C3 shape (5.4 GFLOP per half-step) shards, the reference's
+    shipped three-group shape (0.27 GFLOP: a step is ~10 us launches, which the fused half-step of a sharded run adds to)
+    does not -- every rank then runs the chain itself; GPEMU_SHARD_MIN_GFLOP moves the threshold."""
+    import types
+    from gpemu.sampler import DeviceSampler
+    monkeypatch.delenv("GPEMU_SHARD_MIN_GFLOP", raising=False)
+    mk = lambda N, k: types.SimpleNamespace(N=N, k=k)
+    c3 = types.SimpleNamespace(models=[mk(1000, 10)], ns=(512, 512), n_chains=1)
+    shipped = types.SimpleNamespace(models=[mk(150, 5), mk(150, 11), mk(150, 25)], ns=(100, 100), n_chains=1)
+    assert DeviceSampler.worth_sharding(c3) is True
+    assert DeviceSampler.worth_sharding(shipped) is False
+    monkeypatch.setenv("GPEMU_SHARD_MIN_GFLOP", "0")
+    assert DeviceSampler.worth_sharding(shipped) is True
