@@ -221,11 +221,16 @@ __device__ __forceinline__ double front_kstar_block(const FrontGroup &gk, const 
 // JTW: j-tiles per wave of the cross-kernel workgroups: 1 = 32 training rows per workgroup, 2 = 64.  KBIG: a group has
 // 17 ... 32 PCs -- its likelihood in registers like the smaller ones (walker_loglik_lowrank<32>: 256 VGPRs; the
 // instantiation without it keeps the 168 of the C3-sized run)
-// (KBIG: two workgroups per CU instead of three -- at the three-per-CU budget of 168 VGPRs the 32-PC likelihood spilled
-// 9 registers to scratch; the launches that take this instantiation are those of the shipped shape, a few hundred
-// workgroups: all resident either way)
+// The KBIG instantiation spills 9 VGPRs (40 B of scratch per lane) at the three-workgroups-per-CU budget of 168 registers; at two
+// per CU (-DGPEMU_FRONT_KBIG_WPE=2) it takes 190 and spills nothing.  Three stays: measured on the shipped three-group
+// shape (tools/ab_front_spill.sh, profiles/r05_front_spill.txt) the spill costs nothing that shows, and two per CU is a
+// third less room where several ranks share a device (the two-rank rehearsal of the shipped shape no longer fits: 660
+// workgroups against 512).
+#ifndef GPEMU_FRONT_KBIG_WPE
+#define GPEMU_FRONT_KBIG_WPE 3
+#endif
 template <int JTW, bool KBIG>
-__global__ __launch_bounds__(256, KBIG ? 2 : 3) void front_kernel(FrontArgs fa) {
+__global__ __launch_bounds__(256, KBIG ? GPEMU_FRONT_KBIG_WPE : 3) void front_kernel(FrontArgs fa) {
   __shared__ double s_tab[1 << KSTAR_TB];
   __shared__ __attribute__((aligned(16))) double s_q[64 * DPAD];
   __shared__ double s_eff[2][64][DPAD];
@@ -268,11 +273,10 @@ __global__ __launch_bounds__(256, KBIG ? 2 : 3) void front_kernel(FrontArgs fa) 
   const int cb = gl % fa.ncolblk;
   // which (row chunk, PC) of column block cb: in index order, or -- XCD-aware -- the one whose K_*^T rows the triangular
   // GEMM will read from THIS workgroup's XCD (workgroup i runs on XCD i % 8; front_perm_for).  Needed only after the
-  // waits below, which hide the load.
-  const int rest = (gk.perm && g < fa.nkstar) ? gk.perm[gl] : gl / fa.ncolblk;
-  const int chunk = rest % gk.nchunk;
-  const int p = rest / gk.nchunk;
-  const int64_t b = (int64_t)cb * 64 + lane;
+  // waits below, which hide the load -- except with the 32-PC likelihood (KBIG), which has no register to carry it
+  // across (the instantiation spilled 9 VGPRs at the three-workgroups-per-CU budget): there it is asked for afterwards.
+  int rest = 0;
+  if (!KBIG) rest = (gk.perm && g < fa.nkstar) ? gk.perm[gl] : gl / fa.ncolblk;
   const bool does_kstar = fa.have_next && g < fa.nkstar;
   const bool does_ll = fa.have_prev && g < fa.n_llwg;
   if (does_kstar && threadIdx.x < (1 << KSTAR_TB)) s_tab[threadIdx.x] = gk.etab[threadIdx.x];
@@ -304,6 +308,10 @@ __global__ __launch_bounds__(256, KBIG ? 2 : 3) void front_kernel(FrontArgs fa) 
     }
   }
   if (!does_kstar) return;
+  if (KBIG) rest = gk.perm ? gk.perm[gl] : gl / fa.ncolblk;
+  const int chunk = rest % gk.nchunk;
+  const int p = rest / gk.nchunk;
+  const int64_t b = (int64_t)cb * 64 + lane;
   // the workgroup's training fragments.  Requested here, not at the top: held across the waits below they cost 12-24
   // VGPRs (174 / 186 instead of 162) and with them the third resident workgroup per CU -- measured slower at 2 and 4
   // ranks (0.175 / 0.115 vs 0.170 / 0.109 ms per step), equal at 8

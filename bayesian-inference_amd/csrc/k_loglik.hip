@@ -189,6 +189,9 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  // overlapped run: this launch follows the triangular GEMM in its stream, so K_*^T may be overwritten from here on
+  if (aa.gemm_word && threadIdx.x == 0 && blockIdx.x == 0)
+    __hip_atomic_store(aa.gemm_word, aa.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (b >= B) return;  // whole wave exits together; no workgroup barriers below
   if (aa.chain_per) {  // several chains stacked: this row's chain selects the data constants
     const int64_t ch = (aa.first + b) / aa.chain_per;

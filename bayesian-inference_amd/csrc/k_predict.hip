@@ -147,6 +147,134 @@ __global__ __launch_bounds__(256, 2) void kstar_groups_kernel(KstarGroups kg, Pr
   kstar_body<KIND, KS, JTW, NBW>(kg.g[gi], pa, (int)blockIdx.x - kg.start[gi], gi == 0);
 }
 
+// ---- the cross-kernel as a PRODUCER beside the triangular GEMM (round 5) ----------------------------
+// One launch on a second stream, at most two workgroups per CU (they fit beside the GEMM's one: 2 x 128 VGPRs and
+// 2 x 5.5 KiB of LDS are what the GEMM leaves), each PERSISTENT over the 64-row chunks s, s + S, ... of ONE (PC, 64-column
+// block): the stretch proposal of its columns is formed once, and the chunks of all workgroups come out in ascending
+// order -- the order in which the GEMM's k-tiles consume them.  A workgroup
+//   waits (bounded) until the half-step before is through for what it touches: the GEMM that read K_*^T (gemm_word,
+//     stored by the first wave of the likelihood kernel that follows that GEMM in its stream) and the accept / reject
+//     of the two walkers of each of its proposals, where those proposed in the half before (stamp[walker] == serial - 1,
+//     stored by the likelihood wave of that walker behind its write-through state stores);
+//   loads the walkers' positions sc1, forms the proposal (kstar_body's arithmetic: the same bits), and per chunk
+//   stores K_*^T write-through, drains its stores, and stores the launch's serial into flags[p][chunk][column block].
+// Nothing here waits for the GEMM of its own half-step, so the pair cannot deadlock; the GEMM waits for these flags.
+struct KstarOverlap {
+  unsigned *flags;              // [k][nchunk][ncb64]
+  unsigned serial;
+  const unsigned *stamp;        // [W]
+  const unsigned *gemm_word;    // [1]
+  const int *inds_chk;          // [W] split the half before was drawn from; a walker proposed in it iff inds_chk[w] == chk_val
+  int chk_val;
+  int S;                        // workgroups per (PC, column block): chunk = s, s + S, ...
+  int *err;
+  int max_polls;
+  double *factors;              // [n] (d - 1) log z of the proposals (kept for the accept), or null
+  int fault;                    // tests only (GPEMU_OVERLAP_FAULT): workgroup 0 never publishes its first chunk
+};
+
+template <int KIND, int KS>
+__global__ __launch_bounds__(256, 2) void kstar_persist_kernel(KstarArgs ka, ProposeArgs pa, KstarOverlap ko) {
+  __shared__ double s_tab[1 << KSTAR_TB];
+  __shared__ __attribute__((aligned(16))) double s_q[64 * DPAD];
+  __shared__ double s_red[2 * 64];                              // (two wave rows: JTW = NBW = 2)
+  constexpr int JTW = 2, NBW = 2, JT = 2 * JTW;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bidx = (int)blockIdx.x;
+  int p, cb, sidx;
+  if (ka.gper > 0) {            // XCD-aware: the rows are written on the XCD whose GEMM workers read them (kstar_body)
+    const int xcd = bidx & 7, slot = bidx >> 3, cpx = 2 * ka.gper;
+    const int cl = slot % cpx, g = xcd * ka.gper + (cl >> 1);
+    sidx = slot / cpx;
+    p = g / ka.ncbp;
+    cb = 2 * (g % ka.ncbp) + (cl & 1);
+  } else {
+    const int ncombos = ka.k * ka.ncb64, c = bidx % ncombos;
+    sidx = bidx / ncombos;
+    p = c / ka.ncb64;
+    cb = c % ka.ncb64;
+  }
+  const int64_t b0 = (int64_t)cb * 64, b = b0 + lane;
+  const int c0 = wave, c1 = wave + 4;
+  const int64_t njt = ka.Npad / 16;
+  if (threadIdx.x < (1 << KSTAR_TB)) s_tab[threadIdx.x] = ka.etab[threadIdx.x];
+  // the draws of this column's proposal (RNG ring: written long before)
+  const bool live = b < pa.n;
+  int w = 0, j = 0;
+  double z = 1.0;
+  if (live) { w = pa.idx_s[b]; j = pa.partner[b]; z = pa.zz[b]; }
+  // ---- wait for the half-step before ----
+  // Two phases, so that the ~500 resident producers of the NEXT half-step cost the running GEMM next to nothing: first one
+  // lane per workgroup naps on gemm_word (it flips when the likelihood kernel behind that GEMM starts: ~100 us of ~1 us
+  // naps), only then the 64 lanes look at their walkers' stamps, which follow within the few us that kernel runs.
+  if (wave == 0) {
+    const unsigned want = ko.serial - 1u;
+    int polls = 0;
+    bool lost = false;
+    for (;;) {
+      const unsigned g = __hip_atomic_load(ko.gemm_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)(g - want) >= 0) break;
+      if (++polls > ko.max_polls) { lost = true; break; }   // every workgroup reaches this exit: the grid always drains
+      __builtin_amdgcn_s_sleep(32);
+    }
+    const bool chk_w = live && ko.inds_chk[w] == ko.chk_val, chk_j = live && ko.inds_chk[j] == ko.chk_val;
+    polls = 0;
+    while (!lost) {
+      bool ok = true;
+      if (chk_w) ok = (int)(__hip_atomic_load(ko.stamp + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0;
+      if (chk_j) ok = ok && (int)(__hip_atomic_load(ko.stamp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0;
+      if (__all(ok)) break;
+      if (++polls > ko.max_polls) { lost = true; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (lost && lane == 0) atomicAdd(ko.err, 1);
+  }
+  __syncthreads();
+  // ---- stretch proposal of column b, two components per thread (kstar_body; the walkers' positions sc1) ----
+  double q0 = 0.0, q1 = 0.0;
+  if (live) {
+    if (c0 < pa.d) {
+      const double cj = __hip_atomic_load(pa.X + (int64_t)j * DPAD + c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double sw = __hip_atomic_load(pa.X + (int64_t)w * DPAD + c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      q0 = cj - (cj - sw) * z;                       // emcee moves/stretch.py get_proposal
+    }
+    if (c1 < pa.d) {
+      const double cj = __hip_atomic_load(pa.X + (int64_t)j * DPAD + c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double sw = __hip_atomic_load(pa.X + (int64_t)w * DPAD + c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      q1 = cj - (cj - sw) * z;
+    }
+  }
+  if (p == 0 && sidx == 0) {                          // the workgroup that keeps the padded rows of its columns
+    __hip_atomic_store(ka.Xq + b * DPAD + c0, q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ka.Xq + b * DPAD + c1, q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (live && wave == 0 && ko.factors)
+      __hip_atomic_store(ko.factors + b, (pa.d - 1.0) * log(z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  s_q[lane * DPAD + c0] = q0;
+  s_q[lane * DPAD + c1] = q1;
+  __syncthreads();
+  const double c = ka.has_const ? ka.constv[p] : 0.0;
+  KstarDirect dir{nullptr, nullptr};
+  if (KIND == 1) dir = KstarDirect{ka.Xs + (int64_t)p * ka.Npad * DPAD, ka.inv_ls + p * DPAD};
+  for (int chunk = sidx; chunk < ka.nchunk; chunk += ko.S) {
+    KstarFrags<KS, JTW> fr;
+    kstar_load_frags<KS, JTW, NBW>(fr, ka.Xa + (int64_t)p * njt * KS * 64, ka.alf + (int64_t)p * njt * 16, (int64_t)chunk * JT,
+                                   lane, wave);
+    const double sum = kstar_mfma_block<KIND, KS, JTW, NBW, KSTAR_TB, 4>(
+        s_q, s_tab, s_red, fr, ka.qsc + p * 4 * KS, ka.qof + p * 4 * KS, c, ka.d, (int64_t)chunk * JT, ka.N,
+        ka.KS + (int64_t)p * ka.Npad * ka.Bcap + b0, ka.Bcap, dir, lane, wave);
+    if (wave == 0)
+      __hip_atomic_store(ka.mean_part + (b * ka.k + p) * ka.nchunk + chunk, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every store of this chunk acknowledged, by every wave; then the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && !(ko.fault && bidx == 0 && chunk == sidx))
+      __hip_atomic_store(ko.flags + ((int64_t)p * ka.nchunk + chunk) * ka.ncb64 + cb, ko.serial, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // Columns per launch of the large-batch triangular GEMM.  More than 512 columns (emulation.predict on a large batch) go
 // one launch per 512 columns: K_*^T of 1024 columns is 82 MB, and with W_p it no longer streams through the XCDs' L2s the
 // way the 512-column schedule is built for (one launch of 1024 columns takes 228 us, two of 512 take 2 x 93 us).  Only
@@ -228,6 +356,40 @@ int launch_kstar(gpemu_model *m, int64_t B, double *dXq, hipStream_t st, const P
   return GPEMU_OK;
 }
 
+// Shapes the overlapped half-step takes: the large-batch GEMM in ONE launch (129 .. 512 columns, or more where they are not
+// cut into pieces), the 64-row cross-kernel form, at least two producer workgroups per (PC, column block) within two per CU.
+static int overlap_splits(const gpemu_model *m, int64_t B) {
+  const int ncombos = (int)m->k * (int)(round_up(B, TILE) / 64), nchunk = (int)(m->Npad / KSTAR_ROWS_BIG);
+  // producer workgroups that fit on a CU beside the GEMM's one (which takes half of every SIMD's registers): two of the
+  // RBF instantiation (128 VGPRs), one of the others (142 .. 170)
+  const int per_cu = (kstar_kind(m) == 0 && m->ksteps == 2) ? 2 : 1;
+  return std::min(nchunk, per_cu * m->num_cu / std::max(ncombos, 1));
+}
+bool overlap_eligible(const gpemu_model *m, int64_t B) {
+  if (m->variant_B != 0 || m->profiling || B <= KSTAR_SMALL_MAX) return false;
+  if (trmm_piece_cols(m, B) < round_up(B, TILE)) return false;
+  return overlap_splits(m, B) >= 2;
+}
+
+int launch_kstar_persist(gpemu_model *m, int64_t B, double *dXq, const ProposeArgs &pa, const OverlapCtx &oc) {
+  int nwg = 0;
+  bool small = false;
+  KstarArgs ka = kstar_setup(m, B, dXq, nwg, small);
+  if (small || !pa.enabled) { set_error("launch_kstar_persist: shape outside the overlapped run"); return GPEMU_ERR_ARG; }
+  const int S = overlap_splits(m, B);
+  const int ncombos = ka.k * ka.ncb64;
+  // (kstar_setup's XCD-aware numbers assume whole combos per XCD: 2 gper (PC, 64-column block) pairs each)
+  if (ka.gper > 0 && 8 * 2 * ka.gper != ncombos) ka.gper = 0;
+  const KstarOverlap ko{m->kflags, oc.serial, oc.stamp, oc.gemm_word, oc.inds_chk, oc.chk_val, S, oc.err, oc.max_polls, oc.factors,
+                        oc.fault};
+  const dim3 grid((unsigned)(ncombos * S)), block(256);
+#define GP_LAUNCH_PERSIST(KD, KSV, JT) hipLaunchKernelGGL((kstar_persist_kernel<KD, KSV>), grid, block, 0, oc.side, ka, pa, ko)
+  GP_KSTAR_DISPATCH(kstar_kind(m), m->ksteps, false, GP_LAUNCH_PERSIST);
+#undef GP_LAUNCH_PERSIST
+  GP_HIP(hipGetLastError());
+  return GPEMU_OK;
+}
+
 // one launch for the cross-kernels of ng groups on the same B query rows (same base kernel and parameter count in all
 // of them: the caller checks); `pa`: the stretch proposal, formed by every group, stored by the first
 int launch_kstar_groups(gpemu_model *const *ms, int ng, int64_t B, double *dXq, hipStream_t st, const ProposeArgs *pa) {
@@ -284,11 +446,30 @@ constexpr int TRMM_MAX_ITEMS = 64;  // per worker; the schedule falls back to mo
 typedef const __attribute__((address_space(1))) void *gas_ptr;
 typedef __attribute__((address_space(3))) void *las_ptr;
 
+// OVL (round 5): the cross-kernel that PRODUCES K_*^T runs at the same time, from a second stream
+// (kstar_persist_kernel) -- it is store / vector-ALU bound, this kernel matrix-core bound, and beside each other they cost
+// what the GEMM costs alone (tools/share_probe: 95.6 us against 92.9 + 11.5 + a launch gap).  Rows arrive in chunks of 64
+// training rows x 64 columns; the producer stores them write-through (sc1), drains its stores and then stores the launch's
+// serial number into flags[p][chunk][column block].  Here wave 0 confirms, one k-tile ahead of the load cursor, that the
+// chunk the cursor moves into has its flag (an LDS-DMA of the flag word issued at the start of a k-tile, looked at when
+// the k-tile ends: no latency on anybody's path while the producer stays ahead, which it does after the first chunks) and
+// holds the k-tile barrier until it has; the K_*^T tiles are then loaded sc1 (not served from a stale line of this XCD's
+// L2: placement of the two launches relative to each other is not something HIP promises).  Every wait is bounded
+// (ovl.err is set, the caller reruns the block on the serial path).
+struct TrmmOverlap {
+  const unsigned *flags;      // [k][nchunk][ncb64]
+  unsigned serial;
+  int nchunk, ncb64;
+  int *err;                   // [1] incremented when a wait expired
+  int max_polls;
+};
+
 // the six loads of k-tile s+2 go out one by one between the MFMA groups of k-tile s
+template <bool OVL>
 __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
     const double *__restrict__ Wt, const double *__restrict__ KS, double *__restrict__ out,
     const TrmmItem *__restrict__ sched, const int *__restrict__ sched_cnt, int max_items,
-    int64_t Npad, int64_t Bcap, int k, int nrb
+    int64_t Npad, int64_t Bcap, int k, int nrb, TrmmOverlap ovl
 #ifdef GPEMU_TRMM_STAMPS        // diagnostic build (tools/trmm_balance.py): per-worker time stamps of a launch
     , unsigned long long *__restrict__ stamps
 #endif
@@ -299,6 +480,7 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
   __shared__ __attribute__((aligned(16))) double L2[BUFD];
   __shared__ double red[2][TILE];
   __shared__ TrmmItem s_items[TRMM_MAX_ITEMS];
+  __shared__ unsigned s_flag[OVL ? 64 : 1];            // mailbox of the flag words wave 0 asked for
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -350,10 +532,45 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
                  : "s"(lds_off), "v"(src)
                  : "memory");
   };
+  auto dma1_sc1 = [&](const double *src, double *dst_wave_uniform) {     // (OVL: the K_*^T chunks, past this XCD's L2)
+    const unsigned lds_off = (unsigned)(uintptr_t)((las_ptr)dst_wave_uniform);
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off sc1"
+                 :
+                 : "s"(lds_off), "v"(src)
+                 : "memory");
+  };
+  // ---- OVL: which flags a cursor position needs, asking for them, waiting for them ----
+  // key of a position = (item, 64-row chunk of its k-tile); its flag words: the item's one or two 64-column blocks
+  auto flag_addr = [&](int item, int t) -> const unsigned * {
+    const TrmmItem it = my[item];
+    const int cb0 = it.col0 >> 6, cb = cb0 + ((it.half || (lane & 1) == 0) ? 0 : 1);
+    return ovl.flags + ((int64_t)it.p * ovl.nchunk + (t >> 1)) * ovl.ncb64 + cb;
+  };
+  auto flag_request = [&](int item, int t) {          // wave 0: LDS-DMA of the words into s_flag (every lane one word)
+    const unsigned lds_off = (unsigned)(uintptr_t)((las_ptr)s_flag);
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off sc1"
+                 :
+                 : "s"(lds_off), "v"(flag_addr(item, t))
+                 : "memory");
+  };
+  auto flag_wait = [&](int item, int t) {             // wave 0: blocking, bounded
+    const unsigned *fp = flag_addr(item, t);
+    int polls = 0;
+    for (;;) {
+      const unsigned v = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all(v == ovl.serial)) break;
+      if (++polls > ovl.max_polls) {                   // the producer is gone: end the launch, the results are void
+        if (lane == 0) atomicAdd(ovl.err, 1);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  };
   // one of the wave's six loads of a k-tile (part compile-time after unrolling); the cursor moves on after the last
   auto dma_part = [&](double *dA, int part) {
     double *dB = dA + KT * TM;
     if (part < 2) dma1(l_pa + offA[part], dA + (wave * 2 + part) * 128);
+    else if (OVL) dma1_sc1(l_pb + offB[part - 2], dB + (wave * 4 + part - 2) * 128);
     else dma1(l_pb + offB[part - 2], dB + (wave * 4 + part - 2) * 128);
     if (part == 5 && l_item < nitems) {
       if (++l_t == l_nt) {
@@ -375,8 +592,23 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
     __builtin_amdgcn_s_barrier();
   };
   l_open();
+  // OVL: (item, chunk) of the newest position confirmed; the first two k-tiles (rows 0 .. 63: chunk 0 of the first item)
+  // and the position after them are confirmed here, blocking -- nothing can start before the producer's first chunks anyway
+  int ok_item = -1, ok_chunk = -1;
+  bool asked = false;
+  if (OVL) {
+    if (wave == 0) flag_wait(0, 0);
+    ok_item = 0; ok_chunk = 0;
+    __syncthreads();
+  }
   dma(L0);
   dma(L1);
+  if (OVL) {                                           // the cursor stands on the third k-tile: confirm it before step 0 issues it
+    if (l_item < nitems && (l_item != ok_item || (l_t >> 1) != ok_chunk)) {
+      if (wave == 0) flag_wait(l_item, l_t);
+      ok_item = l_item; ok_chunk = l_t >> 1;
+    }
+  }
   tile_barrier();
 #ifdef GPEMU_TRMM_STAMPS
   if (stamps && tid == 0) stamps[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -396,6 +628,19 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
 
   auto step = [&](const double *cA, double *nA) -> bool {
     const double *cB = cA + KT * TM;
+    // OVL: this step issues the loads of the cursor's k-tile (confirmed); the position AFTER it is confirmed before this
+    // step's barrier, so that the next step may issue it.  Uniform bookkeeping in every wave, the memory traffic in wave 0.
+    int nx_item = l_item, nx_t = l_t + 1;
+    if (OVL) {
+      asked = false;
+      if (l_item < nitems) {
+        if (nx_t == l_nt) { nx_item = l_item + 1; nx_t = 0; }
+        if (nx_item < nitems && (nx_item != ok_item || (nx_t >> 1) != ok_chunk)) {
+          asked = true;
+          if (wave == 0) flag_request(nx_item, nx_t);   // before this step's six loads: done by the vmcnt(6) below
+        }
+      }
+    }
     if (cur.half) {
       const int ib = lk * TILE + (((cur.col0 & 64) + wn * 16 + lr) ^ sw);
       double a[2][2], b[2];
@@ -442,6 +687,15 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
         if (ks < 6) dma_part(nA, ks);   // k-tile +2 -> the buffer k-tile -1 was read from
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
+    if (OVL && asked) {
+      if (wave == 0) {
+        // the words asked for at the start of the step have landed (they are older than the step's six loads)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        const unsigned v = reinterpret_cast<volatile unsigned *>(s_flag)[lane & 1];
+        if (!__all(v == ovl.serial)) flag_wait(nx_item, nx_t);
+      }
+      ok_item = nx_item; ok_chunk = nx_t >> 1;
     }
     tile_barrier();
     if (++c_t == c_nt) {
@@ -553,7 +807,7 @@ static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &
   }
 }
 
-int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
+int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st, const OverlapCtx *oc) {
   Workspace &w = m->ws;
   constexpr int64_t smallb_max = 128;
   const int64_t Bv = m->variant_B > 0 ? m->variant_B : B;   // a chain stacked with others is evaluated as it would be alone
@@ -564,7 +818,7 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
     for (int64_t c0 = 0; c0 < B && rc == GPEMU_OK; c0 += per) {
       w.KS = KS0 + c0;
       w.vsq_part = V0 + c0 * m->k * m->vsq_nrb;
-      rc = launch_trmm_vsq(m, std::min(per, B - c0), st);
+      rc = launch_trmm_vsq(m, std::min(per, B - c0), st, nullptr);
     }
     w.KS = KS0;
     w.vsq_part = V0;
@@ -620,9 +874,9 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
     GP_HIP(hipMalloc((void **)&dstamps, sizeof(unsigned long long) * 16 * 1024));
     GP_HIP(hipMemset(dstamps, 0, sizeof(unsigned long long) * 16 * 1024));
   }
-  hipLaunchKernelGGL(trmm_vsq_dma_kernel, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
+  hipLaunchKernelGGL(trmm_vsq_dma_kernel<false>, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
                      w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
-                     m->Npad, w.Bcap, (int)m->k, nrb, dstamps);
+                     m->Npad, w.Bcap, (int)m->k, nrb, TrmmOverlap(), dstamps);
   GP_HIP(hipGetLastError());
   prof_pair(m, 0, pe0, prof_mark(m, st));
   if (stamp_path && ++stamp_calls == 600) {
@@ -643,9 +897,18 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
     }
   }
 #else
-  hipLaunchKernelGGL(trmm_vsq_dma_kernel, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
-                     w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
-                     m->Npad, w.Bcap, (int)m->k, nrb);
+  if (oc) {
+    // the producer of K_*^T runs beside this launch (launch_kstar_persist, on oc->side): wait for its rows chunk by chunk
+    const TrmmOverlap ovl{m->kflags, oc->serial, (int)(m->Npad / KSTAR_ROWS_BIG), (int)(round_up(B, TILE) / 64), oc->err,
+                          oc->max_polls};
+    hipLaunchKernelGGL(trmm_vsq_dma_kernel<true>, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
+                       w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
+                       m->Npad, w.Bcap, (int)m->k, nrb, ovl);
+  } else {
+    hipLaunchKernelGGL(trmm_vsq_dma_kernel<false>, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
+                       w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
+                       m->Npad, w.Bcap, (int)m->k, nrb, TrmmOverlap());
+  }
   GP_HIP(hipGetLastError());
   prof_pair(m, 0, pe0, prof_mark(m, st));
 #endif

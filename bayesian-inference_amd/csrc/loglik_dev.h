@@ -87,7 +87,16 @@ __device__ __forceinline__ void finish_walker(double total, double *__restrict__
   if (total != total && lane == 0) atomicAdd(aa.flags, 1);  // emcee raises on NaN
   const bool acc = (ao.factor + total - oldlp) > ao.logu;
   const double xold = ao.xold;
-  if (lane < DPAD && acc) aa.X[(int64_t)w * DPAD + lane] = ao.xnew;
+  if (aa.stamp) {
+    // overlapped run: the producer of the next half-step's K_*^T is already running on another stream and reads this
+    // walker's position as soon as its stamp says so -- the state goes out write-through, the stamp behind its
+    // acknowledgement (one wave = one walker: the wave's own vmcnt covers every store of the walker)
+    if (lane < DPAD && acc) __hip_atomic_store(aa.X + (int64_t)w * DPAD + lane, ao.xnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(aa.stamp + w, aa.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (lane < DPAD && acc) {
+    aa.X[(int64_t)w * DPAD + lane] = ao.xnew;
+  }
   if (lane == 0) {
     out[b] = total;
     if (acc) {

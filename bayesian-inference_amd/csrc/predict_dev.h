@@ -174,7 +174,9 @@ __device__ __forceinline__ kd4 kstar_tile_product(const double (&a)[KS], const d
 }
 
 // kernel values, stores and the mean's FMAs of one tile from its accumulator
-template <int KIND, int TB, int ABL = 0>   // ABL: probe ablations (1: no stores, 2: no exponential, 3: nontemporal stores)
+// ABL: probe ablations (1: no stores, 2: no exponential, 3: nontemporal stores); 4 (product: the producer beside the
+// GEMM, kstar_persist_kernel): write-through (agent-scope) stores, read by another kernel while this one runs
+template <int KIND, int TB, int ABL = 0>
 __device__ __forceinline__ void kstar_tile_finish(kd4 acc, double hq, kd4 al, double c, const double *s_tab, bool ragged,
                                                   int64_t row0, int64_t N, double *__restrict__ kout, int64_t Bcap, double &macc,
                                                   const KstarDirect &dir, const double *s_q, int col) {
@@ -188,7 +190,8 @@ __device__ __forceinline__ void kstar_tile_finish(kd4 acc, double hq, kd4 al, do
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    if (ABL == 3) __builtin_nontemporal_store(v[r], &kout[(int64_t)(4 * r) * Bcap]);
+    if (ABL == 4) __hip_atomic_store(&kout[(int64_t)(4 * r) * Bcap], v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (ABL == 3) __builtin_nontemporal_store(v[r], &kout[(int64_t)(4 * r) * Bcap]);
     else if (ABL != 1) kout[(int64_t)(4 * r) * Bcap] = v[r];
     macc = fma(al[r], v[r], macc);
   }

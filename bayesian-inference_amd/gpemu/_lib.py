@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpemu.so")
+# GPEMU_LIBRARY: another build of the library (A/B measurements of one kernel variant against the in-tree build)
+LIB_PATH = os.environ.get("GPEMU_LIBRARY") or os.path.join(_HERE, "libgpemu.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_i64 = C.c_int64
@@ -96,6 +97,7 @@ _SIGNATURES = {
     "gpemu_sampler_run_peer": (C.c_int, [C.c_void_p, c_i64, C.c_int]),
     "gpemu_sampler_peer_selftest": (C.c_int, [C.c_void_p]),
     "gpemu_sampler_peer_share": (C.c_int, [C.c_void_p, C.c_int]),
+    "gpemu_sampler_last_run_mode": (C.c_int, [C.c_void_p]),
     "gpemu_sampler_snapshot": (C.c_int, [C.c_void_p]),
     "gpemu_sampler_restore": (C.c_int, [C.c_void_p]),
     "gpemu_philox4x32": (C.c_int, [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]),

@@ -252,7 +252,7 @@ def measure_fit_c5(device=0):
     scaler, pca, Y_pca = estimators.scale_and_pca(prob["Y"], device=device)
     t_pca = time.perf_counter() - t0
     theta = np.log(np.r_[(prob["hi"] - prob["lo"]) * 0.5, 0.05])
-    fit = DeviceFit(prob["design"], kernel_kind=kernel_kind, nu=nu, has_noise=True, jitter=1e-10, device=device)
+    fit = DeviceFit(prob["design"], kernel_kind=0, has_noise=True, jitter=1e-10, device=device)
     y = Y_pca[:, 0]
     out = {"workload": "C5: N_design=5000 x N_obs=2000", "pca_5000x2000_ms": t_pca * 1e3}
     for grad in (False, True):
