@@ -10,7 +10,7 @@
 
 namespace gpemu {
 
-static thread_local char g_err[512] = "";
+static thread_local char g_err[1024] = "";
 
 void set_error(const char *fmt, ...) {
   va_list ap;
@@ -66,6 +66,12 @@ int ensure_workspace(gpemu_model *m, int64_t B) {
   GP_TRY(dev_alloc(&w.logp, need));
   GP_TRY(dev_alloc(&w.kflags, k * (m->Npad / 64) * (need / 64)));
   m->kflags = w.kflags;
+  m->ovl_serial = 0;           // fresh (zeroed) flags: the count starts again
+  m->ovl_shape = 0;
+  if (!m->ovl_ctl) {
+    GP_TRY(dev_alloc(&m->ovl_ctl, 64 + 2048 + 24));       // (k_predict.hip: OVL_QRING + OVL_CU_KEYS + the debug records)
+    GP_HIP(hipMemsetAsync(m->ovl_ctl, 0, sizeof(int) * (64 + 2048 + 24), m->stream));
+  }
   GP_HIP(hipMemsetAsync(w.kflags, 0, sizeof(unsigned) * (size_t)(k * (m->Npad / 64) * (need / 64)), m->stream));
   GP_HIP(hipMemsetAsync(w.KS, 0, sizeof(double) * (size_t)(k * m->Npad * need), m->stream));
   GP_HIP(hipMemsetAsync(w.Xq, 0, sizeof(double) * (size_t)(need * DPAD), m->stream));
@@ -385,7 +391,7 @@ int gpemu_model_destroy(gpemu_model *m) {
   hipSetDevice(m->device);
   if (m->stream) hipStreamSynchronize(m->stream);
   hipFree(m->Xs); hipFree(m->inv_ls); hipFree(m->ls); hipFree(m->Xa); hipFree(m->alf); hipFree(m->qsc); hipFree(m->qof);
-  hipFree(m->etab); hipFree(m->constv); hipFree(m->kdiag);
+  hipFree(m->etab); hipFree(m->constv); hipFree(m->kdiag); hipFree(m->ovl_ctl);
   hipFree(m->alpha); hipFree(m->Wt); hipFree(m->comp); hipFree(m->smean); hipFree(m->sscale);
   hipFree(m->cunexpl); hipFree(m->yexp); hipFree(m->yerr); hipFree(m->lo); hipFree(m->hi);
   for (const gpemu_model::LikEntry &en : m->lik_cache) { hipFree(en.G); hipFree(en.g0); hipFree(en.scal); }

@@ -132,6 +132,9 @@ struct gpemu_model {
   int64_t exact_scratch_size = 0;
 
   unsigned *kflags = nullptr;  // = ws.kflags (the launchers' view)
+  unsigned ovl_serial = 0;     // overlapped launches of this model on the current flags: they read 4 x this once a launch's rows are in
+  int64_t ovl_shape = 0;       // (chunks, column blocks) the flags have been counting for
+  int *ovl_ctl = nullptr;      // task counters + producers per CU of the overlapped run's producer (k_predict.hip), zeroed once
   // optional per-kernel timing (gpemu_model_profile): HIP event pairs around the two hot kernels
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;         // reusable events
@@ -165,6 +168,7 @@ struct AcceptArgs {
   // serial says so; the first wave of the launch stores serial to gemm_word (the GEMM in front of this launch is done).
   unsigned *stamp = nullptr, *gemm_word = nullptr;
   unsigned serial = 0;
+  int mean_pairs = 0;            // the partial means come as [chunk][2 wave rows] (kstar_mfma_wave): add each pair first
 };
 
 // One overlapped half-step (logpost_overlapped): the cross-kernel as a producer on `side`, the triangular GEMM and the
@@ -179,7 +183,6 @@ struct OverlapCtx {
   int chk_val = 0;                   // its proposers: inds_chk[w] == chk_val
   int *err = nullptr;                // [1] waits that expired
   int max_polls = 1 << 21;
-  double *factors = nullptr;         // [n] out: (d - 1) log z
   int fault = 0;                     // tests only: a producer workgroup that never publishes (GPEMU_OVERLAP_FAULT)
 };
 
@@ -212,6 +215,7 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st, const OverlapCtx 
 // the overlapped half-step for one group, or GPEMU_ERR_UNSUPPORTED (nothing launched) where the shape does not take it
 bool overlap_eligible(const gpemu_model *m, int64_t B);
 int launch_kstar_persist(gpemu_model *m, int64_t B, double *dXq_padded, const ProposeArgs &pa, const OverlapCtx &oc);
+int overlap_reset(gpemu_model *m);     // flags / counters of the overlapped run back to zero (both streams idle)
 int logpost_overlapped(gpemu_model *m, int64_t B, double *dXq, double *dout, hipStream_t st, const AcceptArgs &aa,
                        const ProposeArgs &pa, const OverlapCtx &oc);
 int small_trmm_xcd_of(const gpemu_model *m, int64_t B, int p, int64_t col);

@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
   const bool inside = __all(in);
 
   double mu, sd;
-  walker_mean_sd<(KMAX <= 16 ? 16 : 32)>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
+  walker_mean_sd<(KMAX <= 16 ? 16 : 32)>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd,
+                                         aa.mean_pairs);
   const double total = walker_loglik_lowrank<KMAX, PRE>(inside, mu, sd, gpre, gl_pre, sc0_pre, sc1_pre, G, g0, scal, k, nblk, lane);
   finish_walker(total, out, b, d, lane, accumulate, aa, ao);
 }
@@ -245,8 +246,8 @@ __global__ __launch_bounds__(256) void loglik_lowrank_lds_kernel(
   if (lane < d) in = (Xq[b * DPAD + lane] > lo[lane]) && (Xq[b * DPAD + lane] < hi[lane]);
   const bool inside = __all(in);
   double mu, sd;
-  if (k <= 32) walker_mean_sd<32>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
-  else walker_mean_sd<64>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
+  if (k <= 32) walker_mean_sd<32>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd, aa.mean_pairs);
+  else walker_mean_sd<64>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd, aa.mean_pairs);
   const double total = walker_loglik_lowrank_lds(inside, mu, sd, G, g0, scal, k, nblk, lane, M, ldm);
   finish_walker(total, out, b, d, lane, accumulate, aa, load_accept_operands(Xq, b, lane, aa));
 }

@@ -461,6 +461,7 @@ static int run_overlapped(gpemu_sampler *s, int64_t steps, int store_chain) {
         aa.lpchain = s->lpchain + s->chain_len * W;
       }
       aa.stamp = s->stamp; aa.gemm_word = gemm_word; aa.serial = serial;
+      aa.mean_pairs = 1;
       OverlapCtx oc;
       oc.side = s->side; oc.serial = serial; oc.stamp = s->stamp; oc.gemm_word = gemm_word;
       // who proposed in the half before: set 0 of this step (h = 1), set 1 of the step before (h = 0)
@@ -482,7 +483,17 @@ static int run_overlapped(gpemu_sampler *s, int64_t steps, int store_chain) {
   if (fl[1]) {
     (void)hipMemsetAsync(s->flags, 0, sizeof(fl), st);
     (void)hipStreamSynchronize(st);
-    set_error("overlapped run: %d waits between the cross-kernel and the triangular GEMM expired", fl[1]);
+    int dbg[24];
+    memset(dbg, 0, sizeof(dbg));
+    if (m->ovl_ctl) {
+      (void)hipMemcpy(dbg, m->ovl_ctl + 64 + 2048, sizeof(dbg), hipMemcpyDeviceToHost);
+      (void)hipMemset(m->ovl_ctl + 64 + 2048, 0, sizeof(dbg));
+    }
+    set_error("overlapped run: waits between the two streams expired (%d: units = the GEMM's waits for rows, thousands = "
+              "producers' waits for the GEMM before, millions = their waits for walkers); first of each kind [serial ids(3) saw "
+              "wanted]: GEMM rows [%d %d %d %d %d %d] GEMM-before [%d %d %d %d %d %d] walker [%d %d %d %d %d %d]; step counter %llu",
+              fl[1], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[9], dbg[10], dbg[11], dbg[12], dbg[13], dbg[14],
+              dbg[17], dbg[18], dbg[19], dbg[20], dbg[21], dbg[22], (unsigned long long)s->step_counter);
     return GPEMU_ERR_STATE;
   }
   return GPEMU_OK;
@@ -746,6 +757,8 @@ int gpemu_sampler_run(gpemu_sampler *s, int64_t steps, int store_chain) {
     if (rc == GPEMU_OK) return check_nan(s);
     if (rc != GPEMU_ERR_STATE) return rc;
     if (s->side) (void)hipStreamSynchronize(s->side);
+    (void)hipStreamSynchronize(st);
+    GP_TRY(overlap_reset(s->groups[0]));       // some rows of the failed attempt were counted, others not
     GP_TRY(gpemu_sampler_restore(s));
     s->ovl_off = true;
     s->last_run_mode = 2;
