@@ -10,7 +10,7 @@
 
 namespace gpemu {
 
-static thread_local char g_err[1024] = "";
+static thread_local char g_err[512] = "";
 
 void set_error(const char *fmt, ...) {
   va_list ap;
@@ -45,7 +45,7 @@ static int upload(double *dst, const double *src, int64_t n, hipStream_t st) {
 
 static void free_workspace(Workspace &w) {
   hipFree(w.Xq); hipFree(w.KS); hipFree(w.mean_part); hipFree(w.mean_part2); hipFree(w.vsq_part);
-  hipFree(w.mean); hipFree(w.var); hipFree(w.logp); hipFree(w.kflags);
+  hipFree(w.mean); hipFree(w.var); hipFree(w.logp);
   w = Workspace();
 }
 
@@ -64,15 +64,6 @@ int ensure_workspace(gpemu_model *m, int64_t B) {
   GP_TRY(dev_alloc(&w.mean, need * k));
   GP_TRY(dev_alloc(&w.var, need * k));
   GP_TRY(dev_alloc(&w.logp, need));
-  GP_TRY(dev_alloc(&w.kflags, k * (m->Npad / 64) * (need / 64)));
-  m->kflags = w.kflags;
-  m->ovl_serial = 0;           // fresh (zeroed) flags: the count starts again
-  m->ovl_shape = 0;
-  if (!m->ovl_ctl) {
-    GP_TRY(dev_alloc(&m->ovl_ctl, 64 + 2048 + 24));       // (k_predict.hip: OVL_QRING + OVL_CU_KEYS + the debug records)
-    GP_HIP(hipMemsetAsync(m->ovl_ctl, 0, sizeof(int) * (64 + 2048 + 24), m->stream));
-  }
-  GP_HIP(hipMemsetAsync(w.kflags, 0, sizeof(unsigned) * (size_t)(k * (m->Npad / 64) * (need / 64)), m->stream));
   GP_HIP(hipMemsetAsync(w.KS, 0, sizeof(double) * (size_t)(k * m->Npad * need), m->stream));
   GP_HIP(hipMemsetAsync(w.Xq, 0, sizeof(double) * (size_t)(need * DPAD), m->stream));
   GP_HIP(hipMemsetAsync(w.vsq_part, 0, sizeof(double) * (size_t)(k * (m->Npad / 32) * need), m->stream));
@@ -148,21 +139,6 @@ int logpost_padded(gpemu_model *m, int64_t B, double *dXq, double *dout, int acc
   if (rc == GPEMU_OK) rc = launch_trmm_vsq(m, B, st);
   if (rc != GPEMU_OK) return rc;
   return launch_loglik_lowrank(m, B, dXq, dout, accumulate, st, aa);
-}
-
-// The overlapped half-step: producer on oc.side, GEMM + likelihood on `st`.  The partial means go to the
-// OTHER of the two buffers than the half before wrote (the likelihood of that half may still be reading its own).
-int logpost_overlapped(gpemu_model *m, int64_t B, double *dXq, double *dout, hipStream_t st, const AcceptArgs &aa,
-                       const ProposeArgs &pa, const OverlapCtx &oc) {
-  if (!m->lik_ready) { set_error("gpemu_likelihood_setup has not been called"); return GPEMU_ERR_STATE; }
-  int rc = ensure_workspace(m, B);
-  if (rc != GPEMU_OK) return rc;
-  if (!overlap_eligible(m, B)) return GPEMU_ERR_UNSUPPORTED;
-  std::swap(m->ws.mean_part, m->ws.mean_part2);
-  rc = launch_kstar_persist(m, B, dXq, pa, oc);
-  if (rc == GPEMU_OK) rc = launch_trmm_vsq(m, B, st, &oc);
-  if (rc != GPEMU_OK) return rc;
-  return launch_loglik_lowrank(m, B, dXq, dout, 0, st, &aa);
 }
 
 // Log-posterior of B padded query rows summed over ng >= 2 emulation groups with ONE launch per stage (cross-kernels,
@@ -391,7 +367,7 @@ int gpemu_model_destroy(gpemu_model *m) {
   hipSetDevice(m->device);
   if (m->stream) hipStreamSynchronize(m->stream);
   hipFree(m->Xs); hipFree(m->inv_ls); hipFree(m->ls); hipFree(m->Xa); hipFree(m->alf); hipFree(m->qsc); hipFree(m->qof);
-  hipFree(m->etab); hipFree(m->constv); hipFree(m->kdiag); hipFree(m->ovl_ctl);
+  hipFree(m->etab); hipFree(m->constv); hipFree(m->kdiag);
   hipFree(m->alpha); hipFree(m->Wt); hipFree(m->comp); hipFree(m->smean); hipFree(m->sscale);
   hipFree(m->cunexpl); hipFree(m->yexp); hipFree(m->yerr); hipFree(m->lo); hipFree(m->hi);
   for (const gpemu_model::LikEntry &en : m->lik_cache) { hipFree(en.G); hipFree(en.g0); hipFree(en.scal); }

@@ -51,7 +51,6 @@ struct Workspace {
   double *mean = nullptr;      // [Bcap][k]
   double *var = nullptr;       // [Bcap][k]
   double *logp = nullptr;      // [Bcap]
-  unsigned *kflags = nullptr;  // [k][Npad/64][Bcap/64] row flags of the producer beside the GEMM (k_predict.hip: kstar_persist_kernel)
   int cur_nrb = 0;             // row blocks of vsq_part written by the last triangular GEMM launch
   int cur_nchunk = 0;          // row chunks of mean_part written by the last kstar launch
 };
@@ -131,10 +130,6 @@ struct gpemu_model {
   double *exact_scratch = nullptr;
   int64_t exact_scratch_size = 0;
 
-  unsigned *kflags = nullptr;  // = ws.kflags (the launchers' view)
-  unsigned ovl_serial = 0;     // overlapped launches of this model on the current flags: they read 4 x this once a launch's rows are in
-  int64_t ovl_shape = 0;       // (chunks, column blocks) the flags have been counting for
-  int *ovl_ctl = nullptr;      // task counters + producers per CU of the overlapped run's producer (k_predict.hip), zeroed once
   // optional per-kernel timing (gpemu_model_profile): HIP event pairs around the two hot kernels
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;         // reusable events
@@ -163,27 +158,6 @@ struct AcceptArgs {
   // chain_per rows per chain; 0 = one chain.  Selects the chain's data constants (g0, q0) in the likelihood.
   int chain_per = 0;
   int64_t first = 0;
-  // overlapped run: the next half-step's proposals are formed by a kernel that is already running on
-  // another stream.  stamp != null: the accepted state goes out write-through and, once acknowledged, stamp[walker] =
-  // serial says so; the first wave of the launch stores serial to gemm_word (the GEMM in front of this launch is done).
-  unsigned *stamp = nullptr, *gemm_word = nullptr;
-  unsigned serial = 0;
-  int mean_pairs = 0;            // the partial means come as [chunk][2 wave rows] (kstar_mfma_wave): add each pair first
-};
-
-// One overlapped half-step (logpost_overlapped): the cross-kernel as a producer on `side`, the triangular GEMM and the
-// likelihood on the caller's stream, ordered through flags in memory instead of stream order (cross-stream events cost
-// more than the overlap wins: tools/share_probe).
-struct OverlapCtx {
-  hipStream_t side = nullptr;
-  unsigned serial = 0;               // of this half-step: 2 step + half + 1
-  unsigned *stamp = nullptr;         // [W]
-  unsigned *gemm_word = nullptr;     // [1]
-  const int *inds_chk = nullptr;     // [W] split the half before was drawn from
-  int chk_val = 0;                   // its proposers: inds_chk[w] == chk_val
-  int *err = nullptr;                // [1] waits that expired
-  int max_polls = 1 << 21;
-  int fault = 0;                     // tests only: a producer workgroup that never publishes (GPEMU_OVERLAP_FAULT)
 };
 
 // optional fused stretch-move proposal: kstar_kernel builds its query rows from the ensemble
@@ -211,13 +185,7 @@ static inline int kstar_kind(const gpemu_model *m) {
 // kernels (launchers; all asynchronous on `st`)
 // dXq_padded is read, or -- with pa->enabled -- written (rows [0, round_up(B, 128))) by the kernel
 int launch_kstar(gpemu_model *m, int64_t B, double *dXq_padded, hipStream_t st, const ProposeArgs *pa = nullptr);
-int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st, const OverlapCtx *oc = nullptr);
-// the overlapped half-step for one group, or GPEMU_ERR_UNSUPPORTED (nothing launched) where the shape does not take it
-bool overlap_eligible(const gpemu_model *m, int64_t B);
-int launch_kstar_persist(gpemu_model *m, int64_t B, double *dXq_padded, const ProposeArgs &pa, const OverlapCtx &oc);
-int overlap_reset(gpemu_model *m);     // flags / counters of the overlapped run back to zero (both streams idle)
-int logpost_overlapped(gpemu_model *m, int64_t B, double *dXq, double *dout, hipStream_t st, const AcceptArgs &aa,
-                       const ProposeArgs &pa, const OverlapCtx &oc);
+int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st);
 int small_trmm_xcd_of(const gpemu_model *m, int64_t B, int p, int64_t col);
 int trmm_xcd_of(const gpemu_model *m, int64_t B, int p, int64_t col);   // XCD that reads K_*^T rows (p, col) in launch_trmm_vsq(m, B); -1: any
 int launch_trmm_vsq_small(gpemu_model *m, int64_t B, hipStream_t st);   // B <= 128; GPEMU_ERR_UNSUPPORTED if the shape does not fit

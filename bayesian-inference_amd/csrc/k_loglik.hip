@@ -189,9 +189,6 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int64_t b = (int64_t)blockIdx.x * 4 + wave;
-  // overlapped run: this launch follows the triangular GEMM in its stream, so K_*^T may be overwritten from here on
-  if (aa.gemm_word && threadIdx.x == 0 && blockIdx.x == 0)
-    __hip_atomic_store(aa.gemm_word, aa.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (b >= B) return;  // whole wave exits together; no workgroup barriers below
   if (aa.chain_per) {  // several chains stacked: this row's chain selects the data constants
     const int64_t ch = (aa.first + b) / aa.chain_per;
@@ -216,8 +213,7 @@ __global__ __launch_bounds__(256) void loglik_lowrank_kernel(
   const bool inside = __all(in);
 
   double mu, sd;
-  walker_mean_sd<(KMAX <= 16 ? 16 : 32)>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd,
-                                         aa.mean_pairs);
+  walker_mean_sd<(KMAX <= 16 ? 16 : 32)>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
   const double total = walker_loglik_lowrank<KMAX, PRE>(inside, mu, sd, gpre, gl_pre, sc0_pre, sc1_pre, G, g0, scal, k, nblk, lane);
   finish_walker(total, out, b, d, lane, accumulate, aa, ao);
 }
@@ -246,8 +242,8 @@ __global__ __launch_bounds__(256) void loglik_lowrank_lds_kernel(
   if (lane < d) in = (Xq[b * DPAD + lane] > lo[lane]) && (Xq[b * DPAD + lane] < hi[lane]);
   const bool inside = __all(in);
   double mu, sd;
-  if (k <= 32) walker_mean_sd<32>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd, aa.mean_pairs);
-  else walker_mean_sd<64>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd, aa.mean_pairs);
+  if (k <= 32) walker_mean_sd<32>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
+  else walker_mean_sd<64>(mean_part, vsq_part, kdiag, mean_out, var_out, b, Bcap, k, nchunk, nrb, lane, mu, sd);
   const double total = walker_loglik_lowrank_lds(inside, mu, sd, G, g0, scal, k, nblk, lane, M, ldm);
   finish_walker(total, out, b, d, lane, accumulate, aa, load_accept_operands(Xq, b, lane, aa));
 }

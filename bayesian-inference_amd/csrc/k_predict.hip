@@ -147,179 +147,6 @@ __global__ __launch_bounds__(256, 2) void kstar_groups_kernel(KstarGroups kg, Pr
   kstar_body<KIND, KS, JTW, NBW>(kg.g[gi], pa, (int)blockIdx.x - kg.start[gi], gi == 0);
 }
 
-// what the first wait that expired was waiting for (one record per model, first come): kind (1 the GEMM for rows, 2 a
-// producer for the GEMM before, 3 a producer for a walker), the launch's / half-step's serial, three identifying values,
-// the value seen and the value wanted.  Read by the host into the error message.
-__device__ __forceinline__ void ovl_record(int *dbg, int kind, unsigned serial, int a, int b, int c, unsigned seen, unsigned want) {
-  dbg += 8 * (kind - 1);                         // one record per kind
-  if (atomicCAS(dbg, 0, kind) == 0) {
-    dbg[1] = (int)serial; dbg[2] = a; dbg[3] = b; dbg[4] = c; dbg[5] = (int)seen; dbg[6] = (int)want;
-  }
-}
-// ---- the cross-kernel as a PRODUCER beside the triangular GEMM (round 5) ----------------------------
-// One launch on a second stream of single-WAVE workgroups that pull tasks -- a quarter (wave row x wave column of the
-// workgroup form) of (PC, 64-column block, chunks s, s + S, ... of 64 training rows), in ascending s: the order in which the
-// GEMM's k-tiles consume the rows -- from a counter.  A wave
-//   takes its place on its CU only if fewer than `per_cu` producer waves are there already (below), else exits;
-//   waits (bounded) until the half-step before is through for what it touches: the GEMM that read K_*^T (gemm_word,
-//     stored by the first wave of the likelihood kernel that follows that GEMM in its stream) and the accept / reject
-//     of the walkers of its proposals, where those proposed in the half before (stamp[walker] == serial - 1, stored by
-//     the likelihood wave of that walker behind its write-through state stores);
-//   loads the walkers' positions sc1, forms the proposal components it needs (kstar_body's arithmetic: the same bits), and
-//   per chunk stores K_*^T write-through, drains its stores, and adds 1 to flags[p][chunk][column block] (4 = complete).
-// Nothing here waits for the GEMM of its own half-step, so the pair cannot deadlock through its data.
-//
-// Residency.  The GEMM needs one workgroup on EVERY CU -- 147 KiB of CONTIGUOUS LDS and half of every SIMD's registers.
-// The producers of the NEXT half-step start (and nap) while this half-step's GEMM is still running, and at a block's start
-// or behind a randomness batch they are on the chip before any GEMM is.  Two things made that stall until the bounded
-// waits gave up (seen: every half-step from step 16 on): producers filling a CU four deep, and -- two deep -- their 6 KiB
-// LDS blocks landing where they cut the CU's free LDS in pieces smaller than the GEMM needs, after which the GEMM's
-// workgroup for that CU and the next launch's producers race for whatever frees up, the producers winning and then
-// waiting for the likelihood behind that very GEMM.  So (1) the producers use NO LDS and no barrier (single waves, the
-// query components in registers, the exponential's table from L1: predict_dev.h kstar_mfma_wave), and (2) a wave
-// counts itself into its CU (xcc / se / sh / cu of HW_REG_HW_ID) and LEAVES AT ONCE if it is not among the first per_cu
-// there -- what fits beside the GEMM's two waves per SIMD; more waves are launched than are needed and the tasks are
-// pulled from a queue, so whoever stays does the work (tools/gate_probe: 256 CU keys, never more than per_cu kept).
-struct KstarOverlap {
-  unsigned *flags;              // [k][nchunk][ncb64] counters: + 1 per finished quarter, 4 fserial once the launch's rows are in
-  unsigned fserial;             // launches of this model on these flags so far, this one included
-  unsigned serial;              // of the half-step (2 step + half + 1): what the walker stamps are compared with
-  const unsigned *stamp;        // [W]
-  const unsigned *gemm_word;    // [1]
-  const int *inds_chk;          // [W] split the half before was drawn from; a walker proposed in it iff inds_chk[w] == chk_val
-  int chk_val;
-  int S;                        // tasks per quarter of a (PC, column block): chunk = s, s + S, ...
-  int *err;
-  int max_polls;
-  int fault;                    // tests only (GPEMU_OVERLAP_FAULT): the first task never publishes its first chunk
-  int *ctl;                     // task counters (a ring over the launches), producer waves per CU, debug records
-  int per_cu;                   // producer waves that fit on a CU beside the GEMM's workgroup
-};
-constexpr int OVL_QRING = 64, OVL_CU_KEYS = 2048;
-static_assert(OVL_QRING + OVL_CU_KEYS + 24 == 64 + 2048 + 24, "gpemu_api.hip: ensure_workspace allocates ovl_ctl with this size");
-
-template <int KIND, int KS>
-__global__ __launch_bounds__(64, 2) void kstar_persist_kernel(KstarArgs ka, ProposeArgs pa, KstarOverlap ko) {
-  constexpr int JTW = 2, NBW = 2, JT = 2 * JTW;
-  const int lane = threadIdx.x;
-  const int ln = lane & 15, lq = lane >> 4;
-  // ---- a place on this CU, or out ----
-  // HW_REG_HW_ID [15:8] = se / sh / cu, HW_REG_XCC_ID [3:0]: one counter per physical CU
-  const int cu_key = ((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) << 8) | ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 255);
-  int *cu_cnt = ko.ctl + OVL_QRING + cu_key;
-  int *queue = ko.ctl + (ko.fserial % OVL_QRING);
-  int keep = 0;
-  if (lane == 0) {
-    const int before = atomicAdd(cu_cnt, 1);
-    keep = before < ko.per_cu;
-    if (!keep) atomicAdd(cu_cnt, -1);
-    if (blockIdx.x == 0) ko.ctl[(ko.fserial + OVL_QRING / 2) % OVL_QRING] = 0;     // the counter of the launch 32 launches on
-  }
-  if (!__builtin_amdgcn_readfirstlane(keep)) return;
-  const int ncombos = ka.k * ka.ncb64, ntasks = ncombos * ko.S * 4;
-  const int64_t njt = ka.Npad / 16;
-  const unsigned want = ko.serial - 1u;
-  bool waited = false;
-  for (;;) {
-    int task = 0;
-    if (lane == 0) task = atomicAdd(queue, 1);
-    task = __builtin_amdgcn_readfirstlane(task);
-    if (task >= ntasks) break;
-    const int vwave = task & 3, t4 = task >> 2;
-    const int wr = vwave % 2, wc = vwave / 2;
-    const int sidx = t4 / ncombos, combo = t4 % ncombos;
-    const int p = combo / ka.ncb64, cb = combo % ka.ncb64;
-    const int64_t b0 = (int64_t)cb * 64;
-    // the draws of this lane's two proposals (RNG ring: written long before)
-    int64_t col[NBW];
-    bool live[NBW];
-    int w[NBW], j[NBW];
-    double z[NBW];
-#pragma unroll
-    for (int bt = 0; bt < NBW; ++bt) {
-      col[bt] = b0 + (wc * NBW + bt) * 16 + ln;
-      live[bt] = col[bt] < pa.n;
-      w[bt] = j[bt] = 0;
-      z[bt] = 1.0;
-      if (live[bt]) { w[bt] = pa.idx_s[col[bt]]; j[bt] = pa.partner[col[bt]]; z[bt] = pa.zz[col[bt]]; }
-    }
-    // ---- wait for the half-step before: first naps on gemm_word (it flips when the likelihood kernel behind that GEMM
-    // starts: ~100 us away), only then a look at the walkers' stamps, which follow within the few us that kernel runs ----
-    {
-      int polls = 0;
-      bool lost = false;
-      while (!waited) {
-        const unsigned g = __hip_atomic_load(ko.gemm_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int)(g - want) >= 0) break;
-        if (++polls > ko.max_polls) { lost = true; break; }   // every wave reaches this exit: the grid always drains
-        __builtin_amdgcn_s_sleep(64);
-      }
-      if (lost && lane == 0) {
-        atomicAdd(ko.err, 1000);
-        ovl_record(ko.ctl + OVL_QRING + OVL_CU_KEYS, 2, ko.serial, task, (int)blockIdx.x, cu_key,
-                   __hip_atomic_load(ko.gemm_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want);
-      }
-      waited = true;
-      polls = 0;
-      while (!lost) {
-        bool ok = true;
-#pragma unroll
-        for (int bt = 0; bt < NBW; ++bt) {
-          if (live[bt] && ko.inds_chk[w[bt]] == ko.chk_val)
-            ok = ok && (int)(__hip_atomic_load(ko.stamp + w[bt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0;
-          if (live[bt] && ko.inds_chk[j[bt]] == ko.chk_val)
-            ok = ok && (int)(__hip_atomic_load(ko.stamp + j[bt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0;
-        }
-        if (__all(ok)) break;
-        if (++polls > ko.max_polls) {
-          if (lane == 0) {
-            atomicAdd(ko.err, 1000000);
-            ovl_record(ko.ctl + OVL_QRING + OVL_CU_KEYS, 3, ko.serial, w[0], j[0], task,
-                       __hip_atomic_load(ko.stamp + j[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want);
-          }
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-    }
-    // ---- the stretch proposal's components this lane feeds the matrix cores with (kstar_body's arithmetic; the walkers'
-    // positions sc1): component 4 s + lq of column col[bt] ----
-    double qv[NBW][KS];
-#pragma unroll
-    for (int bt = 0; bt < NBW; ++bt)
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int comp = 4 * s + lq;
-        double q = 0.0;
-        if (live[bt] && comp < pa.d) {
-          const double cj = __hip_atomic_load(pa.X + (int64_t)j[bt] * DPAD + comp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const double sw = __hip_atomic_load(pa.X + (int64_t)w[bt] * DPAD + comp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          q = cj - (cj - sw) * z[bt];                  // emcee moves/stretch.py get_proposal
-        }
-        qv[bt][s] = q;
-        // the quarter that keeps the padded rows of its columns (read by the likelihood kernel of this half-step)
-        if (p == 0 && sidx == 0 && wr == 0 && comp < DPAD)
-          __hip_atomic_store(ka.Xq + col[bt] * DPAD + comp, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    const double c = ka.has_const ? ka.constv[p] : 0.0;
-    for (int chunk = sidx; chunk < ka.nchunk; chunk += ko.S) {
-      KstarFrags<KS, JTW> fr;
-      kstar_load_frags<KS, JTW, NBW>(fr, ka.Xa + (int64_t)p * njt * KS * 64, ka.alf + (int64_t)p * njt * 16, (int64_t)chunk * JT,
-                                     lane, vwave);
-      // partial means: [column][PC][chunk][wave row]
-      double *mean_dst = ka.mean_part + ((col[0] * ka.k + p) * ka.nchunk + chunk) * 2 + wr;
-      kstar_mfma_wave<KIND, KS, JTW, NBW, KSTAR_TB>(qv, ka.etab, fr, ka.qsc + p * 4 * KS, ka.qof + p * 4 * KS, c, ka.d,
-                                                    (int64_t)chunk * JT, ka.N, ka.KS + (int64_t)p * ka.Npad * ka.Bcap + b0, ka.Bcap,
-                                                    lane, vwave, mean_dst, (int64_t)ka.k * ka.nchunk * 2);
-      // every store of this quarter acknowledged; then it counts
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0 && !(ko.fault && task == 0 && chunk == sidx))
-        __hip_atomic_fetch_add(ko.flags + ((int64_t)p * ka.nchunk + chunk) * ka.ncb64 + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  if (lane == 0) atomicAdd(cu_cnt, -1);
-}
-
 // Columns per launch of the large-batch triangular GEMM.  More than 512 columns (emulation.predict on a large batch) go
 // one launch per 512 columns: K_*^T of 1024 columns is 82 MB, and with W_p it no longer streams through the XCDs' L2s the
 // way the 512-column schedule is built for (one launch of 1024 columns takes 228 us, two of 512 take 2 x 93 us).  Only
@@ -401,92 +228,6 @@ int launch_kstar(gpemu_model *m, int64_t B, double *dXq, hipStream_t st, const P
   return GPEMU_OK;
 }
 
-// Shapes the overlapped half-step takes: the large-batch GEMM in ONE launch (129 .. 512 columns, or more where they are not
-// cut into pieces), the 64-row cross-kernel form, at least two producer workgroups per (PC, column block) within two per CU.
-// Shapes the overlapped half-step takes: the large-batch GEMM in ONE launch (129 .. 512 columns, or more where they are not
-// cut into pieces), the 64-row cross-kernel form (not Matern-0.5, whose direct distance wants the raw query rows in LDS), at
-// least two chunk runs per (PC, column block).
-static int overlap_per_cu(const gpemu_model *m);
-static int overlap_splits(const gpemu_model *m, int64_t B) {
-  const int ncombos = (int)m->k * (int)(round_up(B, TILE) / 64), nchunk = (int)(m->Npad / KSTAR_ROWS_BIG);
-  return std::min(nchunk, overlap_per_cu(m) * m->num_cu / std::max(4 * ncombos, 1));
-}
-bool overlap_eligible(const gpemu_model *m, int64_t B) {
-  if (m->variant_B != 0 || m->profiling || B <= KSTAR_SMALL_MAX || kstar_kind(m) == 1) return false;
-  if (trmm_piece_cols(m, B) < round_up(B, TILE)) return false;
-  return overlap_splits(m, B) >= 2;
-}
-
-#define GP_PERSIST_DISPATCH(kind, ksteps, DO)                            \
-  do {                                                                   \
-    if ((ksteps) == 2) {                                                 \
-      switch (kind) { case 0: DO(0, 2); break; case 2: DO(2, 2); break; default: DO(3, 2); break; } \
-    } else {                                                             \
-      switch (kind) { case 0: DO(0, 3); break; case 2: DO(2, 3); break; default: DO(3, 3); break; } \
-    }                                                                    \
-  } while (0)
-
-// producer waves that fit on a CU beside the GEMM's workgroup, which holds two waves of 128 registers on every SIMD: what
-// the other half of a SIMD's 512 registers takes of this instantiation (the runtime's register count, granule 8)
-static int overlap_per_cu(const gpemu_model *m) {
-  static int cache[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-  const int kind = kstar_kind(m), ks = m->ksteps == 2 ? 0 : 1;
-  if (kind == 1) return 0;
-  if (cache[kind][ks] == 0) {
-    hipFuncAttributes attr;
-    hipError_t e = hipSuccess;
-#define GP_ATTR(KD, KSV) e = hipFuncGetAttributes(&attr, (const void *)kstar_persist_kernel<KD, KSV>)
-    GP_PERSIST_DISPATCH(kind, m->ksteps, GP_ATTR);
-#undef GP_ATTR
-    int regs = (e == hipSuccess && attr.numRegs > 0) ? attr.numRegs : 256;
-    if (e != hipSuccess) (void)hipGetLastError();
-    regs = (regs + 7) / 8 * 8;
-    cache[kind][ks] = std::max(4, std::min(8, 4 * (256 / regs)));
-  }
-  return cache[kind][ks];
-}
-
-// Flags, task counters, CU counters and debug records back to their initial state (a shape change, a block that fell back
-// with some rows counted and others not).  Both streams of the caller must be idle.
-int overlap_reset(gpemu_model *m) {
-  if (m->kflags) GP_HIP(hipMemset(m->kflags, 0, sizeof(unsigned) * (size_t)(m->k * (m->Npad / 64) * (m->ws.Bcap / 64))));
-  if (m->ovl_ctl) GP_HIP(hipMemset(m->ovl_ctl, 0, sizeof(int) * (64 + 2048 + 24)));
-  m->ovl_serial = 0;
-  m->ovl_shape = 0;
-  return GPEMU_OK;
-}
-
-int launch_kstar_persist(gpemu_model *m, int64_t B, double *dXq, const ProposeArgs &pa, const OverlapCtx &oc) {
-  int nwg = 0;
-  bool small = false;
-  KstarArgs ka = kstar_setup(m, B, dXq, nwg, small);
-  if (small || !pa.enabled || kstar_kind(m) == 1) { set_error("launch_kstar_persist: shape outside the overlapped run"); return GPEMU_ERR_ARG; }
-  const int S = overlap_splits(m, B);
-  const int ncombos = ka.k * ka.ncb64;
-  // the row flags are counters: every launch adds 4 to every flag of its shape, so after `fserial` launches they read
-  // 4 fserial -- as long as the shape stays; another shape starts the count again (both streams idle: the caller's run
-  // loop keeps one shape, this is the first launch of a run)
-  const int64_t shape = ((int64_t)ka.nchunk << 32) | (int64_t)ka.ncb64;
-  if (m->ovl_shape != shape) {
-    GP_HIP(hipStreamSynchronize(m->stream));
-    if (oc.side) GP_HIP(hipStreamSynchronize(oc.side));
-    const int rc = overlap_reset(m);
-    if (rc != GPEMU_OK) return rc;
-    m->ovl_shape = shape;
-  }
-  m->ovl_serial += 1;
-  const int per_cu = overlap_per_cu(m);
-  const KstarOverlap ko{m->kflags, m->ovl_serial, oc.serial, oc.stamp, oc.gemm_word, oc.inds_chk, oc.chk_val, S, oc.err,
-                        oc.max_polls, oc.fault, m->ovl_ctl, per_cu};
-  // more waves than tasks: whoever finds a place on its CU (at most per_cu there) pulls tasks, the others leave at once
-  const dim3 grid((unsigned)std::max(ncombos * S * 4, 2 * per_cu * m->num_cu)), block(64);
-#define GP_LAUNCH_PERSIST(KD, KSV) hipLaunchKernelGGL((kstar_persist_kernel<KD, KSV>), grid, block, 0, oc.side, ka, pa, ko)
-  GP_PERSIST_DISPATCH(kstar_kind(m), m->ksteps, GP_LAUNCH_PERSIST);
-#undef GP_LAUNCH_PERSIST
-  GP_HIP(hipGetLastError());
-  return GPEMU_OK;
-}
-
 // one launch for the cross-kernels of ng groups on the same B query rows (same base kernel and parameter count in all
 // of them: the caller checks); `pa`: the stretch proposal, formed by every group, stored by the first
 int launch_kstar_groups(gpemu_model *const *ms, int ng, int64_t B, double *dXq, hipStream_t st, const ProposeArgs *pa) {
@@ -543,38 +284,11 @@ constexpr int TRMM_MAX_ITEMS = 64;  // per worker; the schedule falls back to mo
 typedef const __attribute__((address_space(1))) void *gas_ptr;
 typedef __attribute__((address_space(3))) void *las_ptr;
 
-// OVL (round 5): the cross-kernel that PRODUCES K_*^T runs at the same time, from a second stream
-// (kstar_persist_kernel) -- it is store / vector-ALU bound, this kernel matrix-core bound, and beside each other they cost
-// what the GEMM costs alone (tools/share_probe: 95.6 us against 92.9 + 11.5 + a launch gap).  Rows arrive in chunks of 64
-// training rows x 64 columns; the producer stores them write-through (sc1), drains its stores and then stores the launch's
-// serial number into flags[p][chunk][column block].  Here wave 0 confirms, one k-tile ahead of the load cursor, that the
-// chunk the cursor moves into has its flag (an LDS-DMA of the flag word issued at the start of a k-tile, looked at when
-// the k-tile ends: no latency on anybody's path while the producer stays ahead, which it does after the first chunks) and
-// holds the k-tile barrier until it has; the K_*^T tiles are then loaded sc1 (not served from a stale line of this XCD's
-// L2: placement of the two launches relative to each other is not something HIP promises).  Every wait is bounded
-// (ovl.err is set, the caller reruns the block on the serial path).
-// K_*^T loads of the overlapped GEMM: plain (0, default) or sc1 (1).  Plain is enough and much faster: this launch's
-// kernel-start acquire has emptied the XCD's L2 of the half-step before's K_*^T, a line is first read after its flag, the
-// producer wrote it through -- and from then on the row-block items of the group re-read it from L2.  With sc1 every one of
-// those re-reads (348 MB per launch against 41 MB of distinct K_*^T) went past L2: 113 us per launch against 93.
-#ifndef GPEMU_OVL_SC1_LOADS
-#define GPEMU_OVL_SC1_LOADS 0
-#endif
-struct TrmmOverlap {
-  const unsigned *flags;      // [k][nchunk][ncb64]
-  unsigned serial;
-  int nchunk, ncb64;
-  int *err;                   // [1] incremented when a wait expired
-  int max_polls;
-  int *dbg;                   // [8] ovl_record
-};
-
 // the six loads of k-tile s+2 go out one by one between the MFMA groups of k-tile s
-template <bool OVL>
 __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
     const double *__restrict__ Wt, const double *__restrict__ KS, double *__restrict__ out,
     const TrmmItem *__restrict__ sched, const int *__restrict__ sched_cnt, int max_items,
-    int64_t Npad, int64_t Bcap, int k, int nrb, TrmmOverlap ovl
+    int64_t Npad, int64_t Bcap, int k, int nrb
 #ifdef GPEMU_TRMM_STAMPS        // diagnostic build (tools/trmm_balance.py): per-worker time stamps of a launch
     , unsigned long long *__restrict__ stamps
 #endif
@@ -585,7 +299,6 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
   __shared__ __attribute__((aligned(16))) double L2[BUFD];
   __shared__ double red[2][TILE];
   __shared__ TrmmItem s_items[TRMM_MAX_ITEMS];
-  __shared__ unsigned s_flag[OVL ? 64 : 1];            // mailbox of the flag words wave 0 asked for
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -637,49 +350,10 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
                  : "s"(lds_off), "v"(src)
                  : "memory");
   };
-  auto dma1_sc1 = [&](const double *src, double *dst_wave_uniform) {     // (OVL: the K_*^T chunks, past this XCD's L2)
-    const unsigned lds_off = (unsigned)(uintptr_t)((las_ptr)dst_wave_uniform);
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off sc1"
-                 :
-                 : "s"(lds_off), "v"(src)
-                 : "memory");
-  };
-  // ---- OVL: which flags a cursor position needs, asking for them, waiting for them ----
-  // key of a position = (item, 64-row chunk of its k-tile); its flag words: the item's one or two 64-column blocks
-  auto flag_addr = [&](int item, int t) -> const unsigned * {
-    const TrmmItem it = my[item];
-    const int cb0 = it.col0 >> 6, cb = cb0 + ((it.half || (lane & 1) == 0) ? 0 : 1);
-    return ovl.flags + ((int64_t)it.p * ovl.nchunk + (t >> 1)) * ovl.ncb64 + cb;
-  };
-  auto flag_request = [&](int item, int t) {          // wave 0: LDS-DMA of the words into s_flag (every lane one word)
-    const unsigned lds_off = (unsigned)(uintptr_t)((las_ptr)s_flag);
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off sc1"
-                 :
-                 : "s"(lds_off), "v"(flag_addr(item, t))
-                 : "memory");
-  };
-  auto flag_wait = [&](int item, int t) {             // wave 0: blocking, bounded
-    const unsigned *fp = flag_addr(item, t);
-    int polls = 0;
-    for (;;) {
-      const unsigned v = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__all(v == ovl.serial)) break;
-      if (++polls > ovl.max_polls) {                   // the producer is gone: end the launch, the results are void
-        if (lane == 0) {
-          atomicAdd(ovl.err, 1);                        // (units: GEMM row-flag waits; 1000s: producer waits, below)
-          const TrmmItem it = my[item];
-          ovl_record(ovl.dbg, 1, ovl.serial, it.p, t >> 1, it.col0 + 1000 * it.rb + 1000000 * (int)blockIdx.x, v, ovl.serial);
-        }
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  };
   // one of the wave's six loads of a k-tile (part compile-time after unrolling); the cursor moves on after the last
   auto dma_part = [&](double *dA, int part) {
     double *dB = dA + KT * TM;
     if (part < 2) dma1(l_pa + offA[part], dA + (wave * 2 + part) * 128);
-    else if (OVL && GPEMU_OVL_SC1_LOADS) dma1_sc1(l_pb + offB[part - 2], dB + (wave * 4 + part - 2) * 128);
     else dma1(l_pb + offB[part - 2], dB + (wave * 4 + part - 2) * 128);
     if (part == 5 && l_item < nitems) {
       if (++l_t == l_nt) {
@@ -701,23 +375,8 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
     __builtin_amdgcn_s_barrier();
   };
   l_open();
-  // OVL: (item, chunk) of the newest position confirmed; the first two k-tiles (rows 0 .. 63: chunk 0 of the first item)
-  // and the position after them are confirmed here, blocking -- nothing can start before the producer's first chunks anyway
-  int ok_item = -1, ok_chunk = -1;
-  bool asked = false;
-  if (OVL) {
-    if (wave == 0) flag_wait(0, 0);
-    ok_item = 0; ok_chunk = 0;
-    __syncthreads();
-  }
   dma(L0);
   dma(L1);
-  if (OVL) {                                           // the cursor stands on the third k-tile: confirm it before step 0 issues it
-    if (l_item < nitems && (l_item != ok_item || (l_t >> 1) != ok_chunk)) {
-      if (wave == 0) flag_wait(l_item, l_t);
-      ok_item = l_item; ok_chunk = l_t >> 1;
-    }
-  }
   tile_barrier();
 #ifdef GPEMU_TRMM_STAMPS
   if (stamps && tid == 0) stamps[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -737,19 +396,6 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
 
   auto step = [&](const double *cA, double *nA) -> bool {
     const double *cB = cA + KT * TM;
-    // OVL: this step issues the loads of the cursor's k-tile (confirmed); the position AFTER it is confirmed before this
-    // step's barrier, so that the next step may issue it.  Uniform bookkeeping in every wave, the memory traffic in wave 0.
-    int nx_item = l_item, nx_t = l_t + 1;
-    if (OVL) {
-      asked = false;
-      if (l_item < nitems) {
-        if (nx_t == l_nt) { nx_item = l_item + 1; nx_t = 0; }
-        if (nx_item < nitems && (nx_item != ok_item || (nx_t >> 1) != ok_chunk)) {
-          asked = true;
-          if (wave == 0) flag_request(nx_item, nx_t);   // before this step's six loads: done by the vmcnt(6) below
-        }
-      }
-    }
     if (cur.half) {
       const int ib = lk * TILE + (((cur.col0 & 64) + wn * 16 + lr) ^ sw);
       double a[2][2], b[2];
@@ -796,15 +442,6 @@ __global__ __launch_bounds__(512, 2) void trmm_vsq_dma_kernel(
         if (ks < 6) dma_part(nA, ks);   // k-tile +2 -> the buffer k-tile -1 was read from
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
-    if (OVL && asked) {
-      if (wave == 0) {
-        // the words asked for at the start of the step have landed (they are older than the step's six loads)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        const unsigned v = reinterpret_cast<volatile unsigned *>(s_flag)[lane & 1];
-        if (!__all(v == ovl.serial)) flag_wait(nx_item, nx_t);
-      }
-      ok_item = nx_item; ok_chunk = nx_t >> 1;
     }
     tile_barrier();
     if (++c_t == c_nt) {
@@ -916,7 +553,7 @@ static void build_trmm_schedule(gpemu_model *m, int ncb, std::vector<TrmmItem> &
   }
 }
 
-int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st, const OverlapCtx *oc) {
+int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st) {
   Workspace &w = m->ws;
   constexpr int64_t smallb_max = 128;
   const int64_t Bv = m->variant_B > 0 ? m->variant_B : B;   // a chain stacked with others is evaluated as it would be alone
@@ -927,7 +564,7 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st, const OverlapCtx 
     for (int64_t c0 = 0; c0 < B && rc == GPEMU_OK; c0 += per) {
       w.KS = KS0 + c0;
       w.vsq_part = V0 + c0 * m->k * m->vsq_nrb;
-      rc = launch_trmm_vsq(m, std::min(per, B - c0), st, nullptr);
+      rc = launch_trmm_vsq(m, std::min(per, B - c0), st);
     }
     w.KS = KS0;
     w.vsq_part = V0;
@@ -983,9 +620,9 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st, const OverlapCtx 
     GP_HIP(hipMalloc((void **)&dstamps, sizeof(unsigned long long) * 16 * 1024));
     GP_HIP(hipMemset(dstamps, 0, sizeof(unsigned long long) * 16 * 1024));
   }
-  hipLaunchKernelGGL(trmm_vsq_dma_kernel<false>, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
+  hipLaunchKernelGGL(trmm_vsq_dma_kernel, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
                      w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
-                     m->Npad, w.Bcap, (int)m->k, nrb, TrmmOverlap(), dstamps);
+                     m->Npad, w.Bcap, (int)m->k, nrb, dstamps);
   GP_HIP(hipGetLastError());
   prof_pair(m, 0, pe0, prof_mark(m, st));
   if (stamp_path && ++stamp_calls == 600) {
@@ -1006,18 +643,9 @@ int launch_trmm_vsq(gpemu_model *m, int64_t B, hipStream_t st, const OverlapCtx 
     }
   }
 #else
-  if (oc) {
-    // the producer of K_*^T runs beside this launch (launch_kstar_persist, on oc->side): wait for its rows chunk by chunk
-    const TrmmOverlap ovl{m->kflags, 4u * m->ovl_serial, (int)(m->Npad / KSTAR_ROWS_BIG), (int)(round_up(B, TILE) / 64), oc->err,
-                          oc->max_polls, m->ovl_ctl + OVL_QRING + OVL_CU_KEYS};
-    hipLaunchKernelGGL(trmm_vsq_dma_kernel<true>, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
-                       w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
-                       m->Npad, w.Bcap, (int)m->k, nrb, ovl);
-  } else {
-    hipLaunchKernelGGL(trmm_vsq_dma_kernel<false>, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
-                       w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
-                       m->Npad, w.Bcap, (int)m->k, nrb, TrmmOverlap());
-  }
+  hipLaunchKernelGGL(trmm_vsq_dma_kernel, dim3((unsigned)m->sched_workers), dim3(512), 0, st, m->Wt,
+                     w.KS, w.vsq_part, (const TrmmItem *)m->sched_items, m->sched_cnt, m->sched_max_items,
+                     m->Npad, w.Bcap, (int)m->k, nrb);
   GP_HIP(hipGetLastError());
   prof_pair(m, 0, pe0, prof_mark(m, st));
 #endif

@@ -382,124 +382,6 @@ static int end_step(gpemu_sampler *s, int store_chain, hipStream_t st, bool reco
   return GPEMU_OK;
 }
 
-__global__ void fill_u32_kernel(unsigned *p, int64_t n, unsigned v) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
-
-// Does this sampler take the overlapped half-step?  One emulation group, one chain, halves the
-// large-batch GEMM takes in one launch; GPEMU_NO_OVERLAP (read once) and a wait that expired switch it off.
-static bool overlap_wanted(const gpemu_sampler *s) {
-  const bool off = getenv("GPEMU_NO_OVERLAP") != nullptr;       // read per run call (tests compare the two paths)
-  if (off || s->ovl_off || s->groups.size() != 1 || s->nchains != 1) return false;
-  const gpemu_model *m = s->groups[0];
-  return m->lik_ready && overlap_eligible(m, s->ns[0]) && overlap_eligible(m, s->ns[1]);
-}
-
-// `steps` stretch-move steps with the cross-kernel of every half-step running BESIDE its triangular GEMM: the producer
-// (kstar_persist_kernel) on s->side, GEMM and likelihood on the chain's stream, ordered through memory (row flags, walker
-// stamps) -- no event, no extra launch.  Same arithmetic, same order of additions as the three-launch half-step: the same
-// chain.  Returns GPEMU_ERR_STATE if a wait expired (the caller restores the snapshot and takes the serial path).
-static int run_overlapped(gpemu_sampler *s, int64_t steps, int store_chain) {
-  hipStream_t st = s->stream;
-  gpemu_model *m = s->groups[0];
-  const int64_t W = s->W;
-  if (!s->side) {
-    GP_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
-    GP_HIP(hipMalloc((void **)&s->stamp, sizeof(unsigned) * (size_t)(W + 1)));
-  }
-  GP_TRY0(ensure_workspace(m, std::max(s->ns[0], s->ns[1])));
-  if (store_chain) GP_TRY0(ensure_chain(s, s->chain_len + steps));
-  // everything up to here is complete and in memory; from here on both streams take part
-  unsigned *gemm_word = s->stamp + W;
-  const unsigned serial0 = (unsigned)(2 * s->step_counter + 1);
-  hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((W + 1 + 255) / 256)), dim3(256), 0, st, s->stamp, W + 1, serial0 - 1u);
-  GP_HIP(hipGetLastError());
-  // randomness one batch AHEAD: the producer reads the ring without a stream order against the generator -- what it reads
-  // was generated at least RNG_BATCH steps (or one synchronisation, here) before
-  auto rng_ahead = [&]() -> int {
-    const uint64_t step = s->step_counter, want = (step / RNG_BATCH + 2) * RNG_BATCH;
-    if (s->rng_ready_until < step) s->rng_ready_until = step;
-    while (s->rng_ready_until < want) {
-      const uint64_t first = s->rng_ready_until;
-      const int64_t n = RNG_BATCH - (int64_t)(first % RNG_BATCH);
-      GP_TRY0(launch_rng_batch(s, st, first, n));
-      s->rng_ready_until = first + (uint64_t)n;
-    }
-    return GPEMU_OK;
-  };
-  // (whatever the serial path left in the ring is generated again with the rest: the generator is counter based, and the
-  // two streams are synchronised below before anything reads it)
-  s->rng_ready_until = s->step_counter;
-  GP_TRY0(rng_ahead());
-  GP_HIP(hipStreamSynchronize(st));
-  GP_HIP(hipStreamSynchronize(s->side));
-  // bound of every wait between the two streams (GPEMU_OVERLAP_TIMEOUT_MS, default 4000; ~1 us per poll) and the tests'
-  // fault injection, read per run call
-  double timeout_ms = 4000.0;
-  if (const char *e = getenv("GPEMU_OVERLAP_TIMEOUT_MS")) timeout_ms = std::min(std::max(atof(e), 1.0), 60000.0);
-  const int max_polls = (int)(timeout_ms * 1000.0);
-  const int fault = getenv("GPEMU_OVERLAP_FAULT") ? 1 : 0;
-  for (int64_t it = 0; it < steps; ++it) {
-    GP_TRY0(rng_ahead());
-    const size_t slot = rslot(s), pslot = (size_t)((s->step_counter + RNG_RING - 1) % RNG_RING);
-    const size_t o2 = slot * 2 * W;
-    for (int h = 0; h < 2; ++h) {
-      const int64_t n = s->ns[h];
-      const unsigned serial = (unsigned)(2 * s->step_counter + h + 1);
-      ProposeArgs pa = propose_args(s, h, 0, n);
-      pa.factors = nullptr;
-      AcceptArgs aa;
-      aa.enabled = 1;
-      aa.X = s->X; aa.logp = s->logp;
-      aa.idx_s = s->idx + o2 + h * W;
-      aa.factors = s->fac + o2 + h * W;            // (d - 1) log z from the generator: the expression the cross-kernel evaluates
-      aa.logu = s->logu + o2 + h * W;
-      aa.naccept = s->naccept; aa.flags = s->flags;
-      if (store_chain) {
-        aa.chain = s->chain + s->chain_len * W * s->d;
-        aa.lpchain = s->lpchain + s->chain_len * W;
-      }
-      aa.stamp = s->stamp; aa.gemm_word = gemm_word; aa.serial = serial;
-      aa.mean_pairs = 1;
-      OverlapCtx oc;
-      oc.side = s->side; oc.serial = serial; oc.stamp = s->stamp; oc.gemm_word = gemm_word;
-      // who proposed in the half before: set 0 of this step (h = 1), set 1 of the step before (h = 0)
-      oc.inds_chk = s->inds + (h == 1 ? slot : pslot) * W;
-      oc.chk_val = h == 1 ? 0 : 1;
-      oc.err = s->flags + 1;
-      oc.max_polls = max_polls;
-      oc.fault = fault;
-      double *dXq = s->q2 + (size_t)(serial & 1u) * s->qcap * DPAD;
-      const int rc = logpost_overlapped(m, n, dXq, s->newlp, st, aa, pa, oc);
-      if (rc != GPEMU_OK) return rc;
-    }
-    GP_TRY0(end_step(s, store_chain, st, true));
-  }
-  GP_HIP(hipStreamSynchronize(s->side));
-  int fl[2] = {0, 0};
-  GP_HIP(hipMemcpyAsync(fl, s->flags, sizeof(fl), hipMemcpyDeviceToHost, st));
-  GP_HIP(hipStreamSynchronize(st));
-  if (fl[1]) {
-    (void)hipMemsetAsync(s->flags, 0, sizeof(fl), st);
-    (void)hipStreamSynchronize(st);
-    int dbg[24];
-    memset(dbg, 0, sizeof(dbg));
-    if (m->ovl_ctl) {
-      (void)hipMemcpy(dbg, m->ovl_ctl + 64 + 2048, sizeof(dbg), hipMemcpyDeviceToHost);
-      (void)hipMemset(m->ovl_ctl + 64 + 2048, 0, sizeof(dbg));
-    }
-    set_error("overlapped run: waits between the two streams expired (%d: units = the GEMM's waits for rows, thousands = "
-              "producers' waits for the GEMM before, millions = their waits for walkers); first of each kind [serial ids(3) saw "
-              "wanted]: GEMM rows [%d %d %d %d %d %d] GEMM-before [%d %d %d %d %d %d] walker [%d %d %d %d %d %d]; step counter %llu",
-              fl[1], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[9], dbg[10], dbg[11], dbg[12], dbg[13], dbg[14],
-              dbg[17], dbg[18], dbg[19], dbg[20], dbg[21], dbg[22], (unsigned long long)s->step_counter);
-    return GPEMU_ERR_STATE;
-  }
-  return GPEMU_OK;
-}
-
-
 }  // namespace gpemu
 
 using namespace gpemu;
@@ -601,8 +483,6 @@ int gpemu_sampler_destroy(gpemu_sampler *s) {
   (void)hipFree(s->factors); (void)hipFree(s->newlp); (void)hipFree(s->naccept); (void)hipFree(s->flags);
   (void)hipFree(s->chain); (void)hipFree(s->lpchain);
   (void)hipFree(s->snapX); (void)hipFree(s->snaplp); (void)hipFree(s->snapacc);
-  if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
-  (void)hipFree(s->stamp);
   (void)hipFree(s->acf_part); (void)hipFree(s->acf_acf); (void)hipFree(s->acf_mean); (void)hipFree(s->acf_acf0);
   for (int h = 0; h < 2; ++h) { (void)hipFree(s->gmine[h]); (void)hipFree(s->gfull[h]); }
   delete s;
@@ -748,23 +628,6 @@ int gpemu_sampler_run(gpemu_sampler *s, int64_t steps, int store_chain) {
   // tools/time_fused_single.py: the fused front kernel runs its likelihood and cross-kernel phases back to back); the two-launch form at one rank is
   // reachable through gpemu_sampler_run_peer with a one-rank import (test_fused_run_world1_equals_three_launch_run).
   if (store_chain) GP_TRY(ensure_chain(s, s->chain_len + steps));
-  if (steps > 0 && overlap_wanted(s)) {
-    // the cross-kernel beside the triangular GEMM: same chain, a shorter half-step.  Its waits are bounded;
-    // should one expire, the block is rerun from the snapshot on the serial path below and the sampler stays there.
-    GP_TRY(gpemu_sampler_snapshot(s));
-    const int rc = run_overlapped(s, steps, store_chain);
-    s->last_run_mode = 1;
-    if (rc == GPEMU_OK) return check_nan(s);
-    if (rc != GPEMU_ERR_STATE) return rc;
-    if (s->side) (void)hipStreamSynchronize(s->side);
-    (void)hipStreamSynchronize(st);
-    GP_TRY(overlap_reset(s->groups[0]));       // some rows of the failed attempt were counted, others not
-    GP_TRY(gpemu_sampler_restore(s));
-    s->ovl_off = true;
-    s->last_run_mode = 2;
-  } else {
-    s->last_run_mode = 0;
-  }
   for (int64_t it = 0; it < steps; ++it) {
     GP_TRY(launch_rng(s, st, steps - it));
     for (int h = 0; h < 2; ++h) GP_TRY(half_step_fused(s, h, store_chain, st));
@@ -772,8 +635,6 @@ int gpemu_sampler_run(gpemu_sampler *s, int64_t steps, int store_chain) {
   }
   return check_nan(s);
 }
-
-int gpemu_sampler_last_run_mode(const gpemu_sampler *s) { return s ? s->last_run_mode : GPEMU_ERR_ARG; }
 
 int gpemu_sampler_step_host_rng(gpemu_sampler *s, const int32_t *inds, const double *zz,
                                 const int64_t *rint, const double *logu, int store_chain) {

@@ -16,15 +16,12 @@ namespace gpemu {
 //   * optionally finishes the stretch move for its walker (accept / reject, state update, chain
 //     record: emcee moves/red_blue.py), so a half-step needs no further launch.
 // sums the partials of walker b; returns (mu, sd) of PC `lane`
-// pairs: the partial means come as [chunk][2] -- the two wave rows of a chunk stored apart by the LDS-free producer of
-// the overlapped run (predict_dev.h: kstar_mfma_wave) -- and each pair is added first, which is the one addition the
-// workgroup form of the cross-kernel makes before it stores a chunk's partial: the same operands in the same order
 template <int KP>   // power of two >= k, <= 64
 __device__ __forceinline__ void walker_mean_sd(const double *__restrict__ mean_part,
                                                const double *__restrict__ vsq_part,
                                                const double *__restrict__ kdiag, double *mean_out,
                                                double *var_out, int64_t b, int64_t Bcap, int k,
-                                               int nchunk, int nrb, int lane, double &mu, double &sd, int pairs = 0) {
+                                               int nchunk, int nrb, int lane, double &mu, double &sd) {
   // lane = sub * KP + pc: SUBS = 64 / KP lanes share one PC's partial sums (independent loads in flight
   // instead of one long dependent chain), combined by xor-shuffles; lanes < k end up with the totals
   constexpr int SUBS = 64 / KP;
@@ -32,15 +29,10 @@ __device__ __forceinline__ void walker_mean_sd(const double *__restrict__ mean_p
   double mu_p = 0.0, vs_p = 0.0;
   if (pc < k) {
     // parts of one (walker, PC) are contiguous
-    const double *mp = mean_part + (b * k + pc) * nchunk * (pairs ? 2 : 1);
+    const double *mp = mean_part + (b * k + pc) * nchunk;
     const double *vp = vsq_part + (b * k + pc) * nrb;
-    if (pairs) {
 #pragma unroll 8
-      for (int c = sub; c < nchunk; c += SUBS) mu_p += (mp[2 * c] + mp[2 * c + 1]);
-    } else {
-#pragma unroll 8
-      for (int c = sub; c < nchunk; c += SUBS) mu_p += mp[c];
-    }
+    for (int c = sub; c < nchunk; c += SUBS) mu_p += mp[c];
 #pragma unroll 8
     for (int r = sub; r < nrb; r += SUBS) vs_p += vp[r];
   }
@@ -95,16 +87,7 @@ __device__ __forceinline__ void finish_walker(double total, double *__restrict__
   if (total != total && lane == 0) atomicAdd(aa.flags, 1);  // emcee raises on NaN
   const bool acc = (ao.factor + total - oldlp) > ao.logu;
   const double xold = ao.xold;
-  if (aa.stamp) {
-    // overlapped run: the producer of the next half-step's K_*^T is already running on another stream and reads this
-    // walker's position as soon as its stamp says so -- the state goes out write-through, the stamp behind its
-    // acknowledgement (one wave = one walker: the wave's own vmcnt covers every store of the walker)
-    if (lane < DPAD && acc) __hip_atomic_store(aa.X + (int64_t)w * DPAD + lane, ao.xnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(aa.stamp + w, aa.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else if (lane < DPAD && acc) {
-    aa.X[(int64_t)w * DPAD + lane] = ao.xnew;
-  }
+  if (lane < DPAD && acc) aa.X[(int64_t)w * DPAD + lane] = ao.xnew;
   if (lane == 0) {
     out[b] = total;
     if (acc) {

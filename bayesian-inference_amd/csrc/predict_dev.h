@@ -174,9 +174,7 @@ __device__ __forceinline__ kd4 kstar_tile_product(const double (&a)[KS], const d
 }
 
 // kernel values, stores and the mean's FMAs of one tile from its accumulator
-// ABL: probe ablations (1: no stores, 2: no exponential, 3: nontemporal stores); 4 (product: the producer beside the
-// GEMM, kstar_persist_kernel): write-through (agent-scope) stores, read by another kernel while this one runs
-template <int KIND, int TB, int ABL = 0>
+template <int KIND, int TB, int ABL = 0>   // ABL: probe ablations (1: no stores, 2: no exponential, 3: nontemporal stores)
 __device__ __forceinline__ void kstar_tile_finish(kd4 acc, double hq, kd4 al, double c, const double *s_tab, bool ragged,
                                                   int64_t row0, int64_t N, double *__restrict__ kout, int64_t Bcap, double &macc,
                                                   const KstarDirect &dir, const double *s_q, int col) {
@@ -190,8 +188,7 @@ __device__ __forceinline__ void kstar_tile_finish(kd4 acc, double hq, kd4 al, do
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    if (ABL == 4) __hip_atomic_store(&kout[(int64_t)(4 * r) * Bcap], v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else if (ABL == 3) __builtin_nontemporal_store(v[r], &kout[(int64_t)(4 * r) * Bcap]);
+    if (ABL == 3) __builtin_nontemporal_store(v[r], &kout[(int64_t)(4 * r) * Bcap]);
     else if (ABL != 1) kout[(int64_t)(4 * r) * Bcap] = v[r];
     macc = fma(al[r], v[r], macc);
   }
@@ -289,68 +286,6 @@ __device__ __forceinline__ double kstar_mfma_block(const double *s_q, const doub
     else sum = s_red[lane];
   }
   return sum;
-}
-
-// The same tiles by ONE wave on its own, for the producer that runs beside the triangular GEMM (k_predict.hip:
-// kstar_persist_kernel): no LDS and no barrier -- a resident producer must not stand in the way of the GEMM's 147 KiB LDS
-// allocation -- so the query components come in registers (qv[bt][s]: component 4 s + (lane >> 4) of column
-// (wc NBW + bt) 16 + (lane & 15), unscaled), the exponential's table from memory (`tab`, 512 bytes: L1), and the column
-// sums of the wave's rows go straight to `mean_dst` (this lane's column, the wave row's slot) instead of being added to the
-// other wave row's through LDS: the reader adds the two (loglik_dev.h: walker_mean_sd, PAIRS), in the order the workgroup
-// form adds them.  Same instructions in the same order per element as kstar_mfma_block: the same bits.  Stores write-through.
-// KIND 1 (Matern-0.5: needs the raw query rows for its direct distance) does not take this form.
-template <int KIND, int KS, int JTW, int NBW, int TB>
-__device__ __forceinline__ void kstar_mfma_wave(const double (&qv)[NBW][KS], const double *__restrict__ tab,
-                                                const KstarFrags<KS, JTW> &fr, const double *__restrict__ qsc,
-                                                const double *__restrict__ qof, double c, int d, int64_t jt0, int64_t N,
-                                                double *__restrict__ ks, int64_t Bcap, int lane, int vwave,
-                                                double *__restrict__ mean_dst, int64_t mean_col_stride) {
-  constexpr int WC = 4 / NBW, WR = 4 / WC;
-  const int wr = vwave % WR, wc = vwave / WR;
-  const int ln = lane & 15, lq = lane >> 4;
-  double bq[NBW][KS], hq[NBW];
-  double sc[KS], of[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) { sc[s] = qsc[4 * s + lq]; of[s] = qof[4 * s + lq]; }
-#pragma unroll
-  for (int bt = 0; bt < NBW; ++bt) {
-    double part = 0.0;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int comp = 4 * s + lq;
-      const double v = fma(qv[bt][s], sc[s], of[s]);
-      bq[bt][s] = v;
-      part = (comp < d) ? fma(v, v, part) : part;
-    }
-    part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);
-    hq[bt] = (KIND == 0) ? -0.5 * part : part;
-  }
-  double macc[NBW];
-#pragma unroll
-  for (int bt = 0; bt < NBW; ++bt) macc[bt] = 0.0;
-  double *kcol = ks + (int64_t)lq * Bcap + wc * NBW * 16 + ln;
-  const KstarDirect none{nullptr, nullptr};
-  constexpr int NT = JTW * NBW;
-  kd4 acc = kstar_tile_product<KS>(fr.a[0], bq[0]);
-#pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int jj = i / NBW, bt = i % NBW;
-    kd4 nxt = acc;
-    if (i + 1 < NT) nxt = kstar_tile_product<KS>(fr.a[(i + 1) / NBW], bq[(i + 1) % NBW]);
-    const int64_t jt = jt0 + wr * JTW + jj;
-    kstar_tile_finish<KIND, TB, 4>(acc, hq[bt], fr.al[jj], c, tab, (jt + 1) * 16 > N, jt * 16 + lq, N,
-                                   kcol + jt * 16 * Bcap + bt * 16, Bcap, macc[bt], none, nullptr, 0);
-    acc = nxt;
-  }
-#pragma unroll
-  for (int bt = 0; bt < NBW; ++bt) {
-    double s = macc[bt];
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    if (hq[bt] != hq[bt]) s = hq[bt];                // a NaN in the query: the column's mean says so
-    if (lq == 0) __hip_atomic_store(mean_dst + (int64_t)(bt * 16) * mean_col_stride, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 }  // namespace gpemu

@@ -5,8 +5,7 @@
 #include "internal.h"
 
 namespace gpemu {
-constexpr int RNG_RING = 64;        // steps of randomness kept on the device (the overlapped run generates one batch AHEAD
-                                    // and still reads the step before: 64, not 32)
+constexpr int RNG_RING = 32;        // steps of randomness kept on the device
 constexpr int RNG_BATCH = 16;       // steps generated per launch (half the ring: the previous step's draws stay
                                     // readable while the next batch is written)
 constexpr int GATHER_SLOTS = 3;
@@ -66,12 +65,6 @@ struct gpemu_sampler {
   // XCD-aware order of the front kernel's cross-kernel workgroups, per (share size, group): device tables (k_front.hip)
   struct FrontPerm { int64_t cnt; int group, wg0; int *dperm; };
   std::vector<FrontPerm> front_perms;
-  // overlapped run (k_sampler.hip: run_overlapped): the cross-kernel as a producer on a second stream
-  hipStream_t side = nullptr;
-  unsigned *stamp = nullptr;         // [W] + [1]: per walker the serial of the half-step whose accept / reject of it is in
-                                     // memory; the word behind them: the half-step whose GEMM has finished
-  bool ovl_off = false;              // a wait expired once: this sampler stays on the serial half-step
-  int last_run_mode = 0;             // of the last gpemu_sampler_run: 0 serial half-steps, 1 overlapped, 2 overlapped, then rerun serially
   // snapshot of the chain state (gpemu_sampler_snapshot / _restore): a block of steps that failed -- a lost peer
   // exchange -- is rerun from here over another transport and gives the chain of an unbroken run
   double *snapX = nullptr, *snaplp = nullptr;        // [W][DPAD], [W]

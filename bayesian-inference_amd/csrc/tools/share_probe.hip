@@ -147,8 +147,8 @@ int main(int argc, char **argv) {
       void *ditems = nullptr; int *dcnt = nullptr;
       upload_sched(flat.data(), sizeof(TrmmItem) * flat.size(), cnt, &ditems, &dcnt);
       t[variant] = time_us([&] {
-        hipLaunchKernelGGL(trmm_vsq_dma_kernel<false>, dim3((unsigned)nworkers), dim3(512), 0, sA, m.Wt, w.KS, w.vsq_part,
-                           (const TrmmItem *)ditems, dcnt, max_items, Npad, Bcap, (int)k, (int)m.vsq_nrb, TrmmOverlap());
+        hipLaunchKernelGGL(trmm_vsq_dma_kernel, dim3((unsigned)nworkers), dim3(512), 0, sA, m.Wt, w.KS, w.vsq_part,
+                           (const TrmmItem *)ditems, dcnt, max_items, Npad, Bcap, (int)k, (int)m.vsq_nrb);
       }, sA, 200, 300);
       for (int c : cnt) nit[variant] += c;
       nwk[variant] = nworkers; mx[variant] = max_items;

@@ -97,7 +97,6 @@ _SIGNATURES = {
     "gpemu_sampler_run_peer": (C.c_int, [C.c_void_p, c_i64, C.c_int]),
     "gpemu_sampler_peer_selftest": (C.c_int, [C.c_void_p]),
     "gpemu_sampler_peer_share": (C.c_int, [C.c_void_p, C.c_int]),
-    "gpemu_sampler_last_run_mode": (C.c_int, [C.c_void_p]),
     "gpemu_sampler_snapshot": (C.c_int, [C.c_void_p]),
     "gpemu_sampler_restore": (C.c_int, [C.c_void_p]),
     "gpemu_philox4x32": (C.c_int, [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]),

@@ -182,11 +182,6 @@ class DeviceSampler:
             raise ValueError("Probability function returned NaN")
         check(rc)
 
-    def last_run_mode(self):
-        """0: the last ``run`` took three launches per half-step in stream order; 1: the cross-kernel ran beside the
-        triangular GEMM (same chain, shorter step); 2: that was tried and rerun in stream order after an expired wait."""
-        return int(_lib.lib().gpemu_sampler_last_run_mode(self._h))
-
     def step_host_rng(self, inds, zz, rint, logu, store=True):
         inds = np.ascontiguousarray(inds, dtype=np.int32)
         zz = as_f64(np.concatenate(zz), (self.W,))

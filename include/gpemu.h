@@ -287,13 +287,6 @@ int gpemu_sampler_peer_share(gpemu_sampler *s, int ranks_on_device);
 int gpemu_sampler_peer_import(gpemu_sampler *s, int world, int rank, const char *handles);
 int gpemu_sampler_run_peer(gpemu_sampler *s, int64_t steps, int store_chain);
 
-/* How the last gpemu_sampler_run went: 0 = three launches per half-step in stream order; 1 = the cross-kernel of every
- * half-step ran BESIDE its triangular GEMM (one emulation group, one chain, halves of more than 128 proposals that the
- * large-batch GEMM takes in one launch; GPEMU_NO_OVERLAP switches it off): the same chain, a shorter step; 2 = that was
- * tried, a bounded wait between the two kernels expired, the block was rerun from the snapshot in stream order (the
- * sampler stays there).  Replaces ref: mcmc.py:83-107 like gpemu_sampler_run itself. */
-int gpemu_sampler_last_run_mode(const gpemu_sampler *s);
-
 /* Snapshot / restore of the chain state on the device (ensemble, log-probabilities, acceptance counters, step and
  * chain counters).  A block of steps whose peer exchange was lost (GPEMU_ERR_STATE from gpemu_sampler_run_peer) is
  * rerun from the snapshot over a collective transport: the random stream is counter based, so the rerun draws what the

@@ -953,87 +953,3 @@ def test_device_autocorrelation_time_equals_host_estimator():
                                    S.integrated_time(mc[:, 32 * c:32 * (c + 1)], quiet=True), rtol=1e-10)
     ms.close()
     dm.close()
-
-
-def _big_sampler_model(N, k, kind=O.RBF, nu=np.inf, seed=0):
-    model, prob, _ = GU.fixed_theta_model(N, 60, k, seed=seed, kind=kind, nu=nu)
-    dm = GU.device_model(model)
-    dm.likelihood_setup(prob["y_exp"], prob["y_err"], prob["lo"], prob["hi"], 1.0)
-    return dm
-
-
-@pytest.mark.parametrize("N,k,W,blocks,kind,nu", [
-    (300, 4, 600, (13, 27, 30), O.RBF, np.inf),          # generic placement; 70 steps: across the 64-step randomness ring
-    (300, 4, 610, (9, 17), O.MATERN, 1.5),               # the shipped kernel: one producer workgroup per CU; ragged halves
-    (1000, 10, 1024, (40, 33), O.RBF, np.inf),           # C3: the XCD-aware placement of the headline
-])
-def test_overlapped_run_is_the_three_launch_chain(N, k, W, blocks, kind, nu, monkeypatch):
-    """with halves of more than 128 proposals the cross-kernel of every half-step runs BESIDE its triangular
-    GEMM (producer on a second stream, rows handed over chunk by chunk through flags, accept / reject through walker
-    stamps).  Same arithmetic, same order of additions: the chain, the log-probabilities, the acceptance counts and the
-    final state are those of the three-launch half-step (GPEMU_NO_OVERLAP), bit for bit, whatever the blocking of the
-    steps into run calls.  ref: mcmc.py:83-107 (emcee's stretch move, restated in oracle/sampler_oracle.py)."""
-    from gpemu import synthetic
-    from gpemu.sampler import DeviceSampler
-    dm = _big_sampler_model(N, k, kind, nu)
-    X0 = synthetic.make_walkers(W, seed=5)
-    total = sum(blocks)
-    monkeypatch.setenv("GPEMU_NO_OVERLAP", "1")
-    ref = DeviceSampler([dm], W, seed=99)
-    ref.set_state(X0)
-    ref.run(total)
-    assert ref.last_run_mode() == 0
-    monkeypatch.delenv("GPEMU_NO_OVERLAP")
-    ds = DeviceSampler([dm], W, seed=99)
-    ds.set_state(X0)
-    for nb in blocks:
-        ds.run(nb)
-        assert ds.last_run_mode() == 1, "the overlapped half-step was not taken"
-    (c1, l1), (c0, l0) = ds.get_chain(), ref.get_chain()
-    np.testing.assert_array_equal(c1, c0)
-    np.testing.assert_array_equal(l1, l0)
-    np.testing.assert_array_equal(ds.counts()[0], ref.counts()[0])
-    np.testing.assert_array_equal(ds.get_state()[0], ref.get_state()[0])
-    np.testing.assert_array_equal(ds.get_state()[1], ref.get_state()[1])
-    # the two forms may alternate on one sampler
-    monkeypatch.setenv("GPEMU_NO_OVERLAP", "1")
-    ds.run(5)
-    monkeypatch.delenv("GPEMU_NO_OVERLAP")
-    ds.run(6)
-    ref.run(11)
-    np.testing.assert_array_equal(ds.get_chain()[0], ref.get_chain()[0])
-    ds.close(); ref.close(); dm.close()
-
-
-def test_overlapped_run_falls_back_when_a_wait_expires(monkeypatch):
-    """Every wait between the two streams of the overlapped run is bounded.  A producer workgroup that never publishes its
-    rows (fault injection): the GEMM's wait expires, the call restores the snapshot it took, reruns the block with three
-    launches per half-step and says so (mode 2); the chain is the serial chain, and the sampler stays on the serial path."""
-    import time
-    from gpemu import synthetic
-    from gpemu.sampler import DeviceSampler
-    dm = _big_sampler_model(300, 4)
-    W = 600
-    X0 = synthetic.make_walkers(W, seed=5)
-    monkeypatch.setenv("GPEMU_NO_OVERLAP", "1")
-    ref = DeviceSampler([dm], W, seed=3)
-    ref.set_state(X0)
-    ref.run(9)
-    monkeypatch.delenv("GPEMU_NO_OVERLAP")
-    ds = DeviceSampler([dm], W, seed=3)
-    ds.set_state(X0)
-    ds.run(4)
-    assert ds.last_run_mode() == 1
-    monkeypatch.setenv("GPEMU_OVERLAP_FAULT", "1")
-    monkeypatch.setenv("GPEMU_OVERLAP_TIMEOUT_MS", "200")
-    t0 = time.time()
-    ds.run(3)
-    assert time.time() - t0 < 30.0
-    assert ds.last_run_mode() == 2
-    monkeypatch.delenv("GPEMU_OVERLAP_FAULT")
-    ds.run(2)
-    assert ds.last_run_mode() == 0                       # stays on the serial path
-    np.testing.assert_array_equal(ds.get_chain()[0], ref.get_chain()[0])
-    np.testing.assert_array_equal(ds.get_chain()[1], ref.get_chain()[1])
-    np.testing.assert_array_equal(ds.counts()[0], ref.counts()[0])
-    ds.close(); ref.close(); dm.close()
