@@ -32,6 +32,7 @@ for name, out in (("stats_bench/**/*kernel_stats.csv", f"{prefix}_bench_kernel_s
     if f:
         shutil.copy(f, os.path.join(dst, out))
 for name, out in (("bench_default.json", f"{prefix}_bench_default.json"), ("emulated_sharding.jsonl", f"{prefix}_emulated_sharding.jsonl"),
+                  ("bench_10k_steps.json", f"{prefix}_bench_10k_steps.json"),
                   ("fit_lml.txt", f"{prefix}_fit_lml.txt"), ("predict_gbps.txt", f"{prefix}_predict_gbps.txt"),
                   ("closure_batch.txt", f"{prefix}_closure_batch.txt"), ("pca.txt", f"{prefix}_pca.txt"),
                   ("fit_batch.txt", f"{prefix}_fit_batch.txt"), ("fit_probes.txt", f"{prefix}_fit_probes.txt"),
