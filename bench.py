@@ -168,7 +168,8 @@ def measure_scaling_model(ds, dm, single_ms_per_step, steps=300):
     the triangular GEMM of the share, the front kernel (likelihood of the share + exchange + accept + proposal +
     cross-kernel: latency, not throughput), the rest (RNG batch, gaps).  `floor`: the same step with the GEMM at 100 % of
     the fp64 matrix peak and the front kernel as measured -- the speed-up NO schedule of the GEMM can exceed."""
-    out = {"single_gpu_ms_per_step": single_ms_per_step, "note": "emulated on one GPU; no cross-GPU hop; not a throughput claim"}
+    out = {"single_gpu_ms_per_step": single_ms_per_step, "note": "emulated on one GPU; no cross-GPU hop; not a throughput claim; gemm_us / front_us are HIP-event spans on the launch "
+                   "stream (each takes in part of the launch gap beside it), so their sum can exceed half of ms_per_step"}
     for world in (2, 4, 8):
         try:
             t_pre = time.perf_counter()
@@ -190,7 +191,7 @@ def measure_scaling_model(ds, dm, single_ms_per_step, steps=300):
             gemm_floor_us = N_PC * N_DESIGN ** 2 * share / (FP64_MATRIX_PEAK_TFLOPS * 1e12) * 1e6
             floor_ms = 2.0 * (gemm_floor_us + front_us) * 1e-3
             out[str(world)] = {"ms_per_step": ms, "speedup": single_ms_per_step / ms, "proposals_per_rank_and_half": share,
-                               "gemm_us": gemm_us, "front_us": front_us, "other_us_per_half_step": ms * 1e3 / 2 - gemm_us - front_us,
+                               "gemm_us": gemm_us, "front_us": front_us, "half_step_us": ms * 1e3 / 2,
                                "gemm_frac_of_peak": gemm_floor_us / gemm_us,
                                "floor": {"gemm_at_peak_us": gemm_floor_us, "ms_per_step": floor_ms,
                                          "speedup_bound": single_ms_per_step / floor_ms}}
@@ -482,6 +483,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fit", action="store_true", help="skip the fit-side legs (fit_c5, fit_c3)")
     ap.add_argument("--no-predict", action="store_true", help="skip metric 2 (gp_predict); for kernel profiles of the sampler alone")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the scaling_model and matern15 legs: they launch the headline's kernels on other amounts of work, "
+                         "which would mix into a kernel profile's per-kernel averages")
     ap.add_argument("--transport", default="both", choices=["both", "peer", "rccl", "torch"],
                     help="N > 1: how the new log-probabilities are exchanged; 'both' times the RCCL all-gather run and "
                          "the peer-store run in one invocation and reports the faster as `value`")
@@ -664,10 +668,10 @@ def main():
         except Exception as e:
             steady = {"error": repr(e)}
         try:
-            scaling_model = measure_scaling_model(ds, dm, headline["ms_per_step"])
+            scaling_model = None if args.no_extra else measure_scaling_model(ds, dm, headline["ms_per_step"])
         except Exception as e:
             scaling_model = {"error": repr(e)}
-        if not args.no_fit:
+        if not args.no_fit and not args.no_extra:
             try:
                 matern = measure_matern15(dev_index)
             except Exception as e:

@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo bench done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-fit --no-predict > $OUT/stats_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-fit --no-predict --no-extra > $OUT/stats_bench.log 2>&1
 echo stats_bench done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_predict -- python3 $R/tools/prof_predict.py 1024 200 > $OUT/stats_predict.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_predict -- python3 $R/tools/prof_predict.py 1024 3 > $OUT/pmc_write_predict.log 2>&1
