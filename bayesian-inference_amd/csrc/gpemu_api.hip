@@ -172,6 +172,33 @@ int logpost_groups(gpemu_model *const *ms, int ng, int64_t B, double *dXq, doubl
   if (rc != GPEMU_OK) return rc;
   return launch_loglik_groups(ms, ng, B, dXq, dout, 0, st, aa);
 }
+
+// Log-posterior of B <= 128 padded query rows over ng >= 1 groups of small emulators (at most 256 design points, 32 PCs
+// each): cross-kernel and triangular GEMM of every group in ONE launch (k_halfstep.hip), then the likelihood launch of
+// the general path on single partial sums.  The same bits as the general path.  GPEMU_NO_HALFSTEP (or
+// GPEMU_NO_GROUP_MERGE: "stage by stage, group by group") switches it off (tests; read per call).
+int logpost_small(gpemu_model *const *ms, int ng, int64_t B, double *dXq, double *dout, hipStream_t st,
+                  const AcceptArgs *aa, const ProposeArgs *pa) {
+  if (getenv("GPEMU_NO_HALFSTEP") != nullptr || getenv("GPEMU_NO_GROUP_MERGE") != nullptr) return GPEMU_ERR_UNSUPPORTED;
+  if (ng < 1 || ng > 8 || B < 1 || B > 128 || (aa && aa->chain_per != 0)) return GPEMU_ERR_UNSUPPORTED;
+  for (int g = 0; g < ng; ++g) {
+    const gpemu_model *m = ms[g];
+    if (!m->lik_ready) { set_error("gpemu_likelihood_setup has not been called"); return GPEMU_ERR_STATE; }
+    if (m->Npad > 256 || m->k > 32) return GPEMU_ERR_UNSUPPORTED;
+  }
+  for (int g = 0; g < ng; ++g) {
+    const int rc = ensure_workspace(ms[g], B);
+    if (rc != GPEMU_OK) return rc;
+  }
+  // the sampler's half-step (proposal in, accept out): likelihood and accept in the same launch, unless switched off
+  // (measured: 67.6 us per step against 56.2 with the likelihood as a launch of its own at the shipped shape -- signalling
+  // between XCDs goes through memory, ~3.5 us, as much as the kernel boundary it replaces: off unless asked for)
+  const bool one_launch = aa && aa->enabled && pa && pa->enabled && getenv("GPEMU_HALFSTEP_ONE_LAUNCH") != nullptr;
+  const int rc = launch_halfstep_small(ms, ng, B, dXq, st, pa, one_launch ? aa : nullptr, one_launch ? dout : nullptr);
+  if (rc != GPEMU_OK || one_launch) return rc;
+  if (ng == 1) return launch_loglik_lowrank(ms[0], B, dXq, dout, 0, st, aa);
+  return launch_loglik_groups(ms, ng, B, dXq, dout, 0, st, aa);
+}
 }  // namespace gpemu
 
 using namespace gpemu;
@@ -375,6 +402,7 @@ int gpemu_model_destroy(gpemu_model *m) {
   hipFree(m->blk_start); hipFree(m->blk_of);
   for (const gpemu_model::SchedEntry &en : m->sched_cache) { hipFree(en.items); hipFree(en.cnt); }
   for (const gpemu_model::SchedEntry &en : m->sm_cache) { hipFree(en.items); hipFree(en.cnt); }
+  (void)hipFree(m->hs_tickets);
   free_workspace(m->ws);
   for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
   if (m->stream) hipStreamDestroy(m->stream);

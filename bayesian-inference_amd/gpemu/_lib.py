@@ -99,6 +99,7 @@ _SIGNATURES = {
     "gpemu_sampler_peer_share": (C.c_int, [C.c_void_p, C.c_int]),
     "gpemu_sampler_snapshot": (C.c_int, [C.c_void_p]),
     "gpemu_sampler_restore": (C.c_int, [C.c_void_p]),
+    "gpemu_halfstep_small_launches": (C.c_int64, []),
     "gpemu_philox4x32": (C.c_int, [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]),
 }
 

@@ -295,6 +295,11 @@ int gpemu_sampler_run_peer(gpemu_sampler *s, int64_t steps, int store_chain);
 int gpemu_sampler_snapshot(gpemu_sampler *s);
 int gpemu_sampler_restore(gpemu_sampler *s);
 
+/* Launches so far, in this process, of the one-launch cross-kernel + triangular GEMM for small emulators (at most 256
+ * design points and 32 PCs per group, at most 128 rows: csrc/k_halfstep.hip; what a sampler's half-step and a small
+ * batched log-posterior take there).  For tests: which path ran.  GPEMU_NO_HALFSTEP=1 switches that path off. */
+int64_t gpemu_halfstep_small_launches(void);
+
 /* Philox4x32-10 block function (host copy of the device generator; for tests) */
 int gpemu_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                      uint32_t *out4);

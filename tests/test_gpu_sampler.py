@@ -334,6 +334,65 @@ def test_groups_in_one_launch_per_stage_equal_the_per_group_launches(monkeypatch
         dm.close()
 
 
+@pytest.mark.parametrize("N,pcs,W,kind,nu", [
+    (150, (5, 11, 25), 200, "rbf", np.inf),      # the shipped shape (ref: config/jet_substructure.yaml:243-271)
+    (150, (5, 11, 25), 100, "matern", 1.5),      # ... with the shipped kernel and walker count
+    (33, (3,), 10, "rbf", np.inf),               # two 32-row blocks, the second with one real row; five proposals per half
+    (97, (16, 17), 37, "matern", 2.5),           # both orders of the likelihood's partial sums (k <= 16, k > 16); ragged halves
+    (256, (32,), 256, "matern", 0.5),            # the largest shape the kernel takes: 256 rows, 32 PCs, 128 proposals
+    (128, (10,), 64, "rbf", np.inf),
+])
+def test_small_emulators_cross_kernel_and_gemm_in_one_launch_have_the_bits_of_the_general_path(N, pcs, W, kind, nu, monkeypatch):
+    """Emulators of at most 256 design points (the reference's shipped analysis has ~150): cross-kernel and triangular
+    GEMM of every group in ONE launch per half-step, K_*^T never leaving the workgroup (csrc/k_halfstep.hip), then the
+    likelihood launch.  Every partial sum is formed and added in the order of the three-launch path: with
+    GPEMU_NO_HALFSTEP the same chain, bit for bit -- positions, log-probabilities, acceptance counts -- and the stored
+    log-probabilities are the oracle's."""
+    from gpemu import _lib, synthetic
+    from gpemu.sampler import DeviceSampler
+    L = _lib.lib()
+    K = O.RBF if kind == "rbf" else O.MATERN
+    models, dms, probs = [], [], []
+    for gi, k in enumerate(pcs):
+        model, prob, _ = GU.fixed_theta_model(N, 40 + 10 * gi, k, seed=gi, kind=K, nu=nu)
+        dm = GU.device_model(model)
+        dm.likelihood_setup(prob["y_exp"], prob["y_err"], prob["lo"], prob["hi"], 1.0)
+        models.append(model); dms.append(dm); probs.append(prob)
+    lo, hi = probs[0]["lo"], probs[0]["hi"]
+    X0 = synthetic.make_walkers(W, seed=5, lo=lo, hi=hi)
+    out, launches = {}, {}
+    for form in ("one launch", "two launches", "general"):
+        monkeypatch.delenv("GPEMU_NO_HALFSTEP", raising=False)
+        monkeypatch.delenv("GPEMU_HALFSTEP_ONE_LAUNCH", raising=False)
+        if form == "one launch":            # likelihood + accept behind tickets in the same launch
+            monkeypatch.setenv("GPEMU_HALFSTEP_ONE_LAUNCH", "1")
+        elif form == "general":
+            monkeypatch.setenv("GPEMU_NO_HALFSTEP", "1")
+        n0 = L.gpemu_halfstep_small_launches()
+        ds = DeviceSampler(dms, W, seed=12)
+        ds.set_state(X0)
+        ds.run(7)
+        ds.run(3)
+        out[form] = ds.get_chain() + (ds.counts()[0], ds.get_state()[0], ds.get_state()[1])
+        launches[form] = L.gpemu_halfstep_small_launches() - n0
+        ds.close()
+    monkeypatch.delenv("GPEMU_NO_HALFSTEP", raising=False)
+    monkeypatch.delenv("GPEMU_HALFSTEP_ONE_LAUNCH", raising=False)
+    # which path ran (20 half-steps; set_state's evaluation of the start positions takes it too)
+    assert launches["one launch"] >= 20 and launches["two launches"] >= 20 and launches["general"] == 0, launches
+    for form in ("one launch", "two launches"):
+        for a, b in zip(out[form], out["general"]):
+            np.testing.assert_array_equal(a, b)
+    assert out["general"][2].sum() > 0                                     # (moves were accepted)
+    chain, lps = out["one launch"][0], out["one launch"][1]
+    for w in (0, W - 1):
+        ref = sum(O.log_posterior(chain[-1, w], {"g": models[g]}, lo, hi, probs[g]["y_exp"], probs[g]["y_err"])[0]
+                  for g in range(len(pcs)))
+        np.testing.assert_allclose(lps[-1, w], ref, rtol=1e-9)
+    for dm in dms:
+        dm.close()
+
+
 # ---- BASELINE configs[3] ("C4") at its full size: the C3 model, 1024 walkers, shares of 128 / 64 proposals ----------
 def _c4_reference(dm, prob, steps):
     from gpemu import synthetic
