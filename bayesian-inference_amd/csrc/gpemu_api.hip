@@ -190,12 +190,8 @@ int logpost_small(gpemu_model *const *ms, int ng, int64_t B, double *dXq, double
     const int rc = ensure_workspace(ms[g], B);
     if (rc != GPEMU_OK) return rc;
   }
-  // the sampler's half-step (proposal in, accept out): likelihood and accept in the same launch, unless switched off
-  // (measured: 67.6 us per step against 56.2 with the likelihood as a launch of its own at the shipped shape -- signalling
-  // between XCDs goes through memory, ~3.5 us, as much as the kernel boundary it replaces: off unless asked for)
-  const bool one_launch = aa && aa->enabled && pa && pa->enabled && getenv("GPEMU_HALFSTEP_ONE_LAUNCH") != nullptr;
-  const int rc = launch_halfstep_small(ms, ng, B, dXq, st, pa, one_launch ? aa : nullptr, one_launch ? dout : nullptr);
-  if (rc != GPEMU_OK || one_launch) return rc;
+  const int rc = launch_halfstep_small(ms, ng, B, dXq, st, pa);
+  if (rc != GPEMU_OK) return rc;
   if (ng == 1) return launch_loglik_lowrank(ms[0], B, dXq, dout, 0, st, aa);
   return launch_loglik_groups(ms, ng, B, dXq, dout, 0, st, aa);
 }
@@ -402,7 +398,6 @@ int gpemu_model_destroy(gpemu_model *m) {
   hipFree(m->blk_start); hipFree(m->blk_of);
   for (const gpemu_model::SchedEntry &en : m->sched_cache) { hipFree(en.items); hipFree(en.cnt); }
   for (const gpemu_model::SchedEntry &en : m->sm_cache) { hipFree(en.items); hipFree(en.cnt); }
-  (void)hipFree(m->hs_tickets);
   free_workspace(m->ws);
   for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
   if (m->stream) hipStreamDestroy(m->stream);

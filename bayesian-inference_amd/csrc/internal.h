@@ -79,10 +79,6 @@ struct gpemu_model {
   // sampler blocks), and a launch in flight keeps reading the one it was given -- so none is freed before the model is
   // (a few KB each; bounded: the oldest goes, after a stream sync, beyond 16)
   std::vector<SchedEntry> sm_cache;
-  // one-launch half-step of small emulators (k_halfstep.hip): per column block, how many (PC, block) workgroups have
-  // published so far (never reset: launch n waits for n x the PCs of the launch), and the count of expired waits
-  unsigned *hs_tickets = nullptr;   // [4] + [1] expired waits
-  uint32_t hs_target = 0;           // tickets of a column block once every launch so far has published
   int kernel_kind = 0;
   double nu = 0;
   int has_const = 0, has_noise = 0;
@@ -210,10 +206,7 @@ int logpost_groups(gpemu_model *const *ms, int ng, int64_t B, double *dXq, doubl
                    const AcceptArgs *aa, const ProposeArgs *pa);
 // small emulators (N <= 256 design points, k_halfstep.hip): cross-kernel + triangular GEMM of all groups in one launch,
 // then the likelihood launch; the bits of the general path.  GPEMU_ERR_UNSUPPORTED (nothing launched) where it does not apply
-// `aa` with `aa->enabled` and `dout`: the likelihood, the sum over the groups and the stretch move's accept step in the
-// SAME launch (workgroups behind the (PC, block) ones, waiting for their tickets)
-int launch_halfstep_small(gpemu_model *const *ms, int ng, int64_t B, double *dXq_padded, hipStream_t st, const ProposeArgs *pa,
-                          const AcceptArgs *aa = nullptr, double *dout = nullptr);
+int launch_halfstep_small(gpemu_model *const *ms, int ng, int64_t B, double *dXq_padded, hipStream_t st, const ProposeArgs *pa);
 int logpost_small(gpemu_model *const *ms, int ng, int64_t B, double *dXq, double *dout, hipStream_t st,
                   const AcceptArgs *aa, const ProposeArgs *pa);
 // fit-side building blocks (k_fit.hip): in-place blocked Cholesky of an Np x Np matrix (Np multiple of 64) with the

@@ -30,7 +30,6 @@
 #include "internal.h"
 #include "kstar_host.h"
 #include "predict_dev.h"
-#include "loglik_dev.h"
 
 namespace gpemu {
 static std::atomic<int64_t> g_halfstep_launches{0};
@@ -49,7 +48,7 @@ typedef double hd2 __attribute__((ext_vector_type(2)));
 
 constexpr int HS_COLS = 32;          // proposals per workgroup (the small-batch GEMM's column block)
 constexpr int HS_LDK = 34;           // leading dimension of K_*^T in LDS (doubles): 272-byte rows, 16-byte aligned
-constexpr int HS_RING = 8;           // k-tiles of W^T fragments in flight per wave
+constexpr int HS_RING = 4;           // k-tiles of W^T fragments in flight per wave
 constexpr int HS_NMAX = 256;         // design points at most
 constexpr int HS_GROUPS_MAX = 8;
 
@@ -59,9 +58,6 @@ struct HsGroup {
   int64_t N, Npad;
   int k, has_const, pc0;             // pc0: index of the group's first PC in the launch's list of all PCs
   int subs;                          // lanes that share a PC's partial sums in walker_mean_sd: 4 for k <= 16, else 2
-  // likelihood (the one-launch form only)
-  const double *lo, *hi, *kdiag, *G, *g0, *scal;
-  int nblk;
 };
 struct HsArgs {
   HsGroup g[HS_GROUPS_MAX];
@@ -69,122 +65,12 @@ struct HsArgs {
   int64_t B;
   const double *etab;
   double *Xq;                        // [..][DPAD] padded query rows (read, or written by the first PC's workgroups)
-  // one-launch form: workgroups [nprod, gridDim.x) take the likelihood + accept of the proposals once the (PC, block)
-  // workgroups of their column block have all published (tickets[cb] reaches `target`)
-  int nprod;                         // (PC, block) workgroups incl. the padding of the XCD-aware order; 0 = two-launch form
-  unsigned *tickets;                 // [4] per column block, [4] = expired waits
-  unsigned target;
-  long long max_polls;
-  double *out;                       // [B] new log-probabilities
 };
 
-// likelihood of proposal b for one group from the single partials the (PC, block) workgroups left (loglik_groups_kernel's
-// group_loglik with nchunk = nrb = 1: the same functions, the same order)
-template <int KMAX>
-__device__ __forceinline__ double hs_group_loglik(const HsGroup &gr, bool inside, int64_t b, int lane) {
-  constexpr bool PRE = KMAX <= 16;
-  const int k = gr.k;
-  double gpre[PRE ? KMAX : 1];
-  if (PRE) {
-#pragma unroll
-    for (int q = 0; q < KMAX; ++q) gpre[q] = (q < k && lane < k) ? gr.G[q * k + lane] : 0.0;
-  }
-  const double gl_pre = (lane < k) ? gr.g0[lane] : 0.0;
-  const double sc0_pre = gr.scal[0], sc1_pre = gr.scal[1];
-  // walker_mean_sd with one chunk and one row block (lane sub = 0 holds the partial, the others +0.0, then the shuffle
-  // adds): 0.0 + x for lanes < k.  The partials are read at the device's coherence point (see the stores).
-  double mu = 0.0, sd = 0.0;
-  if (lane < k) {
-    const double mp = __hip_atomic_load(gr.mean_part + b * k + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double vp = __hip_atomic_load(gr.vsq_part + b * k + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    mu = 0.0 + mp;
-    double v = gr.kdiag[lane] - (0.0 + vp);
-    if (v < 0.0) v = 0.0;     // skl _gpr.py:479-485
-    sd = sqrt(v);
-  }
-  return walker_loglik_lowrank<KMAX, PRE>(inside, mu, sd, gpre, gl_pre, sc0_pre, sc1_pre, gr.G, gr.g0, gr.scal, k, gr.nblk, lane);
-}
-
-// The likelihood + accept workgroups of the one-launch form.  They sit BEHIND the (PC, block) workgroups in the grid and
-// wait only for those -- which wait for nothing -- so with workgroups dispatched in index order (per XCD) every wait ends
-// whatever is resident beside this launch; the wait is bounded all the same (expired: counted, the host ends the run).
-// One proposal per group of `ng` waves (8 / ng proposals per workgroup); the groups' terms meet in LDS and are added in
-// group order (loglik_groups_kernel).
-__device__ __forceinline__ void hs_likelihood(const HsArgs &ha, const ProposeArgs &pa, const AcceptArgs &aa, int cidx) {
-  __shared__ double s_lp[8][HS_GROUPS_MAX];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ng = ha.ng, slots = 8 / ng;
-  const int slot = wave / ng, gw = wave % ng;
-  const int64_t b = (int64_t)cidx * slots + slot;
-  const bool active = slot < slots && b < ha.B;          // (wave-uniform; every wave reaches the barrier)
-  AcceptOperands ao;
-  if (active) {
-    const HsGroup &gr = ha.g[gw];
-    // Nothing here is read from this launch's (PC, block) workgroups except the partial sums: the wave forms the proposal
-    // itself (the same arithmetic: the same row and stretch factor the first PC's workgroups store).
-    double qv = 0.0;
-    {
-      const int w = pa.idx_s[b], j = pa.partner[b];
-      const double z = pa.zz[b];
-      if (lane < pa.d) {
-        const double cj = pa.X[(int64_t)j * DPAD + lane], sw = pa.X[(int64_t)w * DPAD + lane];
-        qv = cj - (cj - sw) * z;                     // emcee moves/stretch.py get_proposal
-        if (gw == 0) ao.xold = sw;
-      }
-      if (gw == 0) {
-        ao.w = w;
-        ao.oldlp = aa.logp[w];
-        ao.logu = aa.logu[b];
-        ao.factor = (pa.d - 1.0) * log(z);
-        ao.xnew = qv;
-      }
-    }
-    bool in = true;
-    if (lane < ha.d) in = (qv > gr.lo[lane]) && (qv < gr.hi[lane]);
-    const bool inside = __all(in);
-    const unsigned *tk = ha.tickets + (b / HS_COLS);
-    long long polls = 0;
-    bool ok = true;
-    while ((int)(__hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ha.target) < 0) {
-      if (++polls > ha.max_polls) { ok = false; break; }
-      __builtin_amdgcn_s_sleep(4);
-    }
-    HS_WALL(1);
-    if (!ok) {
-      if (lane == 0) atomicAdd(ha.tickets + 4, 1u);
-      s_lp[slot][gw] = 0.0 / 0.0;
-    } else {
-      double lp;
-      if (gr.k <= 4) lp = hs_group_loglik<4>(gr, inside, b, lane);
-      else if (gr.k <= 8) lp = hs_group_loglik<8>(gr, inside, b, lane);
-      else if (gr.k <= 12) lp = hs_group_loglik<12>(gr, inside, b, lane);
-      else if (gr.k <= 16) lp = hs_group_loglik<16>(gr, inside, b, lane);
-      else if (gr.k <= 20) lp = hs_group_loglik<20>(gr, inside, b, lane);
-      else if (gr.k <= 24) lp = hs_group_loglik<24>(gr, inside, b, lane);
-      else if (gr.k <= 28) lp = hs_group_loglik<28>(gr, inside, b, lane);
-      else lp = hs_group_loglik<32>(gr, inside, b, lane);
-      if (lane == 0) s_lp[slot][gw] = lp;
-    }
-  }
-  __syncthreads();
-  if (active && gw == 0) {
-    double total = s_lp[slot][0];
-    for (int g = 1; g < ng; ++g) total = s_lp[slot][g] + total;     // (a launch per group: total_g + out[b])
-    finish_walker(total, ha.out, b, ha.d, lane, 0, aa, ao);
-  }
-}
-
-
 template <int KIND>
-__global__ __launch_bounds__(512) void halfstep_small_kernel(HsArgs ha, ProposeArgs pa, AcceptArgs aa) {
+__global__ __launch_bounds__(512) void halfstep_small_kernel(HsArgs ha, ProposeArgs pa) {
   constexpr int KS = 2, TB = KSTAR_TB;
   HS_WALL(0);
-  if (ha.nprod > 0 && (int)blockIdx.x >= ha.nprod) {
-    hs_likelihood(ha, pa, aa, (int)blockIdx.x - ha.nprod);
-    HS_WALL(2);
-    return;
-  }
   extern __shared__ __attribute__((aligned(16))) double s_K[];              // [32 ceil(N / 32)][HS_LDK]
   __shared__ __attribute__((aligned(16))) double s_ex[2 * 2 * 3 * 2 * 64 * 4];   // K-slice sums on their way to wave g = 0: two buffers of 24 KiB
   __shared__ double s_sq[(HS_NMAX / 32) * 4 * 64];                          // per 32-row block, tile and lane: V^2 summed over the lane's rows
@@ -219,16 +105,19 @@ __global__ __launch_bounds__(512) void halfstep_small_kernel(HsArgs ha, ProposeA
   // W^T fragments three k-tiles ahead: lane (q, lk) takes W^T[32 t + 4 s + lk][32 rb + 2 q, + 1] for its two slices.
   const int gy = wave & 1, gg = wave >> 1;
   const double *Wp = gr.Wt + (int64_t)p * Npad * Npad + (int64_t)(4 * gg + lk) * Npad + 2 * q;
-  int l_rb = 0, l_t = 0;
   // (every call loads -- beyond the last k-tile the last one again -- so that the number of loads in flight is known at
-  // compile time; the cursor moves by selects, not branches)
+  // compile time; the cursor is three 32-bit scalars moved by selects: the k-tile's ~60 scalar instructions of address
+  // arithmetic in 64 bits were what the loop spent its time on, 350 of 750 clocks per k-tile with the MFMAs taken out)
+  const int npad = (int)Npad;
+  const double *Wp2 = Wp + 16 * npad;
+  int l_rb = 0, l_t = 0, l_off = 0;
   auto issue = [&](hd2 (&r)[2]) {
-    const double *src = Wp + (int64_t)(32 * l_t) * Npad + 32 * l_rb;
-    r[0] = *reinterpret_cast<const hd2 *>(src);
-    r[1] = *reinterpret_cast<const hd2 *>(src + 16 * Npad);
+    r[0] = *reinterpret_cast<const hd2 *>(Wp + l_off);
+    r[1] = *reinterpret_cast<const hd2 *>(Wp2 + l_off);
     const bool in_block = l_t < l_rb, next_block = !in_block && (l_rb + 1 < nt32);
-    l_t = in_block ? l_t + 1 : (next_block ? 0 : l_t);
     l_rb = next_block ? l_rb + 1 : l_rb;
+    l_t = in_block ? l_t + 1 : (next_block ? 0 : l_t);
+    l_off = in_block ? l_off + 32 * npad : (next_block ? 32 * l_rb : l_off);
   };
   hd2 ring[HS_RING][2];
 #pragma unroll
@@ -346,8 +235,7 @@ __global__ __launch_bounds__(512) void halfstep_small_kernel(HsArgs ha, ProposeA
     for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
       for (int x = 0; x < 2; ++x) acc[sl][x] = hd4{0.0, 0.0, 0.0, 0.0};
-    int pend_rb = -1;                                        // block whose sums wave g = 0 still has to finish
-    hd4 pt0 = hd4{0.0, 0.0, 0.0, 0.0}, pt1 = pt0;
+    hd4 pt0, pt1;
     auto finish_block = [&](int rb, const hd4 &t0, const hd4 &t1) {
       const hd4 *ex = reinterpret_cast<const hd4 *>(s_ex) + (size_t)(rb & 1) * (2 * 3 * 2 * 64);
       hd4 v0 = t0, v1 = t1;
@@ -360,7 +248,7 @@ __global__ __launch_bounds__(512) void halfstep_small_kernel(HsArgs ha, ProposeA
       s_sq[(rb * 4 + 1 + 2 * gy) * 64 + lane] = fma(v1[0], v1[0], v1[1] * v1[1]) + fma(v1[2], v1[2], v1[3] * v1[3]);
     };
     const int nsteps = nt32 * (nt32 + 1) / 2;                // k-tiles (rb, t), t <= rb, in the order the fragments were requested
-    int c_rb = 0, c_t = 0;
+    int c_rb = 0, c_t = 0, c_boff = 0;
     double b0 = Kl[0], b1 = Kl[16 * HS_LDK];
     for (int s0 = 0; s0 < nsteps; s0 += HS_RING) {
 #pragma unroll
@@ -372,22 +260,21 @@ __global__ __launch_bounds__(512) void halfstep_small_kernel(HsArgs ha, ProposeA
         if (s0 + u < nsteps) {                               // (wave-uniform)
           const double c0 = b0, c1 = b1;
           const bool last_t = (c_t == c_rb);
-          const int n_t = last_t ? 0 : c_t + 1;              // the next k-tile's K_*^T fragments while the matrix cores work
-          b0 = Kl[(32 * n_t) * HS_LDK];
-          b1 = Kl[(32 * n_t + 16) * HS_LDK];
+          c_boff = last_t ? 0 : c_boff + 32 * HS_LDK;        // the next k-tile's K_*^T fragments while the matrix cores work
+          b0 = Kl[c_boff];
+          b1 = Kl[c_boff + 16 * HS_LDK];
 #pragma unroll
           for (int x = 0; x < 2; ++x) {
             acc[0][x] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[x], c0, acc[0][x], 0, 0, 0);
             acc[1][x] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[x], c1, acc[1][x], 0, 0, 0);
           }
-          // (wave g = 0: the block before's sums, while the matrix cores work on this k-tile)
-          if (pend_rb >= 0 && gg == 0) { finish_block(pend_rb, pt0, pt1); }
-          pend_rb = -1;
           if (last_t) {
             // slices g and g + 4 here; waves g > 0 hand their sums to wave g = 0 of the same column tile, which adds them
             // in turn (k_trmm_small.hip: ((t0 + t1) + t2) + t3), squares, and sums the register pair and the two pairs of
             // a lane (that kernel's xor-4 step); the lane groups and the two row tiles follow in phase 4.  Two exchange
-            // buffers in turn: one barrier per block, and wave g = 0 reads behind the next k-tile's MFMAs.
+            // buffers in turn: one barrier per block.  (Wave g = 0 finishing the block BEHIND the next k-tile's MFMAs was
+            // measured: slower -- double-precision vector instructions beside another wave's f64 MFMAs on one SIMD halve
+            // both, profiles/r01_fp64_rates.txt.)
             hd4 *ex = reinterpret_cast<hd4 *>(s_ex) + (size_t)(c_rb & 1) * (2 * 3 * 2 * 64);
             pt0 = acc[0][0] + acc[1][0];
             pt1 = acc[0][1] + acc[1][1];
@@ -396,7 +283,7 @@ __global__ __launch_bounds__(512) void halfstep_small_kernel(HsArgs ha, ProposeA
               ex[((gy * 3 + gg - 1) * 2 + 1) * 64 + lane] = pt1;
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            pend_rb = c_rb;
+            if (gg == 0) finish_block(c_rb, pt0, pt1);
             HS_STAMP(8 + c_rb);
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl)
@@ -410,7 +297,6 @@ __global__ __launch_bounds__(512) void halfstep_small_kernel(HsArgs ha, ProposeA
         }
       }
     }
-    if (pend_rb >= 0 && gg == 0) finish_block(pend_rb, pt0, pt1);
   }
   __syncthreads();
   HS_STAMP(3);
@@ -449,32 +335,20 @@ __global__ __launch_bounds__(512) void halfstep_small_kernel(HsArgs ha, ProposeA
       total = sa + __shfl_xor(sa, 32);                          // m0 + m1
     }
     if (half == 0 && b < ha.B) {
-      double *dst = (wave == 0 ? gr.mean_part : gr.vsq_part) + b * gr.k + p;
-      // (one-launch form: straight to the device's coherence point -- the likelihood workgroups run on other XCDs, whose
-      // L2s may still hold the half-step before's value of this very address)
-      if (ha.nprod > 0) __hip_atomic_store(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else *dst = total;
+      if (wave == 0) gr.mean_part[b * gr.k + p] = total;
+      else gr.vsq_part[b * gr.k + p] = total;
     }
   }
   HS_STAMP(4);
-  if (ha.nprod > 0) {
-    // the partials went out as device-scope stores; once they are acknowledged (s_waitcnt) and the workgroup's waves have
-    // met, one relaxed increment publishes them.  No release fence: at device scope it writes the XCD's whole L2 back
-    // (5 us per workgroup measured), and the readers' acquire would invalidate theirs (300 waves, one after the other).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(ha.tickets + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   HS_WALL(2);
 }
 
 // cross-kernel + triangular GEMM of B <= 128 query rows for ng groups of at most 256 design points in one launch; the
 // groups' workspaces then hold ONE partial per (row, PC) (cur_nchunk = cur_nrb = 1) for the likelihood launch.
 // GPEMU_ERR_UNSUPPORTED (nothing launched, no error set) where the shape does not fit: the caller takes the general path.
-int launch_halfstep_small(gpemu_model *const *ms, int ng, int64_t B, double *dXq, hipStream_t st, const ProposeArgs *pa,
-                          const AcceptArgs *aa, double *dout) {
+int launch_halfstep_small(gpemu_model *const *ms, int ng, int64_t B, double *dXq, hipStream_t st, const ProposeArgs *pa) {
   if (ng < 1 || ng > HS_GROUPS_MAX || B < 1 || B > 128) return GPEMU_ERR_UNSUPPORTED;
-  gpemu_model *m0 = ms[0];
+  const gpemu_model *m0 = ms[0];
   int nt32max = 0;
   for (int g = 0; g < ng; ++g) {
     const gpemu_model *m = ms[g];
@@ -484,11 +358,14 @@ int launch_halfstep_small(gpemu_model *const *ms, int ng, int64_t B, double *dXq
       return GPEMU_ERR_UNSUPPORTED;
     nt32max = std::max(nt32max, (int)((m->N + 31) / 32));
   }
-  const bool one_launch = aa && aa->enabled && dout;
-  if (one_launch && !m0->hs_tickets) {
-    GP_HIP(hipMalloc((void **)&m0->hs_tickets, sizeof(unsigned) * 8));
-    GP_HIP(hipMemsetAsync(m0->hs_tickets, 0, sizeof(unsigned) * 8, st));
-    m0->hs_target = 0;
+  // few (PC, block) pairs: the general path spreads the same work over more, shorter workgroups (one group of 11 PCs, 200
+  // walkers: 44 pairs, 41.1 us per step here against 38.6; 25 PCs: 100 pairs, 53.3 against 63.5)
+  {
+    int ktot = 0;
+    for (int g = 0; g < ng; ++g) ktot += (int)ms[g]->k;
+    const char *e = getenv("GPEMU_HALFSTEP_MIN_PAIRS");
+    const int min_pairs = e ? atoi(e) : 64;
+    if (ktot * (int)((B + HS_COLS - 1) / HS_COLS) < min_pairs) return GPEMU_ERR_UNSUPPORTED;
   }
   HsArgs ha;
   memset(&ha, 0, sizeof(ha));
@@ -503,28 +380,16 @@ int launch_halfstep_small(gpemu_model *const *ms, int ng, int64_t B, double *dXq
     gpemu_model *m = ms[g];
     Workspace &w = m->ws;
     ha.g[g] = HsGroup{m->Xa, m->alf, m->qsc, m->qof, m->constv, m->Xs, m->inv_ls, m->Wt, w.mean_part, w.vsq_part,
-                      m->N, m->Npad, (int)m->k, m->has_const, pc0, m->k <= 16 ? 4 : 2,
-                      m->lo, m->hi, m->kdiag, m->G, m->g0, m->scal, (int)m->nblk};
+                      m->N, m->Npad, (int)m->k, m->has_const, pc0, m->k <= 16 ? 4 : 2};
     pc0 += (int)m->k;
     w.cur_nchunk = 1;
     w.cur_nrb = 1;
   }
   ha.ktot = pc0;
   const int nprod = (ha.ktot + 7) / 8 * 8 * ha.ncb;
-  int ncons = 0;
-  if (one_launch) {
-    m0->hs_target += (uint32_t)ha.ktot;       // (wraps with the counters)
-    ha.nprod = nprod;
-    ha.tickets = m0->hs_tickets;
-    ha.target = m0->hs_target;
-    ha.max_polls = 20000000;                  // ~ seconds: never reached unless a (PC, block) workgroup died
-    ha.out = dout;
-    ncons = (int)((B + (8 / ng) - 1) / (8 / ng));
-  }
   const ProposeArgs pargs = pa ? *pa : ProposeArgs();
-  const AcceptArgs aargs = one_launch ? *aa : AcceptArgs();
   const size_t shm = sizeof(double) * (size_t)nt32max * 32 * HS_LDK;
-  const dim3 grid((unsigned)(nprod + ncons)), block(512);
+  const dim3 grid((unsigned)nprod), block(512);
 #define GP_LAUNCH_HS(KD)                                                                                                  \
   do {                                                                                                                    \
     static bool allowed[64] = {false};       /* per device: the kernel's LDS goes beyond the default 64 KiB */             \
@@ -533,7 +398,7 @@ int launch_halfstep_small(gpemu_model *const *ms, int ng, int64_t B, double *dXq
                                  (int)(sizeof(double) * HS_NMAX * HS_LDK)));                                              \
       allowed[m0->device & 63] = true;                                                                                    \
     }                                                                                                                     \
-    hipLaunchKernelGGL(halfstep_small_kernel<KD>, grid, block, shm, st, ha, pargs, aargs);                                \
+    hipLaunchKernelGGL(halfstep_small_kernel<KD>, grid, block, shm, st, ha, pargs);                                      \
   } while (0)
   switch (kstar_kind(m0)) {
     case 0: GP_LAUNCH_HS(0); break;

@@ -614,19 +614,8 @@ int gpemu_sampler_restore(gpemu_sampler *s) {
 
 static int check_nan(gpemu_sampler *s) {
   int flag = 0;
-  unsigned expired = 0;
-  gpemu_model *m0 = s->groups[0];
   GP_HIP(hipMemcpyAsync(&flag, s->flags, sizeof(int), hipMemcpyDeviceToHost, s->stream));
-  if (m0->hs_tickets) GP_HIP(hipMemcpyAsync(&expired, m0->hs_tickets + 4, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
   GP_HIP(hipStreamSynchronize(s->stream));
-  if (expired) {     // (k_halfstep.hip: a likelihood workgroup gave up waiting for the (PC, block) workgroups of its launch)
-    (void)hipMemsetAsync(m0->hs_tickets, 0, sizeof(unsigned) * 8, s->stream);
-    (void)hipMemsetAsync(s->flags, 0, sizeof(int), s->stream);
-    m0->hs_target = 0;
-    set_error("one-launch half-step: %u waits for the cross-kernel / GEMM workgroups expired; the chain state is not valid "
-              "(GPEMU_HALFSTEP_TWO_LAUNCHES=1 selects the form without waits)", expired);
-    return GPEMU_ERR_STATE;
-  }
   if (flag) {
     (void)hipMemsetAsync(s->flags, 0, sizeof(int), s->stream);
     set_error("log-probability returned NaN for %d proposals (emcee raises ValueError here)", flag);

@@ -360,13 +360,11 @@ def test_small_emulators_cross_kernel_and_gemm_in_one_launch_have_the_bits_of_th
         models.append(model); dms.append(dm); probs.append(prob)
     lo, hi = probs[0]["lo"], probs[0]["hi"]
     X0 = synthetic.make_walkers(W, seed=5, lo=lo, hi=hi)
+    monkeypatch.setenv("GPEMU_HALFSTEP_MIN_PAIRS", "0")      # (the kernel also where the general path is the faster one)
     out, launches = {}, {}
-    for form in ("one launch", "two launches", "general"):
+    for form in ("small", "general"):
         monkeypatch.delenv("GPEMU_NO_HALFSTEP", raising=False)
-        monkeypatch.delenv("GPEMU_HALFSTEP_ONE_LAUNCH", raising=False)
-        if form == "one launch":            # likelihood + accept behind tickets in the same launch
-            monkeypatch.setenv("GPEMU_HALFSTEP_ONE_LAUNCH", "1")
-        elif form == "general":
+        if form == "general":
             monkeypatch.setenv("GPEMU_NO_HALFSTEP", "1")
         n0 = L.gpemu_halfstep_small_launches()
         ds = DeviceSampler(dms, W, seed=12)
@@ -377,14 +375,12 @@ def test_small_emulators_cross_kernel_and_gemm_in_one_launch_have_the_bits_of_th
         launches[form] = L.gpemu_halfstep_small_launches() - n0
         ds.close()
     monkeypatch.delenv("GPEMU_NO_HALFSTEP", raising=False)
-    monkeypatch.delenv("GPEMU_HALFSTEP_ONE_LAUNCH", raising=False)
     # which path ran (20 half-steps; set_state's evaluation of the start positions takes it too)
-    assert launches["one launch"] >= 20 and launches["two launches"] >= 20 and launches["general"] == 0, launches
-    for form in ("one launch", "two launches"):
-        for a, b in zip(out[form], out["general"]):
-            np.testing.assert_array_equal(a, b)
+    assert launches["small"] >= 20 and launches["general"] == 0, launches
+    for a, b in zip(out["small"], out["general"]):
+        np.testing.assert_array_equal(a, b)
     assert out["general"][2].sum() > 0                                     # (moves were accepted)
-    chain, lps = out["one launch"][0], out["one launch"][1]
+    chain, lps = out["small"][0], out["small"][1]
     for w in (0, W - 1):
         ref = sum(O.log_posterior(chain[-1, w], {"g": models[g]}, lo, hi, probs[g]["y_exp"], probs[g]["y_err"])[0]
                   for g in range(len(pcs)))

@@ -45,21 +45,15 @@ for rep in range(3):
                 print(f"    row block {rb}: done {st[0, 8 + rb] - t} ticks after the one before")
                 t = st[0, 8 + rb]
 
-# wall-clock picture of the last launch: start / (ticket seen) / end of every workgroup, in us after the first start
+# wall-clock picture of the last launch: start / end of every workgroup (wall_clock64: one 100 MHz counter for the chip)
 g = L.gpemu_debug_hs_wall
 g.restype = C.c_int
 wl = (C.c_longlong * 2048)()
 assert g(wl) == 0
 wl = np.array(wl[:]).reshape(512, 4)
-used = wl[:, 0] > 0
-t0 = wl[used, 0].min()
-idx = np.flatnonzero(used)
-ends = (wl[idx, 2] - t0) / 100.0
-seen = (wl[idx, 1] - t0) / 100.0
-prod = (wl[idx, 1] == 0) & (ends > 0)
-cons = wl[idx, 1] > 0
-print(f"(PC, block) workgroups: {prod.sum()}, end min {ends[prod].min():.2f} median {np.median(ends[prod]):.2f} max {ends[prod].max():.2f} us; the five latest: "
-      + ", ".join(f"{idx[prod][j]}: {ends[prod][j]:.2f}" for j in np.argsort(ends[prod])[-5:]))
-if cons.any():
-    print(f"likelihood workgroups: {cons.sum()}, ticket seen {seen[cons].min():.2f} .. {seen[cons].max():.2f}, end {ends[cons].min():.2f} .. {ends[cons].max():.2f} us")
+idx = np.flatnonzero((wl[:, 0] > 0) & (wl[:, 2] > wl[:, 0]))
+t0 = wl[idx, 0].min()
+starts, ends = (wl[idx, 0] - t0) / 100.0, (wl[idx, 2] - t0) / 100.0
+print(f"{len(idx)} workgroups: start {starts.min():.2f} .. {starts.max():.2f} us, end min {ends.min():.2f} median {np.median(ends):.2f} max {ends.max():.2f} us "
+      "after the first start; the five latest: " + ", ".join(f"{idx[j]}: {ends[j]:.2f}" for j in np.argsort(ends)[-5:]))
 s.close()
