@@ -20,10 +20,12 @@
 //
 // Every value is formed by the device functions and in the order of kstar_kernel<., 2, 1, 2> / trmm_vsq_small_kernel /
 // walker_mean_sd; rows and k-tiles that are padding contribute exact zeros there and are skipped here: the chain is the
-// three-launch path's BIT FOR BIT (tests/test_gpu_shapes.py, test_gpu_shipped.py).  No workgroup waits for another, so
-// nothing depends on how many are resident (several ranks rehearsing on one device, other streams).
+// three-launch path's BIT FOR BIT (tests/test_gpu_sampler.py::test_small_emulators_..., test_gpu_shipped.py).  No
+// workgroup waits for another, so nothing depends on how many are resident (several ranks rehearsing on one device).
 //
-// A second launch for the likelihood instead of tickets inside this one: measured alternatives in DESIGN.md 4.17.
+// Shipped shape (150 design points, 5 + 11 + 25 PCs, 200 walkers): 84.2 -> 54.7 us per step.  What was measured on the
+// way -- six forms of the GEMM phase, and the likelihood + accept behind tickets in the SAME launch (slower: signalling
+// between XCDs goes through memory) -- is in profiles/r05_halfstep_small.txt and DESIGN.md 4.17.
 #include <algorithm>
 #include <atomic>
 
