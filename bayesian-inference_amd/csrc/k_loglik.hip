@@ -322,10 +322,148 @@ __global__ __launch_bounds__(256) void loglik_groups_kernel(const double *__rest
   }
 }
 
+// ---- the observable blocks of a proposal on different waves -----------------------------------------------------------
+// The covariance is block diagonal over the OBSERVABLES of a group (ref: emulation.py:370-388), so a group's log-likelihood
+// is a sum of per-observable terms, each with its own k x k factorisation -- the serial part of the half-step.  The
+// reference's shipped configuration has 2 + 4 + 10 observables in its groups of 5 / 11 / 25 PCs: one wave per group
+// factorises ten 25 x 25 matrices in turn, 78 us per launch (golden G7, 200 walkers: 199 us per step).  Here every
+// (group, observable) pair of a proposal is a TASK, dealt to the 12 waves of the proposal's workgroup longest first; the
+// terms meet in LDS and are added in the order of the serial loop (block after block, then group after group): the same
+// bits.  12 waves: three per SIMD, 170 VGPRs each -- what the 32-PC factorisation needs without spilling.
+constexpr int LL_TASKS_MAX = 64, LL_TASK_WAVES = 12;
+struct LoglikTasks {
+  LoglikGroup g[LL_GROUPS_MAX];
+  int ng, ntask;
+  int first[LL_GROUPS_MAX + 1];              // slot of group g's block 0 in the list of terms
+  unsigned char tg[LL_TASKS_MAX], to[LL_TASKS_MAX];   // tasks in the order the waves take them: wave w has [wstart[w], wstart[w + 1])
+  unsigned char wstart[LL_TASK_WAVES + 1];
+};
+
+template <int KMAX>
+__device__ __forceinline__ double task_term(const LoglikGroup &gr, int o, int64_t b, int lane) {
+  constexpr bool PRE = KMAX <= 16;
+  const int k = gr.k;
+  // the block's own constants as "block 0" of lowrank_block_term: requested ahead of the partial sums where the registers
+  // allow (PRE), the same values either way
+  const double *G = gr.G + (int64_t)o * k * k, *g0 = gr.g0 + (int64_t)o * k, *scal = gr.scal + 2 * o;
+  double gpre[PRE ? KMAX : 1];
+  if (PRE) {
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q) gpre[q] = (q < k && lane < k) ? G[q * k + lane] : 0.0;
+  }
+  const double gl_pre = (lane < k) ? g0[lane] : 0.0;
+  const double sc0_pre = scal[0], sc1_pre = scal[1];
+  double mu, sd;
+  walker_mean_sd<(KMAX <= 16 ? 16 : 32)>(gr.mean_part, gr.vsq_part, gr.kdiag, o == 0 ? gr.mean_out : nullptr,
+                                         o == 0 ? gr.var_out : nullptr, b, gr.Bcap, k, gr.nchunk, gr.nrb, lane, mu, sd);
+  return lowrank_block_term<KMAX, PRE>(0, mu, sd, gpre, gl_pre, sc0_pre, sc1_pre, G, g0, scal, k, lane);
+}
+
+__global__ __launch_bounds__(64 * LL_TASK_WAVES) void loglik_tasks_kernel(const double *__restrict__ Xq, LoglikTasks lt,
+                                                                          double *__restrict__ out, int64_t B, int d, int accumulate,
+                                                                          AcceptArgs aa) {
+  __shared__ double s_term[LL_TASKS_MAX];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t b = blockIdx.x;
+  AcceptOperands ao;
+  if (wave == 0) ao = load_accept_operands(Xq, b, lane, aa);
+  for (int t = lt.wstart[wave]; t < lt.wstart[wave + 1]; ++t) {
+    const int g = lt.tg[t], o = lt.to[t];
+    const LoglikGroup &gr = lt.g[g];
+    bool in = true;
+    if (lane < d) in = (Xq[b * DPAD + lane] > gr.lo[lane]) && (Xq[b * DPAD + lane] < gr.hi[lane]);
+    double term = 0.0;
+    if (__all(in)) {                                         // (outside the box the group's term is -inf whatever the blocks say)
+      if (gr.k <= 4) term = task_term<4>(gr, o, b, lane);
+      else if (gr.k <= 8) term = task_term<8>(gr, o, b, lane);
+      else if (gr.k <= 12) term = task_term<12>(gr, o, b, lane);
+      else if (gr.k <= 16) term = task_term<16>(gr, o, b, lane);
+      else if (gr.k <= 20) term = task_term<20>(gr, o, b, lane);
+      else if (gr.k <= 24) term = task_term<24>(gr, o, b, lane);
+      else if (gr.k <= 28) term = task_term<28>(gr, o, b, lane);
+      else term = task_term<32>(gr, o, b, lane);
+    }
+    if (lane == 0) s_term[lt.first[g] + o] = term;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double total = 0.0;
+    for (int g = 0; g < lt.ng; ++g) {
+      const LoglikGroup &gr = lt.g[g];
+      bool in = true;
+      if (lane < d) in = (Xq[b * DPAD + lane] > gr.lo[lane]) && (Xq[b * DPAD + lane] < gr.hi[lane]);
+      double lp = -INFINITY;
+      if (__all(in)) {
+        lp = 0.0;
+        for (int o = lt.first[g]; o < lt.first[g + 1]; ++o) lp += s_term[o];      // walker_loglik_lowrank's loop
+      }
+      total = (g == 0) ? lp : lp + total;                      // loglik_groups_kernel's sum (a launch per group: total_g + out[b])
+    }
+    finish_walker(total, out, b, d, lane, accumulate, aa, ao);
+  }
+}
+
+// GPEMU_ERR_UNSUPPORTED (nothing launched, no error set) where it does not apply: no group with more than one observable
+// block, more than 64 blocks in all, more than 32 PCs in a group, stacked chains; GPEMU_NO_LOGLIK_TASKS (tests; read per call)
+int launch_loglik_tasks(gpemu_model *const *ms, int ng, int64_t B, const double *dXq, double *dout, int accumulate,
+                        hipStream_t st, const AcceptArgs *aa) {
+  if (getenv("GPEMU_NO_LOGLIK_TASKS") != nullptr || ng < 1 || ng > LL_GROUPS_MAX || B < 1) return GPEMU_ERR_UNSUPPORTED;
+  if (aa && aa->chain_per != 0) return GPEMU_ERR_UNSUPPORTED;
+  int ntask = 0;
+  for (int g = 0; g < ng; ++g) {
+    if (ms[g]->k > 32 || ms[g]->nblk < 1) return GPEMU_ERR_UNSUPPORTED;
+    ntask += (int)ms[g]->nblk;
+  }
+  if (ntask <= ng || ntask > LL_TASKS_MAX) return GPEMU_ERR_UNSUPPORTED;
+  LoglikTasks lt;
+  memset(&lt, 0, sizeof(lt));
+  lt.ng = ng;
+  lt.ntask = ntask;
+  struct T { double cost; int g, o; };
+  std::vector<T> tasks;
+  for (int g = 0; g < ng; ++g) {
+    const gpemu_model *m = ms[g];
+    const Workspace &w = m->ws;
+    lt.g[g] = LoglikGroup{m->lo, m->hi, w.mean_part, w.vsq_part, m->kdiag, m->G, m->g0, m->scal, w.mean, w.var, w.Bcap,
+                          (int)m->k, w.cur_nchunk, w.cur_nrb, (int)m->nblk};
+    lt.first[g + 1] = lt.first[g] + (int)m->nblk;
+    const double kk = (double)((m->k + 3) / 4 * 4);
+    for (int o = 0; o < (int)m->nblk; ++o) tasks.push_back(T{kk * kk + 8.0 * kk + 40.0, g, o});   // (factorisation + row loads + fixed part)
+  }
+  // longest first, each to the wave with the least so far
+  std::stable_sort(tasks.begin(), tasks.end(), [](const T &a, const T &b) { return a.cost > b.cost; });
+  const int nw = std::min(LL_TASK_WAVES, ntask);
+  std::vector<std::vector<T>> per(LL_TASK_WAVES);
+  std::vector<double> load(LL_TASK_WAVES, 0.0);
+  for (const T &t : tasks) {
+    int best = 0;
+    for (int w2 = 1; w2 < nw; ++w2)
+      if (load[w2] < load[best]) best = w2;
+    per[best].push_back(t);
+    load[best] += t.cost;
+  }
+  int n = 0;
+  for (int w2 = 0; w2 < LL_TASK_WAVES; ++w2) {
+    lt.wstart[w2] = (unsigned char)n;
+    for (const T &t : per[w2]) { lt.tg[n] = (unsigned char)t.g; lt.to[n] = (unsigned char)t.o; ++n; }
+  }
+  lt.wstart[LL_TASK_WAVES] = (unsigned char)n;
+  const AcceptArgs a = aa ? *aa : AcceptArgs();
+  hipLaunchKernelGGL(loglik_tasks_kernel, dim3((unsigned)B), dim3(64 * LL_TASK_WAVES), 0, st, dXq, lt, dout, B, (int)ms[0]->d,
+                     accumulate, a);
+  GP_HIP(hipGetLastError());
+  return GPEMU_OK;
+}
+
 // the likelihoods of ng groups (k <= 32 each, one chain) for the B proposals whose partial sums their cross-kernel and
 // triangular GEMM launches have just written; `aa` finishes the stretch move
 int launch_loglik_groups(gpemu_model *const *ms, int ng, int64_t B, const double *dXq, double *dout, int accumulate,
                          hipStream_t st, const AcceptArgs *aa) {
+  {
+    const int rc = launch_loglik_tasks(ms, ng, B, dXq, dout, accumulate, st, aa);      // observable blocks on different waves
+    if (rc != GPEMU_ERR_UNSUPPORTED) return rc;
+  }
   LoglikGroups lg;
   lg.ng = ng;
   for (int g = 0; g < ng; ++g) {
@@ -344,6 +482,11 @@ int launch_loglik_groups(gpemu_model *const *ms, int ng, int64_t B, const double
 
 int launch_loglik_lowrank(gpemu_model *m, int64_t B, const double *dXq, double *dout, int accumulate,
                           hipStream_t st, const AcceptArgs *aa) {
+  if (m->nblk > 1) {
+    gpemu_model *one[1] = {m};
+    const int rc = launch_loglik_tasks(one, 1, B, dXq, dout, accumulate, st, aa);      // observable blocks on different waves
+    if (rc != GPEMU_ERR_UNSUPPORTED) return rc;
+  }
   const Workspace &w = m->ws;
   const int k = (int)m->k;
   AcceptArgs a = aa ? *aa : AcceptArgs();

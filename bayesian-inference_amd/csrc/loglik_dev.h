@@ -124,6 +124,60 @@ __device__ __forceinline__ double sum_first_lanes(double v) {
 // so the factorisation is branch-free, row `lane` lives in registers, every cross-lane operand is a v_readlane of a
 // compile-time lane.  The padding adds exact zeros and pivots of exactly 1: the value does not depend on KMAX.
 // -inf outside the box.
+// the term of observable block o (see walker_loglik_lowrank below, which adds the blocks' terms in turn)
+template <int KMAX, bool PRE = true>
+__device__ __forceinline__ double lowrank_block_term(int o, double mu, double sd, const double *gpre, double gl_pre, double sc0_pre,
+                                                     double sc1_pre, const double *__restrict__ G, const double *__restrict__ g0,
+                                                     const double *__restrict__ scal, int k, int lane) {
+  const double *Go = G + (int64_t)o * k * k;
+  // row `lane` of G_o (symmetric: read column-wise so that the wave's loads coalesce)
+  double row[KMAX];
+  double h = 0.0;
+  // KMAX > 16: every lane loads from a clamped, valid position and the select follows -- scalar base per q plus ONE
+  // vector offset, where the predicated form keeps an address per q in vector registers (2 KMAX of them)
+  const double *Gl = Go + ((lane < k) ? lane : k - 1);
+  // ... and the lane index is made opaque per block, or the KMAX unit-matrix terms (lane == q ? 1 : 0) are kept in
+  // 2 KMAX registers across the loop over the blocks (KMAX = 32: 262 -> 200 -> 136 VGPRs)
+  int lane_q = lane;
+  if (!PRE) asm volatile("" : "+v"(lane_q));
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q) {
+    double gq;
+    if (PRE) gq = (o == 0) ? gpre[q] : ((q < k && lane < k) ? Go[q * k + lane] : 0.0);
+    else gq = (q < k && lane < k) ? Gl[((q < k) ? q : k - 1) * k] : 0.0;
+    h = fma(gq, readlane_f64(mu, q), h);
+    row[q] = ((lane_q == q) ? 1.0 : 0.0) + sd * gq * readlane_f64(sd, q);
+  }
+  const double gl = (o == 0) ? gl_pre : ((lane < k) ? g0[(int64_t)o * k + lane] : 0.0);
+  const double sc0 = (o == 0) ? sc0_pre : scal[2 * o], sc1 = (o == 0) ? sc1_pre : scal[2 * o + 1];
+  h += gl;
+  const double quadA = sum_first_lanes<KMAX>((lane < k) ? mu * (h + gl) : 0.0) + sc0;
+  // right-looking Cholesky; y = L_M^-1 (sd o h) by forward substitution alongside.  One reciprocal
+  // square root per pivot on the critical path; the logarithms of the pivots are taken after the
+  // loop, one per lane in parallel.  Entries above the diagonal (lane < column) are never read.
+  double y = (lane < k) ? sd * h : 0.0;
+  double mypiv2 = 1.0;
+#pragma unroll
+  for (int jx = 0; jx < KMAX; ++jx) {
+    const double piv2 = readlane_f64(row[jx], jx);
+    // 1/sqrt: hardware estimate + two Newton steps (a third of the IEEE sqrt-and-divide sequence, which
+    // sits on the serial path of every pivot); relative error ~1e-16
+    double rinv = __builtin_amdgcn_rsq(piv2);
+    rinv = fma(0.5 * rinv, fma(-piv2 * rinv, rinv, 1.0), rinv);
+    rinv = fma(0.5 * rinv, fma(-piv2 * rinv, rinv, 1.0), rinv);
+    if (lane == jx) mypiv2 = piv2;
+    const double lj = row[jx] * rinv;                             // column jx of L (lanes >= jx)
+    const double zj = readlane_f64(y, jx) * rinv;
+    y = (lane == jx) ? zj : ((lane > jx) ? fma(-lj, zj, y) : y);
+#pragma unroll
+    for (int c = jx + 1; c < KMAX; ++c) row[c] = fma(-lj, readlane_f64(lj, c), row[c]);
+  }
+  const double logdiag = 0.5 * log(mypiv2);                       // lanes >= k hold pivot 1
+  const double ww = sum_first_lanes<KMAX>(y * y);
+  const double ldsum = sum_first_lanes<KMAX>(logdiag);
+  return -0.5 * (quadA - ww) - 0.5 * (sc1 + 2.0 * ldsum);
+}
+
 template <int KMAX, bool PRE = true>
 __device__ __forceinline__ double walker_loglik_lowrank(bool inside, double mu, double sd, const double *gpre,
                                                         double gl_pre, double sc0_pre, double sc1_pre,
@@ -132,55 +186,8 @@ __device__ __forceinline__ double walker_loglik_lowrank(bool inside, double mu, 
   double total = -INFINITY;
   if (inside) {
     total = 0.0;
-    for (int o = 0; o < nblk; ++o) {
-      const double *Go = G + (int64_t)o * k * k;
-      // row `lane` of G_o (symmetric: read column-wise so that the wave's loads coalesce)
-      double row[KMAX];
-      double h = 0.0;
-      // KMAX > 16: every lane loads from a clamped, valid position and the select follows -- scalar base per q plus ONE
-      // vector offset, where the predicated form keeps an address per q in vector registers (2 KMAX of them)
-      const double *Gl = Go + ((lane < k) ? lane : k - 1);
-      // ... and the lane index is made opaque per block, or the KMAX unit-matrix terms (lane == q ? 1 : 0) are kept in
-      // 2 KMAX registers across the loop over the blocks (KMAX = 32: 262 -> 200 -> 136 VGPRs)
-      int lane_q = lane;
-      if (!PRE) asm volatile("" : "+v"(lane_q));
-#pragma unroll
-      for (int q = 0; q < KMAX; ++q) {
-        double gq;
-        if (PRE) gq = (o == 0) ? gpre[q] : ((q < k && lane < k) ? Go[q * k + lane] : 0.0);
-        else gq = (q < k && lane < k) ? Gl[((q < k) ? q : k - 1) * k] : 0.0;
-        h = fma(gq, readlane_f64(mu, q), h);
-        row[q] = ((lane_q == q) ? 1.0 : 0.0) + sd * gq * readlane_f64(sd, q);
-      }
-      const double gl = (o == 0) ? gl_pre : ((lane < k) ? g0[(int64_t)o * k + lane] : 0.0);
-      const double sc0 = (o == 0) ? sc0_pre : scal[2 * o], sc1 = (o == 0) ? sc1_pre : scal[2 * o + 1];
-      h += gl;
-      const double quadA = sum_first_lanes<KMAX>((lane < k) ? mu * (h + gl) : 0.0) + sc0;
-      // right-looking Cholesky; y = L_M^-1 (sd o h) by forward substitution alongside.  One reciprocal
-      // square root per pivot on the critical path; the logarithms of the pivots are taken after the
-      // loop, one per lane in parallel.  Entries above the diagonal (lane < column) are never read.
-      double y = (lane < k) ? sd * h : 0.0;
-      double mypiv2 = 1.0;
-#pragma unroll
-      for (int jx = 0; jx < KMAX; ++jx) {
-        const double piv2 = readlane_f64(row[jx], jx);
-        // 1/sqrt: hardware estimate + two Newton steps (a third of the IEEE sqrt-and-divide sequence, which
-        // sits on the serial path of every pivot); relative error ~1e-16
-        double rinv = __builtin_amdgcn_rsq(piv2);
-        rinv = fma(0.5 * rinv, fma(-piv2 * rinv, rinv, 1.0), rinv);
-        rinv = fma(0.5 * rinv, fma(-piv2 * rinv, rinv, 1.0), rinv);
-        if (lane == jx) mypiv2 = piv2;
-        const double lj = row[jx] * rinv;                             // column jx of L (lanes >= jx)
-        const double zj = readlane_f64(y, jx) * rinv;
-        y = (lane == jx) ? zj : ((lane > jx) ? fma(-lj, zj, y) : y);
-#pragma unroll
-        for (int c = jx + 1; c < KMAX; ++c) row[c] = fma(-lj, readlane_f64(lj, c), row[c]);
-      }
-      const double logdiag = 0.5 * log(mypiv2);                       // lanes >= k hold pivot 1
-      const double ww = sum_first_lanes<KMAX>(y * y);
-      const double ldsum = sum_first_lanes<KMAX>(logdiag);
-      total += -0.5 * (quadA - ww) - 0.5 * (sc1 + 2.0 * ldsum);
-    }
+    for (int o = 0; o < nblk; ++o)
+      total += lowrank_block_term<KMAX, PRE>(o, mu, sd, gpre, gl_pre, sc0_pre, sc1_pre, G, g0, scal, k, lane);
   }
   return total;
 }

@@ -70,21 +70,27 @@ def build_workload(device=0, n_design=None, n_obs=None, n_pc=None, seed=0, kerne
                 cun=cun)
 
 
-def measure_shipped_shape(device=0, n_walkers=200, steps=3000):
+def measure_shipped_shape(device=0, n_walkers=200, steps=3000, observable_blocks=False):
     """One chain at the size the reference ships (ref: config/jet_substructure.yaml: ~150 design points, d = 6, 200
     walkers, three emulation groups of 5 / 11 / 25 PCs, block-diagonal likelihood over the groups): the regime where a
-    stretch-move step is a handful of ~10 us launches, nothing like C3.  Models built by the product's own device fit."""
+    stretch-move step is a handful of ~10 us launches, nothing like C3.  Models built by the product's own device fit.
+    observable_blocks: the covariance of a group block diagonal over its OBSERVABLES as well (ref: emulation.py:370-388),
+    2 / 4 / 10 of them as in the shipped configuration (golden G7): a k x k factorisation per observable and proposal."""
     from gpemu import synthetic
     from gpemu.model import DeviceModel
     from gpemu.sampler import DeviceSampler
     dms = []
+    n_blocks = {60: 2, 120: 4, 215: 10}
     for gi, (n_obs, n_pc) in enumerate([(60, 5), (120, 11), (215, 25)]):
         wl = build_workload(device, 150, n_obs, n_pc, seed=gi)
         prob = wl["prob"]
         dmg = DeviceModel(X_train=prob["design"], ls=wl["ls"], alpha=wl["alpha"], L=wl["L"], components=wl["components"],
                           scaler_mean=wl["mean"], scaler_scale=wl["scale"], kernel_kind=0, noise=wl["noise"],
                           cov_unexplained=wl["cun"], device=device)
-        dmg.likelihood_setup(prob["y_exp"], prob["y_err"], prob["lo"], prob["hi"], 1.0)
+        blocks = None
+        if observable_blocks:
+            blocks = [int(round(i * n_obs / n_blocks[n_obs])) for i in range(n_blocks[n_obs] + 1)]
+        dmg.likelihood_setup(prob["y_exp"], prob["y_err"], prob["lo"], prob["hi"], 1.0, block_start=blocks)
         dms.append(dmg)
     ds = DeviceSampler(dms, n_walkers, seed=11)
     ds.set_state(synthetic.make_walkers(n_walkers, seed=3))
@@ -97,7 +103,8 @@ def measure_shipped_shape(device=0, n_walkers=200, steps=3000):
     ds.close()
     for dmg in dms:
         dmg.close()
-    return {"workload": f"shipped shape: N_design=150, groups of 5 + 11 + 25 PCs (60 + 120 + 215 observables), {n_walkers} walkers",
+    return {"workload": f"shipped shape: N_design=150, groups of 5 + 11 + 25 PCs (60 + 120 + 215 observables"
+                        + (" in 2 + 4 + 10 observable blocks" if observable_blocks else "") + f"), {n_walkers} walkers",
             "us_per_step": dt / steps * 1e6, "evals_per_s": n_walkers * steps / dt, "steps": steps}
 
 
@@ -694,8 +701,9 @@ def main():
             fit_c3 = fit_c3 or {"error": repr(e)}
         try:
             shipped = measure_shipped_shape(dev_index)
+            shipped["with_observable_blocks"] = measure_shipped_shape(dev_index, steps=2000, observable_blocks=True)
         except Exception as e:
-            shipped = {"error": repr(e)}
+            shipped = shipped or {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

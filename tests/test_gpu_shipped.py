@@ -184,6 +184,53 @@ def test_shipped_device_sampler_equals_oracle_chain(W):
         dm.close()
 
 
+def test_observable_blocks_on_different_waves_have_the_bits_of_the_serial_loop(monkeypatch):
+    """The covariance is block diagonal over the observables of a group (ref: emulation.py:370-388): 2 + 4 + 10 blocks in the
+    shipped groups.  `loglik_tasks_kernel` factorises the blocks of a proposal on different waves and adds the terms in the
+    order of the serial loop; with GPEMU_NO_LOGLIK_TASKS the serial kernels: the same chain bit for bit, through the small-
+    emulator launch and the general one, for the three groups in one sampler and for one group alone (the single-group
+    kernel), and the same batched log-posterior."""
+    from gpemu import synthetic
+    from gpemu.sampler import DeviceSampler
+    g = GU.load("g7_shipped_config")
+    names, mapping, block_start, cols = GU.g7_groups(g)
+    models, dms = _device_models(g, names, block_start, cols)
+    monkeypatch.setenv("GPEMU_HALFSTEP_MIN_PAIRS", "0")
+    for sel, W in ((slice(0, 3), 200), (slice(2, 3), 37), (slice(0, 2), 24)):
+        X0 = synthetic.make_walkers(W, seed=11, lo=g["design"].min(0), hi=g["design"].max(0))
+        out = {}
+        for tasks in (True, False):
+            for general in (False, True):
+                monkeypatch.delenv("GPEMU_NO_LOGLIK_TASKS", raising=False)
+                monkeypatch.delenv("GPEMU_NO_HALFSTEP", raising=False)
+                if not tasks:
+                    monkeypatch.setenv("GPEMU_NO_LOGLIK_TASKS", "1")
+                if general:
+                    monkeypatch.setenv("GPEMU_NO_HALFSTEP", "1")
+                ds = DeviceSampler(dms[sel], W, seed=5)
+                ds.set_state(X0)
+                ds.run(5)
+                out[(tasks, general)] = ds.get_chain() + (ds.counts()[0],)
+                ds.close()
+        monkeypatch.delenv("GPEMU_NO_LOGLIK_TASKS", raising=False)
+        monkeypatch.delenv("GPEMU_NO_HALFSTEP", raising=False)
+        ref = out[(False, True)]
+        assert ref[2].sum() > 0
+        for key, val in out.items():
+            for a, b in zip(val, ref):
+                np.testing.assert_array_equal(a, b, err_msg=str(key))
+    # batched log-posterior of one group (gpemu_logpost -> the single-group likelihood launch)
+    Xq = synthetic.make_walkers(50, seed=4, lo=g["design"].min(0), hi=g["design"].max(0))
+    lp_tasks = dms[2].logpost(Xq)
+    monkeypatch.setenv("GPEMU_NO_LOGLIK_TASKS", "1")
+    lp_serial = dms[2].logpost(Xq)
+    monkeypatch.delenv("GPEMU_NO_LOGLIK_TASKS", raising=False)
+    np.testing.assert_array_equal(lp_tasks, lp_serial)
+    assert np.isfinite(lp_tasks).any()
+    for dm in dms:
+        dm.close()
+
+
 def test_shipped_stacked_closure_chains_equal_separate_chains():
     """Closure chains on the shipped shape (ref: steer_analysis.py:168-183): C chains stacked in one multi-chain sampler
     over the three groups, every chain on its own pseudo-data vector, are the chains C separate samplers produce."""
