@@ -398,6 +398,8 @@ int gpemu_model_destroy(gpemu_model *m) {
   hipFree(m->blk_start); hipFree(m->blk_of);
   for (const gpemu_model::SchedEntry &en : m->sched_cache) { hipFree(en.items); hipFree(en.cnt); }
   for (const gpemu_model::SchedEntry &en : m->sm_cache) { hipFree(en.items); hipFree(en.cnt); }
+  (void)hipFree(m->lik_terms);
+  (void)hipFree(m->lik_tickets);
   free_workspace(m->ws);
   for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
   if (m->stream) hipStreamDestroy(m->stream);

@@ -79,6 +79,11 @@ struct gpemu_model {
   // sampler blocks), and a launch in flight keeps reading the one it was given -- so none is freed before the model is
   // (a few KB each; bounded: the oldest goes, after a stream sync, beyond 16)
   std::vector<SchedEntry> sm_cache;
+  // likelihood with the observable blocks on different workgroups (k_loglik.hip: loglik_tasks_kernel): the terms' way
+  // to the workgroup that adds them, and the tickets that tell which one that is
+  double *lik_terms = nullptr;      // [lik_terms_cap][64]
+  unsigned *lik_tickets = nullptr;  // [lik_terms_cap], zero between launches
+  int64_t lik_terms_cap = 0;
   int kernel_kind = 0;
   double nu = 0;
   int has_const = 0, has_noise = 0;

@@ -327,16 +327,21 @@ __global__ __launch_bounds__(256) void loglik_groups_kernel(const double *__rest
 // is a sum of per-observable terms, each with its own k x k factorisation -- the serial part of the half-step.  The
 // reference's shipped configuration has 2 + 4 + 10 observables in its groups of 5 / 11 / 25 PCs: one wave per group
 // factorises ten 25 x 25 matrices in turn, 78 us per launch (golden G7, 200 walkers: 199 us per step).  Here every
-// (group, observable) pair of a proposal is a TASK, dealt to the 12 waves of the proposal's workgroup longest first; the
-// terms meet in LDS and are added in the order of the serial loop (block after block, then group after group): the same
-// bits.  12 waves: three per SIMD, 170 VGPRs each -- what the 32-PC factorisation needs without spilling.
-constexpr int LL_TASKS_MAX = 64, LL_TASK_WAVES = 12;
+// (group, observable) pair of a proposal is a TASK on a wave of its own: four tasks per workgroup (one wave per SIMD: twelve
+// on one CU were bound by that CU's vector ALUs, 24.8 us per launch), `nwg` workgroups per proposal, dealt longest first.
+// A workgroup leaves its terms at the device's coherence point and takes a ticket; the LAST one to arrive for a proposal
+// (nobody waits for anybody) reads them all, adds them in the order of the serial loop -- block after block, then group
+// after group: the same bits -- and finishes the stretch move.
+constexpr int LL_TASKS_MAX = 64, LL_TASK_WAVES = 4;
 struct LoglikTasks {
   LoglikGroup g[LL_GROUPS_MAX];
-  int ng, ntask;
+  int ng, ntask, nwg;
   int first[LL_GROUPS_MAX + 1];              // slot of group g's block 0 in the list of terms
-  unsigned char tg[LL_TASKS_MAX], to[LL_TASKS_MAX];   // tasks in the order the waves take them: wave w has [wstart[w], wstart[w + 1])
-  unsigned char wstart[LL_TASK_WAVES + 1];
+  // tasks in the order the waves take them: wave w of workgroup j has [wstart[4 j + w], wstart[4 j + w + 1])
+  unsigned char tg[LL_TASKS_MAX], to[LL_TASKS_MAX];
+  unsigned char wstart[LL_TASKS_MAX + 1];
+  double *terms;                             // [B][ntask] the proposals' terms on their way to the last workgroup
+  unsigned *tickets;                         // [B] workgroups of the proposal that have delivered (back to 0 by the last)
 };
 
 template <int KMAX>
@@ -359,16 +364,22 @@ __device__ __forceinline__ double task_term(const LoglikGroup &gr, int o, int64_
   return lowrank_block_term<KMAX, PRE>(0, mu, sd, gpre, gl_pre, sc0_pre, sc1_pre, G, g0, scal, k, lane);
 }
 
+// grid: workgroup j of proposal b at index j B + b (the workgroups with the longest tasks first)
 __global__ __launch_bounds__(64 * LL_TASK_WAVES) void loglik_tasks_kernel(const double *__restrict__ Xq, LoglikTasks lt,
                                                                           double *__restrict__ out, int64_t B, int d, int accumulate,
                                                                           AcceptArgs aa) {
   __shared__ double s_term[LL_TASKS_MAX];
+  __shared__ unsigned s_ticket;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t b = blockIdx.x;
+  const int64_t b = (int64_t)blockIdx.x % B;
+  const int j = (int)((int64_t)blockIdx.x / B);
+  // (every workgroup asks for the accept step's operands at once -- a dependent index -> state chain: whichever turns out
+  // to be the last has them by then)
   AcceptOperands ao;
   if (wave == 0) ao = load_accept_operands(Xq, b, lane, aa);
-  for (int t = lt.wstart[wave]; t < lt.wstart[wave + 1]; ++t) {
+  const int slot = j * LL_TASK_WAVES + wave;
+  for (int t = lt.wstart[slot]; t < lt.wstart[slot + 1]; ++t) {
     const int g = lt.tg[t], o = lt.to[t];
     const LoglikGroup &gr = lt.g[g];
     bool in = true;
@@ -384,7 +395,25 @@ __global__ __launch_bounds__(64 * LL_TASK_WAVES) void loglik_tasks_kernel(const 
       else if (gr.k <= 28) term = task_term<28>(gr, o, b, lane);
       else term = task_term<32>(gr, o, b, lane);
     }
-    if (lane == 0) s_term[lt.first[g] + o] = term;
+    if (lane == 0) {
+      s_term[lt.first[g] + o] = term;
+      // straight to the device's coherence point: the workgroup that reads it may run on another XCD, whose L2 may still
+      // hold the half-step before's value of this address
+      if (lt.nwg > 1) __hip_atomic_store(lt.terms + b * lt.ntask + lt.first[g] + o, term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (lt.nwg > 1) {
+    // the stores are acknowledged (s_waitcnt), the waves have met: one relaxed increment delivers them.  (No release /
+    // acquire pair at device scope: it writes back / invalidates an XCD's whole L2, profiles/r05_halfstep_small.txt.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(lt.tickets + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != (unsigned)(lt.nwg - 1)) return;          // not the last: done (whole workgroup)
+    if (wave == 0) {
+      if (lane == 0) __hip_atomic_store(lt.tickets + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // for the next launch
+      if (lane < lt.ntask) s_term[lane] = __hip_atomic_load(lt.terms + b * lt.ntask + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   __syncthreads();
   if (wave == 0) {
@@ -416,10 +445,28 @@ int launch_loglik_tasks(gpemu_model *const *ms, int ng, int64_t B, const double 
     ntask += (int)ms[g]->nblk;
   }
   if (ntask <= ng || ntask > LL_TASKS_MAX) return GPEMU_ERR_UNSUPPORTED;
+  gpemu_model *m0 = ms[0];
   LoglikTasks lt;
   memset(&lt, 0, sizeof(lt));
   lt.ng = ng;
   lt.ntask = ntask;
+  lt.nwg = (ntask + LL_TASK_WAVES - 1) / LL_TASK_WAVES;
+  if (lt.nwg > 1) {
+    // the terms' way to the last workgroup: per model (the first group's), grown with the batch
+    if (m0->lik_terms_cap < B) {
+      GP_HIP(hipStreamSynchronize(st));
+      (void)hipFree(m0->lik_terms);
+      (void)hipFree(m0->lik_tickets);
+      m0->lik_terms = nullptr; m0->lik_tickets = nullptr; m0->lik_terms_cap = 0;
+      const int64_t cap = round_up(B, 128);
+      GP_HIP(hipMalloc((void **)&m0->lik_terms, sizeof(double) * (size_t)cap * LL_TASKS_MAX));
+      GP_HIP(hipMalloc((void **)&m0->lik_tickets, sizeof(unsigned) * (size_t)cap));
+      GP_HIP(hipMemsetAsync(m0->lik_tickets, 0, sizeof(unsigned) * (size_t)cap, st));
+      m0->lik_terms_cap = cap;
+    }
+    lt.terms = m0->lik_terms;
+    lt.tickets = m0->lik_tickets;
+  }
   struct T { double cost; int g, o; };
   std::vector<T> tasks;
   for (int g = 0; g < ng; ++g) {
@@ -431,27 +478,27 @@ int launch_loglik_tasks(gpemu_model *const *ms, int ng, int64_t B, const double 
     const double kk = (double)((m->k + 3) / 4 * 4);
     for (int o = 0; o < (int)m->nblk; ++o) tasks.push_back(T{kk * kk + 8.0 * kk + 40.0, g, o});   // (factorisation + row loads + fixed part)
   }
-  // longest first, each to the wave with the least so far
+  // longest first, each to the wave with the least so far (waves of the first workgroups first: they are dispatched first)
   std::stable_sort(tasks.begin(), tasks.end(), [](const T &a, const T &b) { return a.cost > b.cost; });
-  const int nw = std::min(LL_TASK_WAVES, ntask);
-  std::vector<std::vector<T>> per(LL_TASK_WAVES);
-  std::vector<double> load(LL_TASK_WAVES, 0.0);
+  const int nslots = lt.nwg * LL_TASK_WAVES;
+  std::vector<std::vector<T>> per(nslots);
+  std::vector<double> load(nslots, 0.0);
   for (const T &t : tasks) {
     int best = 0;
-    for (int w2 = 1; w2 < nw; ++w2)
+    for (int w2 = 1; w2 < nslots; ++w2)
       if (load[w2] < load[best]) best = w2;
     per[best].push_back(t);
     load[best] += t.cost;
   }
   int n = 0;
-  for (int w2 = 0; w2 < LL_TASK_WAVES; ++w2) {
+  for (int w2 = 0; w2 < nslots; ++w2) {
     lt.wstart[w2] = (unsigned char)n;
     for (const T &t : per[w2]) { lt.tg[n] = (unsigned char)t.g; lt.to[n] = (unsigned char)t.o; ++n; }
   }
-  lt.wstart[LL_TASK_WAVES] = (unsigned char)n;
+  for (int w2 = nslots; w2 <= LL_TASKS_MAX; ++w2) lt.wstart[w2] = (unsigned char)n;
   const AcceptArgs a = aa ? *aa : AcceptArgs();
-  hipLaunchKernelGGL(loglik_tasks_kernel, dim3((unsigned)B), dim3(64 * LL_TASK_WAVES), 0, st, dXq, lt, dout, B, (int)ms[0]->d,
-                     accumulate, a);
+  hipLaunchKernelGGL(loglik_tasks_kernel, dim3((unsigned)(B * lt.nwg)), dim3(64 * LL_TASK_WAVES), 0, st, dXq, lt, dout, B,
+                     (int)ms[0]->d, accumulate, a);
   GP_HIP(hipGetLastError());
   return GPEMU_OK;
 }
