@@ -451,6 +451,9 @@ int launch_loglik_tasks(gpemu_model *const *ms, int ng, int64_t B, const double 
   lt.ng = ng;
   lt.ntask = ntask;
   lt.nwg = (ntask + LL_TASK_WAVES - 1) / LL_TASK_WAVES;
+  // several workgroups per proposal pay ~3.5 us for the last one's detour through memory: worth it while the proposals
+  // alone leave most of the chip idle (the shipped ensembles: 50 - 100 per half-step), not for a large batch
+  if (lt.nwg > 1 && B > 256) return GPEMU_ERR_UNSUPPORTED;
   if (lt.nwg > 1) {
     // the terms' way to the last workgroup: per model (the first group's), grown with the batch
     if (m0->lik_terms_cap < B) {
