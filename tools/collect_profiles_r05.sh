@@ -35,7 +35,9 @@ python3 $R/tools/time_lml_batch.py 5000 8 >> $OUT/fit_batch.txt 2>&1
 ( cd $R/bayesian-inference_amd/csrc/tools && ./kstar_probe 1000 512 && ./kstar_probe 1000 64 && ./kstar_probe 1000 1024 10 7 2 ) > $OUT/kstar_probe.txt 2>&1
 python3 $R/tools/time_exact.py > $OUT/time_exact.txt 2>&1
 python3 $R/tools/run_dropin_c3.py 50 1000 10000 > $OUT/dropin_c3_end_to_end.txt 2>&1
-( python3 $R/tools/time_shipped_chain.py groups 150 0 0 200 3000; python3 $R/tools/time_shipped_chain.py groups 150 0 0 100 3000; GPEMU_NO_GROUP_MERGE=1 python3 $R/tools/time_shipped_chain.py groups 150 0 0 200 3000; python3 $R/tools/time_shipped_chain.py 150 215 25 200 3000; python3 $R/tools/time_shipped_chain.py 150 215 11 200 3000 ) > $OUT/shipped_shape.txt 2>&1
+( python3 $R/tools/time_shipped_chain.py groups 150 0 0 200 3000; python3 $R/tools/time_shipped_chain.py groups 150 0 0 100 3000; GPEMU_NO_HALFSTEP=1 python3 $R/tools/time_shipped_chain.py groups 150 0 0 200 3000; GPEMU_NO_GROUP_MERGE=1 python3 $R/tools/time_shipped_chain.py groups 150 0 0 200 3000; python3 $R/tools/time_shipped_chain.py 150 215 25 200 3000; python3 $R/tools/time_shipped_chain.py 150 215 11 200 3000 ) 2>&1 | grep -v amdgpu.ids > $OUT/shipped_shape.txt
+( python3 $R/tools/time_g7_chain.py 200 2000; python3 $R/tools/time_g7_chain.py 100 2000; GPEMU_NO_LOGLIK_TASKS=1 python3 $R/tools/time_g7_chain.py 200 2000; GPEMU_NO_LOGLIK_TASKS=1 GPEMU_NO_HALFSTEP=1 python3 $R/tools/time_g7_chain.py 200 2000 ) 2>&1 | grep -v amdgpu.ids > $OUT/g7_chain.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_g7 -- python3 $R/tools/time_g7_chain.py 200 2000 > $OUT/stats_g7.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_shipped -- python3 $R/tools/time_shipped_chain.py groups 150 0 0 200 2000 > $OUT/stats_shipped.log 2>&1
 python3 $R/bench.py --steps 10000 --warmup 20 --no-cpu-baseline --no-fit --no-predict 2>/dev/null | grep '^{' > $OUT/bench_10k_steps.json
 ( cd $R/bayesian-inference_amd/csrc && make tools > /dev/null 2>&1; ./tools/share_probe 8 ) > $OUT/share_probe.txt 2>&1

@@ -27,6 +27,7 @@ for name, out in (("stats_bench/**/*kernel_stats.csv", f"{prefix}_bench_kernel_s
                   ("stats_pca/**/*kernel_stats.csv", f"{prefix}_pca_c3_kernel_stats.csv"),
                   ("stats_predict/**/*kernel_stats.csv", f"{prefix}_predict_kernel_stats.csv"),
                   ("stats_shipped/**/*kernel_stats.csv", f"{prefix}_shipped_shape_kernel_stats.csv"),
+                  ("stats_g7/**/*kernel_stats.csv", f"{prefix}_g7_chain_kernel_stats.csv"),
                   ("stats_fit5000/**/*kernel_stats.csv", f"{prefix}_fit_n5000_kernel_stats.csv")):
     f = first(name)
     if f:
@@ -38,6 +39,7 @@ for name, out in (("bench_default.json", f"{prefix}_bench_default.json"), ("emul
                   ("fit_batch.txt", f"{prefix}_fit_batch.txt"), ("fit_probes.txt", f"{prefix}_fit_probes.txt"),
                   ("kstar_probe.txt", f"{prefix}_kstar_probe.txt"), ("time_exact.txt", f"{prefix}_time_exact.txt"),
                   ("shipped_shape.txt", f"{prefix}_shipped_shape_run.txt"),
+                  ("g7_chain.txt", f"{prefix}_g7_chain_run.txt"),
                   ("dropin_c3_end_to_end.txt", f"{prefix}_dropin_c3_end_to_end.txt")):
     f = os.path.join(src, name)
     if os.path.exists(f):
