@@ -135,8 +135,17 @@ int logpost_padded(gpemu_model *m, int64_t B, double *dXq, double *dout, int acc
                    hipStream_t st, const AcceptArgs *aa, const ProposeArgs *pa) {
   if (!m->lik_ready) { set_error("gpemu_likelihood_setup has not been called"); return GPEMU_ERR_STATE; }
   int rc = ensure_workspace(m, B);
-  if (rc == GPEMU_OK) rc = launch_kstar(m, B, dXq, st, pa);
-  if (rc == GPEMU_OK) rc = launch_trmm_vsq(m, B, st);
+  if (rc != GPEMU_OK) return rc;
+  // small emulators: cross-kernel and GEMM in one launch (k_halfstep.hip; the same bits), else the two general launches
+  rc = GPEMU_ERR_UNSUPPORTED;
+  if (getenv("GPEMU_NO_HALFSTEP") == nullptr && getenv("GPEMU_NO_GROUP_MERGE") == nullptr && !(aa && aa->chain_per != 0)) {
+    gpemu_model *one[1] = {m};
+    rc = launch_halfstep_small(one, 1, B, dXq, st, pa);
+  }
+  if (rc == GPEMU_ERR_UNSUPPORTED) {
+    rc = launch_kstar(m, B, dXq, st, pa);
+    if (rc == GPEMU_OK) rc = launch_trmm_vsq(m, B, st);
+  }
   if (rc != GPEMU_OK) return rc;
   return launch_loglik_lowrank(m, B, dXq, dout, accumulate, st, aa);
 }
@@ -448,10 +457,17 @@ int gpemu_model_sync(gpemu_model *m) {
 // ---- GP predict --------------------------------------------------------------------------------
 constexpr int64_t MAX_CHUNK = 2048;   // rows per pass of the predict pipeline (bounds the K_* workspace)
 
-static int gp_predict_core(gpemu_model *m, int64_t B, const double *dX, hipStream_t st) {
+// small_ok: the caller sums the partials in the likelihood's order (walker_mean_sd), which is the order in which the
+// one-launch form for small emulators (k_halfstep.hip) has summed them already
+static int gp_predict_core(gpemu_model *m, int64_t B, const double *dX, hipStream_t st, bool small_ok = false) {
   GP_TRY(ensure_workspace(m, B));
   ProposeArgs raw;                 // the cross-kernel kernel pads the caller's rows itself
   raw.raw = dX; raw.n = (int)B; raw.d = (int)m->d;
+  if (small_ok && getenv("GPEMU_NO_HALFSTEP") == nullptr && getenv("GPEMU_NO_GROUP_MERGE") == nullptr) {
+    gpemu_model *one[1] = {m};
+    const int rc = launch_halfstep_small(one, 1, B, m->ws.Xq, st, &raw);
+    if (rc != GPEMU_ERR_UNSUPPORTED) return rc;
+  }
   GP_TRY(launch_kstar(m, B, m->ws.Xq, st, &raw));
   GP_TRY(launch_trmm_vsq(m, B, st));
   return GPEMU_OK;
@@ -620,7 +636,7 @@ int gpemu_logpost_dev(gpemu_model *m, int64_t B, const double *dX, double *dout,
   hipStream_t st = stream ? (hipStream_t)stream : m->stream;
   for (int64_t off = 0; off < B; off += MAX_CHUNK) {
     const int64_t nb = (B - off < MAX_CHUNK) ? (B - off) : MAX_CHUNK;
-    GP_TRY(gp_predict_core(m, nb, dX + off * m->d, st));
+    GP_TRY(gp_predict_core(m, nb, dX + off * m->d, st, mode == GPEMU_LOGPOST_LOWRANK));
     if (mode == GPEMU_LOGPOST_LOWRANK) GP_TRY(launch_loglik_lowrank(m, nb, m->ws.Xq, dout + off, 0, st));
     else GP_TRY(launch_loglik_exact(m, nb, m->ws.Xq, dout + off, st));
   }

@@ -219,13 +219,21 @@ def test_observable_blocks_on_different_waves_have_the_bits_of_the_serial_loop(m
         for key, val in out.items():
             for a, b in zip(val, ref):
                 np.testing.assert_array_equal(a, b, err_msg=str(key))
-    # batched log-posterior of one group (gpemu_logpost -> the single-group likelihood launch)
+    # batched log-posterior of one group (gpemu_logpost -> the single-group launches): likelihood with / without tasks,
+    # cross-kernel + GEMM in one launch or two
+    from gpemu import _lib
     Xq = synthetic.make_walkers(50, seed=4, lo=g["design"].min(0), hi=g["design"].max(0))
+    n0 = _lib.lib().gpemu_halfstep_small_launches()
     lp_tasks = dms[2].logpost(Xq)
+    assert _lib.lib().gpemu_halfstep_small_launches() == n0 + 1
     monkeypatch.setenv("GPEMU_NO_LOGLIK_TASKS", "1")
     lp_serial = dms[2].logpost(Xq)
+    monkeypatch.setenv("GPEMU_NO_HALFSTEP", "1")
+    lp_general = dms[2].logpost(Xq)
     monkeypatch.delenv("GPEMU_NO_LOGLIK_TASKS", raising=False)
+    monkeypatch.delenv("GPEMU_NO_HALFSTEP", raising=False)
     np.testing.assert_array_equal(lp_tasks, lp_serial)
+    np.testing.assert_array_equal(lp_tasks, lp_general)
     assert np.isfinite(lp_tasks).any()
     for dm in dms:
         dm.close()
