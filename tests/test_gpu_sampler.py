@@ -341,6 +341,7 @@ def test_groups_in_one_launch_per_stage_equal_the_per_group_launches(monkeypatch
     (97, (16, 17), 37, "matern", 2.5),           # both orders of the likelihood's partial sums (k <= 16, k > 16); ragged halves
     (256, (32,), 256, "matern", 0.5),            # the largest shape the kernel takes: 256 rows, 32 PCs, 128 proposals
     (128, (10,), 64, "rbf", np.inf),
+    (12, (3,), 8, "matern", 1.5),                # fewer design points than one 16-row tile
 ])
 def test_small_emulators_cross_kernel_and_gemm_in_one_launch_have_the_bits_of_the_general_path(N, pcs, W, kind, nu, monkeypatch):
     """Emulators of at most 256 design points (the reference's shipped analysis has ~150): cross-kernel and triangular
@@ -387,6 +388,40 @@ def test_small_emulators_cross_kernel_and_gemm_in_one_launch_have_the_bits_of_th
         np.testing.assert_allclose(lps[-1, w], ref, rtol=1e-9)
     for dm in dms:
         dm.close()
+
+
+@pytest.mark.parametrize("name", ["g1_matern25_const_noise", "g1_rbf_only", "g2_rbf_noise"])
+def test_small_emulator_launch_on_the_reference_fits(name, monkeypatch):
+    """The same comparison on models the REFERENCE fitted (goldens G1 / G2: Matern-2.5 + Const + White with the constant
+    kernel's offset in every cross-kernel value, RBF without noise, N = 50 and 200): chain of the one-launch cross-kernel +
+    GEMM equal to the general path's bit for bit, log-probabilities the oracle's."""
+    from gpemu import _lib, synthetic
+    from gpemu.sampler import DeviceSampler
+    L = _lib.lib()
+    g, model, dm, oracle_lp = _setup(name)
+    monkeypatch.setenv("GPEMU_HALFSTEP_MIN_PAIRS", "0")
+    W = 46
+    X0 = synthetic.make_walkers(W, seed=9, lo=g["lo"], hi=g["hi"])
+    out = {}
+    for form in ("small", "general"):
+        monkeypatch.delenv("GPEMU_NO_HALFSTEP", raising=False)
+        if form == "general":
+            monkeypatch.setenv("GPEMU_NO_HALFSTEP", "1")
+        n0 = L.gpemu_halfstep_small_launches()
+        ds = DeviceSampler([dm], W, seed=77)
+        ds.set_state(X0)
+        ds.run(8)
+        out[form] = ds.get_chain() + (ds.counts()[0],)
+        assert (L.gpemu_halfstep_small_launches() - n0 >= 16) == (form == "small")
+        ds.close()
+    monkeypatch.delenv("GPEMU_NO_HALFSTEP", raising=False)
+    for a, b in zip(out["small"], out["general"]):
+        np.testing.assert_array_equal(a, b)
+    chain, lps = out["small"][0], out["small"][1]
+    ref = oracle_lp(chain[-1, :6])
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(lps[-1, :6][fin], ref[fin], rtol=1e-8)
+    dm.close()
 
 
 # ---- BASELINE configs[3] ("C4") at its full size: the C3 model, 1024 walkers, shares of 128 / 64 proposals ----------
