@@ -31,7 +31,7 @@ python3 $R/tools/bench_closure.py > $OUT/closure_batch.txt 2>&1
 python3 $R/tools/time_lml_batch.py 1000 64 > $OUT/fit_batch.txt 2>&1
 python3 $R/tools/time_fit_c3.py 50 64 >> $OUT/fit_batch.txt 2>&1
 python3 $R/tools/time_lml_batch.py 5000 8 >> $OUT/fit_batch.txt 2>&1
-( cd $R/bayesian-inference_amd/csrc && ./tools/gemm_probe && ./tools/potrf_probe ) > $OUT/fit_probes.txt 2>&1
+( cd $R/bayesian-inference_amd/csrc && make tools > /dev/null 2>&1; ./tools/gemm_probe && ./tools/potrf_probe ) > $OUT/fit_probes.txt 2>&1
 ( cd $R/bayesian-inference_amd/csrc/tools && ./kstar_probe 1000 512 && ./kstar_probe 1000 64 && ./kstar_probe 1000 1024 10 7 2 ) > $OUT/kstar_probe.txt 2>&1
 python3 $R/tools/time_exact.py > $OUT/time_exact.txt 2>&1
 python3 $R/tools/run_dropin_c3.py 50 1000 10000 > $OUT/dropin_c3_end_to_end.txt 2>&1
