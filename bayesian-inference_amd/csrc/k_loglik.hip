@@ -470,35 +470,58 @@ int launch_loglik_tasks(gpemu_model *const *ms, int ng, int64_t B, const double 
     lt.terms = m0->lik_terms;
     lt.tickets = m0->lik_tickets;
   }
-  struct T { double cost; int g, o; };
-  std::vector<T> tasks;
   for (int g = 0; g < ng; ++g) {
     const gpemu_model *m = ms[g];
     const Workspace &w = m->ws;
     lt.g[g] = LoglikGroup{m->lo, m->hi, w.mean_part, w.vsq_part, m->kdiag, m->G, m->g0, m->scal, w.mean, w.var, w.Bcap,
                           (int)m->k, w.cur_nchunk, w.cur_nrb, (int)m->nblk};
     lt.first[g + 1] = lt.first[g] + (int)m->nblk;
-    const double kk = (double)((m->k + 3) / 4 * 4);
-    for (int o = 0; o < (int)m->nblk; ++o) tasks.push_back(T{kk * kk + 8.0 * kk + 40.0, g, o});   // (factorisation + row loads + fixed part)
   }
-  // longest first, each to the wave with the least so far (waves of the first workgroups first: they are dispatched first)
-  std::stable_sort(tasks.begin(), tasks.end(), [](const T &a, const T &b) { return a.cost > b.cost; });
-  const int nslots = lt.nwg * LL_TASK_WAVES;
-  std::vector<std::vector<T>> per(nslots);
-  std::vector<double> load(nslots, 0.0);
-  for (const T &t : tasks) {
-    int best = 0;
-    for (int w2 = 1; w2 < nslots; ++w2)
-      if (load[w2] < load[best]) best = w2;
-    per[best].push_back(t);
-    load[best] += t.cost;
+  // who takes which task: longest first, each to the wave with the least so far (waves of the first workgroups first: they
+  // are dispatched first).  Depends on the groups' (PCs, blocks) only: kept per host thread for the next launch.
+  struct Deal { int ng, k[LL_GROUPS_MAX], nblk[LL_GROUPS_MAX]; unsigned char tg[LL_TASKS_MAX], to[LL_TASKS_MAX], wstart[LL_TASKS_MAX + 1]; };
+  static thread_local std::vector<Deal> deals;
+  const Deal *deal = nullptr;
+  for (const Deal &dl : deals) {
+    bool same = dl.ng == ng;
+    for (int g = 0; same && g < ng; ++g) same = dl.k[g] == (int)ms[g]->k && dl.nblk[g] == (int)ms[g]->nblk;
+    if (same) { deal = &dl; break; }
   }
-  int n = 0;
-  for (int w2 = 0; w2 < nslots; ++w2) {
-    lt.wstart[w2] = (unsigned char)n;
-    for (const T &t : per[w2]) { lt.tg[n] = (unsigned char)t.g; lt.to[n] = (unsigned char)t.o; ++n; }
+  if (!deal) {
+    struct T { double cost; int g, o; };
+    std::vector<T> tasks;
+    for (int g = 0; g < ng; ++g) {
+      const double kk = (double)((ms[g]->k + 3) / 4 * 4);
+      for (int o = 0; o < (int)ms[g]->nblk; ++o) tasks.push_back(T{kk * kk + 8.0 * kk + 40.0, g, o});   // (factorisation + row loads + fixed part)
+    }
+    std::stable_sort(tasks.begin(), tasks.end(), [](const T &a, const T &b) { return a.cost > b.cost; });
+    const int nslots = lt.nwg * LL_TASK_WAVES;
+    std::vector<std::vector<T>> per(nslots);
+    std::vector<double> load(nslots, 0.0);
+    for (const T &t : tasks) {
+      int best = 0;
+      for (int w2 = 1; w2 < nslots; ++w2)
+        if (load[w2] < load[best]) best = w2;
+      per[best].push_back(t);
+      load[best] += t.cost;
+    }
+    Deal dl;
+    memset(&dl, 0, sizeof(dl));
+    dl.ng = ng;
+    for (int g = 0; g < ng; ++g) { dl.k[g] = (int)ms[g]->k; dl.nblk[g] = (int)ms[g]->nblk; }
+    int n = 0;
+    for (int w2 = 0; w2 < nslots; ++w2) {
+      dl.wstart[w2] = (unsigned char)n;
+      for (const T &t : per[w2]) { dl.tg[n] = (unsigned char)t.g; dl.to[n] = (unsigned char)t.o; ++n; }
+    }
+    for (int w2 = nslots; w2 <= LL_TASKS_MAX; ++w2) dl.wstart[w2] = (unsigned char)n;
+    if (deals.size() >= 16) deals.erase(deals.begin());
+    deals.push_back(dl);
+    deal = &deals.back();
   }
-  for (int w2 = nslots; w2 <= LL_TASKS_MAX; ++w2) lt.wstart[w2] = (unsigned char)n;
+  memcpy(lt.tg, deal->tg, sizeof(lt.tg));
+  memcpy(lt.to, deal->to, sizeof(lt.to));
+  memcpy(lt.wstart, deal->wstart, sizeof(lt.wstart));
   const AcceptArgs a = aa ? *aa : AcceptArgs();
   hipLaunchKernelGGL(loglik_tasks_kernel, dim3((unsigned)(B * lt.nwg)), dim3(64 * LL_TASK_WAVES), 0, st, dXq, lt, dout, B,
                      (int)ms[0]->d, accumulate, a);

@@ -257,6 +257,7 @@ def test_phase_api_slices_of_eight_ranks_equal_single(world):
                 _lib.check(L.gpemu_sampler_half_propose_eval(a._h, h, lo, hi, C.c_void_p(mine.data_ptr())))
                 torch.cuda.synchronize()
                 full[r * per:(r + 1) * per] = mine
+            torch.cuda.synchronize()          # (the copies into `full` ran on torch's stream, the accept runs on the sampler's)
             _lib.check(L.gpemu_sampler_half_accept(a._h, h, C.c_void_p(full.data_ptr()), 1))
         _lib.check(L.gpemu_sampler_end_step(a._h, 1))
     assert L.gpemu_sampler_check(a._h) == 0
@@ -324,6 +325,7 @@ def test_groups_in_one_launch_per_stage_equal_the_per_group_launches(monkeypatch
                     _lib.check(L.gpemu_sampler_half_propose_eval(a._h, h, l0, h0, C.c_void_p(mine.data_ptr())))
                     torch.cuda.synchronize()
                     full[r * per:(r + 1) * per] = mine
+                torch.cuda.synchronize()          # (the copies into `full` ran on torch's stream, the accept runs on the sampler's)
                 _lib.check(L.gpemu_sampler_half_accept(a._h, h, C.c_void_p(full.data_ptr()), 1))
             _lib.check(L.gpemu_sampler_end_step(a._h, 1))
         ca, la = a.get_chain()
@@ -476,6 +478,7 @@ def test_c4_full_size_eight_slices_equal_single_gpu_chain():
                 _lib.check(L.gpemu_sampler_half_propose_eval(a._h, h, lo, hi, C.c_void_p(mine.data_ptr())))
                 torch.cuda.synchronize()
                 full[r * per:(r + 1) * per] = mine
+            torch.cuda.synchronize()          # (the copies into `full` ran on torch's stream, the accept runs on the sampler's)
             _lib.check(L.gpemu_sampler_half_accept(a._h, h, C.c_void_p(full.data_ptr()), 1))
         _lib.check(L.gpemu_sampler_end_step(a._h, 1))
     assert L.gpemu_sampler_check(a._h) == 0
