@@ -254,6 +254,7 @@ def test_phase_api_slices_of_eight_ranks_equal_single(world):
                 lo, hi, _ = shard_bounds(n, world, r)
                 sizes.append(hi - lo)
                 mine = torch.zeros(per, dtype=torch.float64, device=dev)
+                torch.cuda.synchronize()      # (the fill runs on torch's stream, the evaluation on the sampler's)
                 _lib.check(L.gpemu_sampler_half_propose_eval(a._h, h, lo, hi, C.c_void_p(mine.data_ptr())))
                 torch.cuda.synchronize()
                 full[r * per:(r + 1) * per] = mine
@@ -322,6 +323,7 @@ def test_groups_in_one_launch_per_stage_equal_the_per_group_launches(monkeypatch
                 for r in range(3):
                     l0, h0, _ = shard_bounds(n, 3, r)
                     mine = torch.zeros(per, dtype=torch.float64, device=dev)
+                    torch.cuda.synchronize()      # (the fill runs on torch's stream, the evaluation on the sampler's)
                     _lib.check(L.gpemu_sampler_half_propose_eval(a._h, h, l0, h0, C.c_void_p(mine.data_ptr())))
                     torch.cuda.synchronize()
                     full[r * per:(r + 1) * per] = mine
@@ -475,6 +477,7 @@ def test_c4_full_size_eight_slices_equal_single_gpu_chain():
             for r in range(world):
                 lo, hi, _ = shard_bounds(n, world, r)
                 mine = torch.zeros(per, dtype=torch.float64, device=dev)
+                torch.cuda.synchronize()      # (the fill runs on torch's stream, the evaluation on the sampler's)
                 _lib.check(L.gpemu_sampler_half_propose_eval(a._h, h, lo, hi, C.c_void_p(mine.data_ptr())))
                 torch.cuda.synchronize()
                 full[r * per:(r + 1) * per] = mine
