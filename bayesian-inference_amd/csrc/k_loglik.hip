@@ -451,9 +451,13 @@ int launch_loglik_tasks(gpemu_model *const *ms, int ng, int64_t B, const double 
   lt.ng = ng;
   lt.ntask = ntask;
   lt.nwg = (ntask + LL_TASK_WAVES - 1) / LL_TASK_WAVES;
-  // several workgroups per proposal pay ~3.5 us for the last one's detour through memory: worth it while the proposals
-  // alone leave most of the chip idle (the shipped ensembles: 50 - 100 per half-step), not for a large batch
-  if (lt.nwg > 1 && B > 256) return GPEMU_ERR_UNSUPPORTED;
+  // A wave per task pays where the proposals alone leave most of the chip idle (the shipped ensembles: 50 - 100 per half-step:
+  // 78 -> 19 us per launch) or a proposal has many blocks; measured at C3 size, 512 proposals per half-step
+  // (tools/time_c3_blocks.py): 10 blocks 0.2714 -> 0.2634 ms per step, 5 blocks 0.2476 -> 0.2499, 2 blocks 0.2344 -> 0.2364
+  {
+    const char *e = getenv("GPEMU_LOGLIK_TASKS_MAX_ROWS");
+    if (B > (e ? atoll(e) : 256) && ntask < 8) return GPEMU_ERR_UNSUPPORTED;
+  }
   if (lt.nwg > 1) {
     // the terms' way to the last workgroup: per model (the first group's), grown with the batch
     if (m0->lik_terms_cap < B) {
