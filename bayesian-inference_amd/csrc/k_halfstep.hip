@@ -11,8 +11,8 @@
 //     1  stretch proposal of the block's 32 walkers (ref: emcee moves/stretch.py) -> LDS
 //     2  K_*^T[j][b] for the N real rows on the matrix cores (predict_dev.h), kept in LDS -- never written to memory;
 //        per 16-row tile the partial mean  sum_j alpha_j K_*[j][b]
-//     3  V = W_p K_*^T by 32-row blocks, k-tiles up to the diagonal, the eight waves splitting K (k_trmm_small.hip);
-//        per block the column sums of V^2
+//     3  V = W_p K_*^T by 32-row blocks, k-tiles up to the diagonal, K split over the waves in the eight slices of
+//        k_trmm_small.hip (two per wave, one exchange per block); per block the column sums of V^2
 //     4  the partial sums are added IN THE ORDER the three-launch path adds them (cross-kernel: two 16-row tiles per
 //        32-row chunk, then the likelihood's walker_mean_sd order; GEMM: 32-row blocks, same order): mean and
 //        ||W k_*||^2 of (b, p) are final and go to mean_part / vsq_part as ONE chunk / ONE row block
@@ -37,7 +37,7 @@ namespace gpemu {
 static std::atomic<int64_t> g_halfstep_launches{0};
 #ifdef GPEMU_HS_STAMPS          // diagnostic build (make HS_STAMPS=1; tools/hs_stamps.py): clock64 at the phase boundaries, wave 0 of 3 workgroups
 __device__ long long g_hs_stamps[3][32];
-__device__ long long g_hs_wall[512][4];     // per workgroup: wall_clock64 (100 MHz, one counter for the chip) at start / ticket seen / end
+__device__ long long g_hs_wall[512][4];     // per workgroup: wall_clock64 (100 MHz, one counter for the chip) at start / - / end
 #define HS_WALL(i) do { if (threadIdx.x == 0 && blockIdx.x < 512) g_hs_wall[blockIdx.x][i] = wall_clock64(); } while (0)
 #define HS_STAMP(i) do { if (lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 64 || blockIdx.x == gridDim.x - 9)) g_hs_stamps[blockIdx.x == 0 ? 0 : (blockIdx.x == 64 ? 1 : 2)][i] = clock64(); } while (0)
 #else
